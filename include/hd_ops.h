@@ -1,0 +1,277 @@
+/*
+ * hd_ops.h — C ABI of the MI355X (gfx950) detection hot-path library, libhd_ops.so.
+ *
+ * What this replaces.  Scienthusiasts/HeltonDetection is a pure-PyTorch detector
+ * framework (reference README.md:2) whose FasterRCNN (README.md:8) and YOLOv5
+ * (README.md:9) heads/assigners/post-processing call PyTorch ops for anchors, IoU,
+ * NMS, RoIAlign (README.md:65,73), grid decode, box loss and WBF (README.md:19).
+ * The mounted reference snapshot holds NO source (README + two images only,
+ * SURVEY.md §0), so no reference signature can be cited beyond those README lines;
+ * each entry point below names the README line of the feature it serves and the
+ * public algorithm definition it implements.  Parity is therefore pinned to this
+ * repo's own CPU restatement under oracle/ ("parity unpinned").
+ *
+ * Contract:
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host".
+ *   - the caller owns all memory; the library never allocates, frees or synchronises.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - scratch memory comes from a caller-provided workspace; each op with a
+ *     workspace has a companion *_workspace_bytes() query (pure host arithmetic).
+ *   - return value: HD_OK (0) or a negative hd_status; nothing is thrown.
+ *   - re-entrant and thread-safe given distinct workspaces/outputs.
+ *   - boxes are float32 xyxy in continuous pixel coordinates (no legacy +1).
+ *   - all tensors are dense row-major in the shape written next to them unless
+ *     explicit element strides are part of the signature.
+ *
+ * Conventions (IoU formula, tie-breaks, RoIAlign sampling, ...) are frozen in
+ * DESIGN.md §2 and restated in oracle/hd_oracle.c, the checker for every function.
+ */
+#ifndef HD_OPS_H
+#define HD_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int hd_status;
+typedef void* hd_stream; /* hipStream_t */
+
+#define HD_OK 0
+#define HD_ERR_NULL (-1)       /* required pointer is NULL            */
+#define HD_ERR_SHAPE (-2)      /* a size/shape argument is out of range */
+#define HD_ERR_ALIGN (-3)      /* pointer not aligned as documented   */
+#define HD_ERR_WORKSPACE (-4)  /* workspace missing or too small      */
+#define HD_ERR_LAUNCH (-5)     /* hipLaunch / hipMemsetAsync failed   */
+#define HD_ERR_NO_DEVICE (-6)  /* no HIP device visible               */
+
+#define HD_MAX_LEVELS 8   /* pyramid levels one call may carry */
+#define HD_MAX_ANCHORS 16 /* anchors per location              */
+
+/* ---- library / device ------------------------------------------------------ */
+
+/* ABI version, bumped on any signature change. */
+int hd_abi_version(void);
+/* Human-readable status text (static storage). */
+const char* hd_status_str(hd_status s);
+/* Number of visible HIP devices (0 on a CPU-only host); never throws. */
+int hd_device_count(void);
+
+/* ---- anchors (FasterRCNN RPN, README.md:8) --------------------------------- */
+
+/* HOST helper. Base anchors for one level: for each ratio r (=h/w) then each size z:
+ *   hr = sqrtf(r); w = z / hr; h = z * hr; anchor = (-w/2, -h/2, w/2, h/2).
+ * out_base: host [n_ratios*n_sizes, 4].  Pure host arithmetic, no GPU. */
+hd_status hd_anchor_base(const float* sizes, int n_sizes, const float* ratios, int n_ratios,
+                         float* out_base);
+
+/* Tiles per-level base anchors over the feature grids.
+ * Order of the output is level-major, then y, x, anchor:
+ *   out[off_l + ((y*W_l + x)*A + a)] = base_l[a] + ((x+offset)*stride_l, (y+offset)*stride_l) x2
+ * feat_h, feat_w, strides: host [n_levels]; base_anchors: host [n_levels, A, 4];
+ * out: device [sum_l H_l*W_l*A, 4], 16-byte aligned. */
+hd_status hd_anchor_grid(int n_levels, const int* feat_h, const int* feat_w, const float* strides,
+                         const float* base_anchors, int A, float offset, float* out,
+                         hd_stream stream);
+
+/* ---- pairwise IoU (assigners; SURVEY.md §8a "Batched pairwise IoU") -------- */
+
+/* Materialised IoU.  a: [B,N,4], b: [B,M,4], m_valid: [B] int32 or NULL (all M valid),
+ * out: [B,N,M].  Columns m >= m_valid[b] are written as -1.
+ * iou = inter / (area_a + area_b - inter), 0 when the union is <= 0.
+ * a, b must be 16-byte aligned. */
+hd_status hd_pairwise_iou(const float* a, const float* b, const int32_t* m_valid, int B, int N,
+                          int M, float* out, hd_stream stream);
+
+/* Fused IoU + row max/argmax (per box in a) + column max/argmax (per box in b),
+ * without materialising [B,N,M].
+ *   max_iou[B,N], argmax[B,N]  : best b for each a  (ties -> lowest m); -1/-1 if no valid b.
+ *   gt_max_iou[B,M], gt_argmax[B,M]: best a for each b (ties -> lowest n); -1/-1 for padded b.
+ * gt_* may both be NULL to skip the column reduction (then workspace may be NULL). */
+size_t hd_iou_assign_workspace_bytes(int B, int N, int M);
+hd_status hd_iou_assign(const float* a, const float* b, const int32_t* m_valid, int B, int N,
+                        int M, float* max_iou, int32_t* argmax, float* gt_max_iou,
+                        int32_t* gt_argmax, void* workspace, size_t workspace_bytes,
+                        hd_stream stream);
+
+/* ---- box delta codec (RPN / RoI head regression targets) ------------------- */
+
+/* deltas = encode(src -> dst): dx=(cx_d-cx_s)/w_s, dy, dw=log(w_d/w_s), dh. src,dst,out: [n,4]. */
+hd_status hd_box_encode(const float* src, const float* dst, int64_t n, float* out_deltas,
+                        hd_stream stream);
+/* boxes = decode(anchors, deltas) with dw,dh clamped to <= log(1000/16), then clipped to
+ * [0,img_w] x [0,img_h] when img_w > 0.  anchors, deltas, out: [n,4]. */
+hd_status hd_box_decode(const float* anchors, const float* deltas, int64_t n, float img_h,
+                        float img_w, float* out_boxes, hd_stream stream);
+
+/* ---- NMS (RPN class-agnostic / YOLOv5 per-class) ------------ */
+
+/* Batched greedy NMS, exact (bit-identical to the serial algorithm):
+ *   candidates of image b = { i < n_valid[b] : scores[b,i] > score_thr } (NaN never passes);
+ *   order = score descending, ties -> lower index i; only the first `max_candidates`
+ *   of that order are considered (<=0: all);
+ *   box j is suppressed by an earlier kept box i iff (cls==NULL || cls[i]==cls[j]) and
+ *   iou(i,j) > iou_thr (strict);
+ *   keep[b, 0:count] = kept indices i in that order, stops at max_out; tail = -1.
+ * boxes [B,N,4] (16-B aligned), scores [B,N], cls [B,N] int32 or NULL, n_valid [B] or NULL. */
+size_t hd_nms_workspace_bytes(int B, int N, int max_candidates);
+hd_status hd_nms_batched(const float* boxes, const float* scores, const int32_t* cls,
+                         const int32_t* n_valid, int B, int N, float score_thr, float iou_thr,
+                         int max_candidates, int max_out, int32_t* keep, int32_t* keep_count,
+                         void* workspace, size_t workspace_bytes, hd_stream stream);
+
+/* ---- RPN proposals (README.md:8; SURVEY.md §8a "RPN proposal top-K + NMS") -- */
+
+/* Per image: per level top-`pre_nms_topk` by objectness logit (ties -> lower index),
+ * decode deltas against anchors, clip to the image, drop boxes with w or h < min_size,
+ * NMS per level (level acts as the class id), keep the best `post_nms_topk` overall
+ * by logit.  Outputs are padded with zeros; scores are sigmoid(logit).
+ * logits [B,NA], deltas [B,NA,4], anchors [NA,4] in the hd_anchor_grid order,
+ * level_sizes: host [n_levels], sum = NA.  rois [B,post,4], roi_scores [B,post], count [B]. */
+size_t hd_rpn_proposals_workspace_bytes(int B, int NA, int n_levels, int pre_nms_topk,
+                                        int post_nms_topk);
+hd_status hd_rpn_proposals(const float* logits, const float* deltas, const float* anchors, int B,
+                           int NA, int n_levels, const int* level_sizes, int pre_nms_topk,
+                           int post_nms_topk, float iou_thr, float min_size, float img_h,
+                           float img_w, float* rois, float* roi_scores, int32_t* count,
+                           void* workspace, size_t workspace_bytes, hd_stream stream);
+
+/* ---- RoIAlign over pyramid levels (README.md:65,73) ------------------------ */
+
+typedef struct hd_roi_levels {
+  int n_levels;                       /* 1..HD_MAX_LEVELS                                  */
+  const float* feat[HD_MAX_LEVELS];   /* device base pointer of each level's feature map   */
+  int h[HD_MAX_LEVELS], w[HD_MAX_LEVELS];
+  float spatial_scale[HD_MAX_LEVELS]; /* 1/stride                                          */
+  int64_t sb[HD_MAX_LEVELS], sc[HD_MAX_LEVELS], sh[HD_MAX_LEVELS], sw[HD_MAX_LEVELS];
+                                      /* element strides of (batch, channel, y, x)          */
+  int k_min;                          /* pyramid level number of feat[0] (e.g. 2 for P2)    */
+  float canonical_scale;              /* 224                                               */
+  int canonical_level;                /* 4                                                 */
+} hd_roi_levels;
+
+/* Level of a RoI (exact form of floor(k0 + log2(sqrt(area)/s0)), clamped):
+ *   lvl = #{k in (k_min, k_max] : area >= (s0 * 2^(k-k0))^2}   (index into feat[]).
+ * rois [R,5] = (batch_index, x1, y1, x2, y2); out_level [R] int32. */
+hd_status hd_roi_level_map(const float* rois, int R, int k_min, int n_levels,
+                           float canonical_scale, int canonical_level, int32_t* out_level,
+                           hd_stream stream);
+
+/* Forward. out[r,c,ph,pw] with element strides (out_sr,out_sc,out_sh,out_sw).
+ * Bilinear sampling as the public RoIAlign definition: bin grid sampling_ratio^2 points
+ * (<=0: adaptive ceil(roi_size/P)); aligned!=0 shifts by -0.5 px and allows sub-pixel RoIs,
+ * aligned==0 forces roi size >= 1; samples outside [-1, size] contribute 0. */
+hd_status hd_roi_align_fwd(const hd_roi_levels* levels, const float* rois, int R, int C, int P,
+                           int sampling_ratio, int aligned, float* out, int64_t out_sr,
+                           int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream);
+
+/* Backward: scatter-adds grad_out into grad_feat (same struct, feat[] = grad buffers, which
+ * the caller has zeroed).  Uses float atomics: summation order is not fixed. */
+hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, int R, int C,
+                           int P, int sampling_ratio, int aligned, const float* grad_out,
+                           int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw,
+                           hd_stream stream);
+
+/* ---- YOLOv5 head ops (README.md:9) ----------------------------------------- */
+
+typedef struct hd_yolo_levels {
+  int n_levels;                      /* 1..HD_MAX_LEVELS                                    */
+  int na;                            /* anchors per cell (<= HD_MAX_ANCHORS)                */
+  int no;                            /* 5 + num_classes                                     */
+  float* pred[HD_MAX_LEVELS];        /* raw head output of each level (or its grad buffer)  */
+  int h[HD_MAX_LEVELS], w[HD_MAX_LEVELS];
+  float stride[HD_MAX_LEVELS];
+  float anchor_w[HD_MAX_LEVELS][HD_MAX_ANCHORS]; /* pixels */
+  float anchor_h[HD_MAX_LEVELS][HD_MAX_ANCHORS];
+  /* element strides of pred viewed as [B, na, H, W, no] */
+  int64_t sb[HD_MAX_LEVELS], sa[HD_MAX_LEVELS], sy[HD_MAX_LEVELS], sx[HD_MAX_LEVELS],
+      so[HD_MAX_LEVELS];
+} hd_yolo_levels;
+
+/* Grid decode (v6.1 form): xy=(2*sig(t)-0.5+grid)*stride, wh=(2*sig(t))^2*anchor, sig(rest).
+ * out [B, n_total, no] = (cx, cy, w, h, obj, cls...), rows ordered level, anchor, y, x. */
+hd_status hd_yolo_decode(const hd_yolo_levels* lv, int B, float* out, hd_stream stream);
+
+/* Target assignment (anchor-shape matching + 2 neighbour cells, v6.1 build_targets form).
+ * gt_boxes [B,M,4] xyxy pixels, gt_cls [B,M] int32, m_valid [B].
+ * Fixed slot layout per level: slot = ((k*na + a)*B + b)*M + t, k in 0..4
+ * (0 centre, 1 left, 2 up, 3 right, 4 down).
+ *   slot_cell [n_levels, S] int32 = ((b*na + a)*H + gj)*W + gi, or -1 when unmatched
+ *   slot_tbox [n_levels, S, 4]    = (gx - gi, gy - gj, gw, gh) in grid units
+ *   slot_cls  [n_levels, S] int32
+ * S = 5*na*B*M. */
+hd_status hd_yolo_assign(const hd_yolo_levels* lv, const float* gt_boxes, const int32_t* gt_cls,
+                         const int32_t* m_valid, int B, int M, float anchor_t,
+                         int32_t* slot_cell, float* slot_tbox, int32_t* slot_cls,
+                         hd_stream stream);
+
+typedef struct hd_yolo_loss_cfg {
+  float box_gain, obj_gain, cls_gain; /* hyp.box, hyp.obj, hyp.cls (already rescaled)        */
+  float balance[HD_MAX_LEVELS];       /* objectness weight per level                         */
+} hd_yolo_loss_cfg;
+
+/* Loss forward.  tobj [sum_l B*na*H_l*W_l] scratch (objectness targets, level-major),
+ * acc [n_levels*4] float scratch (sum(1-ciou), n_pos, sum bce_cls, sum bce_obj per level),
+ * loss_out [4] = (total, lbox, lobj, lcls) with
+ *   lbox = box_gain * sum_l mean(1-ciou); lcls = cls_gain * sum_l mean BCE(cls);
+ *   lobj = obj_gain * sum_l balance_l * mean BCE(obj, tobj); total = B*(lbox+lobj+lcls);
+ *   tobj[cell] = max over slots on that cell of clamp(ciou, 0)  (duplicates -> max). */
+size_t hd_yolo_loss_workspace_bytes(const hd_yolo_levels* lv, int B);
+hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, const int32_t* slot_cell,
+                           const float* slot_tbox, const int32_t* slot_cls,
+                           const hd_yolo_loss_cfg* cfg, float* loss_out, void* workspace,
+                           size_t workspace_bytes, hd_stream stream);
+/* Loss backward: writes d(total)/d(pred) * grad_scale[0] densely into grad_lv->pred[l]
+ * (same strides as lv).  workspace must be the one hd_yolo_loss_fwd filled.
+ * grad_scale: device [1] float (upstream gradient of `total`). */
+hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                           const int32_t* slot_cell, const float* slot_tbox,
+                           const int32_t* slot_cls, const hd_yolo_loss_cfg* cfg,
+                           const float* grad_scale, const void* workspace,
+                           size_t workspace_bytes, hd_stream stream);
+
+/* ---- CIoU on matched pairs (SURVEY.md §8a "CIoU loss fwd + bwd") ----------- */
+
+/* pred, target [P,4] xyxy; ciou [P]; loss = 1 - ciou is left to the caller.
+ * eps = 1e-7 placed as in the public v6.1 bbox_iou: h += eps, union += eps, c2 += eps;
+ * alpha = v / (v - iou + 1 + eps) is treated as a constant in backward. */
+hd_status hd_ciou_fwd(const float* pred, const float* target, int64_t P, float* ciou,
+                      hd_stream stream);
+/* grad_pred [P,4] = grad_ciou[p] * d ciou / d pred. */
+hd_status hd_ciou_bwd(const float* pred, const float* target, const float* grad_ciou, int64_t P,
+                      float* grad_pred, hd_stream stream);
+
+/* ---- YOLOv5 post-processing ------------------------------------------------- */
+
+/* From decoded predictions dec [B,n,no]: candidates with obj > conf_thr and
+ * conf = obj*max_cls > conf_thr (best class only), per-class NMS (iou_thr), best `max_det`.
+ * det [B,max_det,6] = (x1,y1,x2,y2,conf,cls), zero padded; det_count [B].
+ * Candidate order = conf descending, ties -> lower row index; at most max_nms candidates. */
+size_t hd_yolo_nms_workspace_bytes(int B, int n, int max_nms);
+hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float conf_thr, float iou_thr,
+                      int max_nms, int max_det, float* det, int32_t* det_count, void* workspace,
+                      size_t workspace_bytes, hd_stream stream);
+
+/* ---- Weighted Boxes Fusion (README.md:19) ---------------------------------- */
+
+/* Per image: boxes [B,K,4], scores [B,K], labels [B,K] int32, model_weight [B,K] (weight of the
+ * TTA view each box came from), k_valid [B].  Boxes with score < skip_thr are dropped; per
+ * label, boxes are visited by weighted score descending (ties -> lower index) and join the
+ * cluster whose fused box has the highest IoU > iou_thr (ties -> older cluster), else open one;
+ * the fused box is the confidence-weighted mean (conf = score*model_weight), fused score =
+ * sum(conf)/n * min(n, weight_sum)/weight_sum with weight_sum = sum of the view weights
+ * (= number of views when all weights are 1; "avg" confidence).  out [B,K,6] = (x1,y1,x2,y2,score,label) sorted by
+ * score descending (ties -> lower label, then older cluster), zero padded; out_count [B]. */
+size_t hd_wbf_workspace_bytes(int B, int K);
+hd_status hd_wbf(const float* boxes, const float* scores, const int32_t* labels,
+                 const float* model_weight, const int32_t* k_valid, int B, int K, float weight_sum,
+                 float iou_thr, float skip_thr, float* out, int32_t* out_count, void* workspace,
+                 size_t workspace_bytes, hd_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HD_OPS_H */
