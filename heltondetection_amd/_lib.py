@@ -1,0 +1,124 @@
+"""ctypes binding of libhd_ops.so (include/hd_ops.h).  No fallback: if the HIP library is missing
+or a call fails, this raises — the product never routes around the kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
+ABI_VERSION = 1
+MAX_LEVELS = 8
+MAX_ANCHORS = 16
+
+
+class HdError(RuntimeError):
+    pass
+
+
+class RoiLevels(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int),
+        ("feat", C.c_void_p * MAX_LEVELS),
+        ("h", C.c_int * MAX_LEVELS),
+        ("w", C.c_int * MAX_LEVELS),
+        ("spatial_scale", C.c_float * MAX_LEVELS),
+        ("sb", C.c_int64 * MAX_LEVELS),
+        ("sc", C.c_int64 * MAX_LEVELS),
+        ("sh", C.c_int64 * MAX_LEVELS),
+        ("sw", C.c_int64 * MAX_LEVELS),
+        ("k_min", C.c_int),
+        ("canonical_scale", C.c_float),
+        ("canonical_level", C.c_int),
+    ]
+
+
+class YoloLevels(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int),
+        ("na", C.c_int),
+        ("no", C.c_int),
+        ("pred", C.c_void_p * MAX_LEVELS),
+        ("h", C.c_int * MAX_LEVELS),
+        ("w", C.c_int * MAX_LEVELS),
+        ("stride", C.c_float * MAX_LEVELS),
+        ("anchor_w", (C.c_float * MAX_ANCHORS) * MAX_LEVELS),
+        ("anchor_h", (C.c_float * MAX_ANCHORS) * MAX_LEVELS),
+        ("sb", C.c_int64 * MAX_LEVELS),
+        ("sa", C.c_int64 * MAX_LEVELS),
+        ("sy", C.c_int64 * MAX_LEVELS),
+        ("sx", C.c_int64 * MAX_LEVELS),
+        ("so", C.c_int64 * MAX_LEVELS),
+    ]
+
+
+class YoloLossCfg(C.Structure):
+    _fields_ = [
+        ("box_gain", C.c_float),
+        ("obj_gain", C.c_float),
+        ("cls_gain", C.c_float),
+        ("balance", C.c_float * MAX_LEVELS),
+    ]
+
+
+_P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); exactly the entry points declared in include/hd_ops.h
+SIGNATURES = {
+    "hd_abi_version": (C.c_int, []),
+    "hd_status_str": (C.c_char_p, [_I]),
+    "hd_device_count": (C.c_int, []),
+    "hd_anchor_base": (_I, [_P, _I, _P, _I, _P]),
+    "hd_anchor_grid": (_I, [_I, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "hd_pairwise_iou": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P]),
+    "hd_iou_assign_workspace_bytes": (_Z, [_I, _I, _I]),
+    "hd_iou_assign": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_box_encode": (_I, [_P, _P, _L, _P, _P]),
+    "hd_box_decode": (_I, [_P, _P, _L, _F, _F, _P, _P]),
+    "hd_nms_workspace_bytes": (_Z, [_I, _I, _I]),
+    "hd_nms_batched": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "hd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "hd_rpn_proposals": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "hd_roi_level_map": (_I, [_P, _I, _I, _I, _F, _I, _P, _P]),
+    "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
+    "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
+    "hd_yolo_decode": (_I, [_P, _I, _P, _P]),
+    "hd_yolo_assign": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "hd_yolo_loss_workspace_bytes": (_Z, [_P, _I]),
+    "hd_yolo_loss_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_ciou_fwd": (_I, [_P, _P, _L, _P, _P]),
+    "hd_ciou_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
+    "hd_yolo_nms_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "hd_yolo_nms": (_I, [_P, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "hd_wbf_workspace_bytes": (_Z, [_I, _I]),
+    "hd_wbf": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libhd_ops.so; raises HdError if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HdError(f"{SO_PATH} not found: build the HIP extension first "
+                      "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.hd_abi_version()
+    if v != ABI_VERSION:
+        raise HdError(f"libhd_ops.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().hd_status_str(status).decode()
+        raise HdError(f"{what} failed: {msg} ({status})")

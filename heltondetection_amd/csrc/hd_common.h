@@ -1,0 +1,76 @@
+// hd_common.h — shared device helpers for the gfx950 detection kernels.
+//
+// Everything here is compiled with -ffp-contract=off: the box arithmetic must round exactly
+// like oracle/hd_oracle.c (same expression order, no FMA contraction) because NMS keep masks
+// and argmax indices are compared bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hd_ops.h"
+
+#define HD_WAVE 64
+
+#define HD_RETURN_IF_LAUNCH_FAILED()                 \
+  do {                                               \
+    if (hipGetLastError() != hipSuccess) return HD_ERR_LAUNCH; \
+  } while (0)
+
+static inline bool hd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t hd_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int hd_next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// IoU of xyxy boxes — expression order is the oracle's iou_xyxy().
+__device__ __forceinline__ float hd_box_area(const float4 a) { return (a.z - a.x) * (a.w - a.y); }
+
+__device__ __forceinline__ float hd_iou_full(const float4 a, const float area_a, const float4 b,
+                                             const float area_b) {
+  float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  iw = iw > 0.0f ? iw : 0.0f;
+  ih = ih > 0.0f ? ih : 0.0f;
+  float inter = iw * ih;
+  float uni = (area_a + area_b) - inter;
+  return uni > 0.0f ? inter / uni : 0.0f;
+}
+
+// True iff the boxes overlap with positive width and height (then and only then IoU can be > 0).
+__device__ __forceinline__ bool hd_overlaps(const float4 a, const float4 b) {
+  float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  return (iw > 0.0f) && (ih > 0.0f);
+}
+
+__device__ __forceinline__ float hd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float hd_bce_logits(float x, float z) {
+  return fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// order-preserving float -> uint32 (larger float -> larger key)
+__device__ __forceinline__ uint32_t hd_f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float hd_key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// 64-lane sum / max reductions (result valid in every lane for xor butterflies)
+__device__ __forceinline__ float hd_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int hd_wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int hd_lane() { return threadIdx.x & 63; }

@@ -1,0 +1,283 @@
+// iou.hip — batched pairwise IoU for gfx950 (SURVEY.md §8a "Batched pairwise IoU").
+//
+// Two kernels, both memory-layout driven (no MFMA: there is no inner product here):
+//
+//  pairwise_iou_kernel   materialises out[B,N,M].  HBM-write bound: 4*N*M bytes out against
+//                        16*(N+M) in.  Each lane owns 4 consecutive outputs of the flat [N*M]
+//                        row space and stores them with one 16-byte store, so a wave writes
+//                        1 KiB contiguous per store instruction.  The b boxes (ground truth)
+//                        and their areas are staged once per workgroup in LDS and read back
+//                        as wave-uniform broadcasts; a boxes come through L1 (4 consecutive
+//                        outputs almost always share one a box).
+//
+//  iou_assign_kernel     fused max/argmax over M per a box and max/argmax over N per b box,
+//                        never writing [B,N,M] (16(N+M)+8N algorithmic bytes).  One lane per a
+//                        box (16-byte coalesced load), b boxes broadcast from LDS.  Pairs that
+//                        do not overlap are rejected after 8 VALU ops (two min, two max, two
+//                        sub, two compares) — the IEEE division runs only for overlapping
+//                        pairs, which keeps the kernel off the VALU roof at large M.  The
+//                        per-b reduction packs (iou bits, ~n) into a 64-bit key: LDS
+//                        atomicMax per workgroup (guarded by a plain read, so only improving
+//                        lanes issue the atomic), then one global atomicMax per b per
+//                        workgroup.
+//
+// Bit-exactness: hd_iou_full() evaluates the oracle's expression order with IEEE division
+// (hipcc's default) and no contraction, so values and argmax indices equal the CPU checker's.
+#include "hd_common.h"
+
+namespace {
+
+constexpr int kIouThreads = 256;
+constexpr int kIouIters = 8;          // 256 lanes * 4 outputs * 8 = 8192 outputs per workgroup
+constexpr int kIouLdsMaxM = 3072;     // 3072 * (16 + 4) B = 60 KiB of LDS
+
+template <bool USE_LDS, bool VEC4>
+__global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
+    const float4* __restrict__ a, int64_t a_bstride4, const float4* __restrict__ b,
+    const int32_t* __restrict__ m_valid, int N, int M, float* __restrict__ out) {
+  __shared__ float4 s_box[USE_LDS ? kIouLdsMaxM : 1];
+  __shared__ float s_area[USE_LDS ? kIouLdsMaxM : 1];
+  const int img = blockIdx.y;
+  const int mv = m_valid ? min(m_valid[img], M) : M;
+  const float4* bb = b + (int64_t)img * M;
+  if (USE_LDS) {
+    for (int m = threadIdx.x; m < M; m += kIouThreads) {
+      float4 v = bb[m];
+      s_box[m] = v;
+      s_area[m] = hd_box_area(v);
+    }
+    __syncthreads();
+  }
+  const int64_t T = (int64_t)N * M;
+  const float4* aa = a + (int64_t)img * a_bstride4;
+  float* o = out + (int64_t)img * T;
+  const int64_t span0 = (int64_t)blockIdx.x * (kIouThreads * 4 * kIouIters);
+#pragma unroll 1
+  for (int it = 0; it < kIouIters; ++it) {
+    const int64_t e0 = span0 + ((int64_t)it * kIouThreads + threadIdx.x) * 4;
+    if (e0 >= T) break;
+    int n = (int)(e0 / M);
+    int m = (int)(e0 - (int64_t)n * M);
+    float4 ab = aa[n];
+    float aarea = hd_box_area(ab);
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (e0 + k < T) {
+        if (m < mv) {
+          float4 gb = USE_LDS ? s_box[m] : bb[m];
+          float garea = USE_LDS ? s_area[m] : hd_box_area(gb);
+          r[k] = hd_iou_full(ab, aarea, gb, garea);
+        } else {
+          r[k] = -1.0f;
+        }
+        if (++m == M) {
+          m = 0;
+          ++n;
+          if (n < N) {
+            ab = aa[n];
+            aarea = hd_box_area(ab);
+          }
+        }
+      } else {
+        r[k] = 0.0f;
+      }
+    }
+    if (VEC4) {
+      *reinterpret_cast<float4*>(o + e0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (e0 + k < T) o[e0 + k] = r[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+constexpr int kAssignThreads = 256;
+constexpr int kAssignLdsMaxM = 2048;  // 2048 * (16 + 4 + 8) B = 56 KiB
+
+__device__ __forceinline__ unsigned long long pack_key(float iou, int n) {
+  return ((unsigned long long)__float_as_uint(iou) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
+}
+
+template <bool WITH_GT>
+__global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
+    const float4* __restrict__ a, int64_t a_bstride4, const float4* __restrict__ b,
+    const int32_t* __restrict__ m_valid, int N, int M, int m_chunk0, float* __restrict__ max_iou,
+    int32_t* __restrict__ argmax, unsigned long long* __restrict__ gt_key) {
+  // One pass handles b boxes [m_chunk0, m_chunk0 + kAssignLdsMaxM); the host loops chunks for
+  // M > kAssignLdsMaxM and the kernel then continues the running max held in max_iou/argmax.
+  __shared__ float4 s_box[kAssignLdsMaxM];
+  __shared__ float s_area[kAssignLdsMaxM];
+  __shared__ unsigned long long s_key[WITH_GT ? kAssignLdsMaxM : 1];
+  const int img = blockIdx.y;
+  const int mv = m_valid ? min(m_valid[img], M) : M;
+  const int m_end = min(mv, m_chunk0 + kAssignLdsMaxM);
+  const int mc = max(m_end - m_chunk0, 0);
+  const float4* bb = b + (int64_t)img * M + m_chunk0;
+  for (int m = threadIdx.x; m < mc; m += kAssignThreads) {
+    float4 v = bb[m];
+    s_box[m] = v;
+    s_area[m] = hd_box_area(v);
+    if (WITH_GT) s_key[m] = 0ull;
+  }
+  __syncthreads();
+  const float4* aa = a + (int64_t)img * a_bstride4;
+  for (int n = blockIdx.x * kAssignThreads + threadIdx.x; n < N; n += gridDim.x * kAssignThreads) {
+    const float4 ab = aa[n];
+    const float aarea = hd_box_area(ab);
+    float best;
+    int bidx;
+    if (m_chunk0 == 0) {
+      // oracle: the first valid b always wins over the initial -1 (IoU >= 0)
+      best = mv > 0 ? 0.0f : -1.0f;
+      bidx = mv > 0 ? 0 : -1;
+      if (mv > 0) {
+        // exact value for m = 0 (may be > 0)
+        best = hd_iou_full(ab, aarea, s_box[0], s_area[0]);
+        if (WITH_GT && best > 0.0f) {
+          unsigned long long key = pack_key(best, n);
+          if (key > s_key[0]) atomicMax(&s_key[0], key);
+        }
+      }
+    } else {
+      best = max_iou[(int64_t)img * N + n];
+      bidx = argmax[(int64_t)img * N + n];
+    }
+    for (int m = (m_chunk0 == 0 ? 1 : 0); m < mc; ++m) {
+      const float4 gb = s_box[m];
+      if (hd_overlaps(ab, gb)) {
+        float v = hd_iou_full(ab, aarea, gb, s_area[m]);
+        if (v > best) {
+          best = v;
+          bidx = m_chunk0 + m;
+        }
+        if (WITH_GT && v > 0.0f) {
+          unsigned long long key = pack_key(v, n);
+          if (key > s_key[m]) atomicMax(&s_key[m], key);
+        }
+      }
+    }
+    max_iou[(int64_t)img * N + n] = best;
+    argmax[(int64_t)img * N + n] = bidx;
+  }
+  if (WITH_GT) {
+    __syncthreads();
+    unsigned long long* gk = gt_key + (int64_t)img * M + m_chunk0;
+    for (int m = threadIdx.x; m < mc; m += kAssignThreads) {
+      unsigned long long k = s_key[m];
+      if (k != 0ull) atomicMax(&gk[m], k);
+    }
+  }
+}
+
+__global__ void iou_assign_finalize_kernel(const unsigned long long* __restrict__ gt_key,
+                                           const int32_t* __restrict__ m_valid, int B, int N, int M,
+                                           float* __restrict__ gt_max_iou,
+                                           int32_t* __restrict__ gt_argmax) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * M) return;
+  int img = i / M, m = i - img * M;
+  int mv = m_valid ? min(m_valid[img], M) : M;
+  float v = -1.0f;
+  int idx = -1;
+  if (m < mv && N > 0) {
+    unsigned long long k = gt_key[i];
+    if (k == 0ull) {  // every IoU with this box was 0: the oracle keeps the first a box
+      v = 0.0f;
+      idx = 0;
+    } else {
+      v = __uint_as_float((uint32_t)(k >> 32));
+      idx = (int)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull));
+    }
+  }
+  gt_max_iou[i] = v;
+  gt_argmax[i] = idx;
+}
+
+}  // namespace
+
+extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const float* b,
+                                     const int32_t* m_valid, int B, int N, int M, float* out,
+                                     hd_stream stream) {
+  if (B < 0 || N < 0 || M < 0 || (a_bstride & 3)) return HD_ERR_SHAPE;
+  if (B == 0 || N == 0 || M == 0) return HD_OK;
+  if (!a || !b || !out) return HD_ERR_NULL;
+  if (!hd_aligned16(a) || !hd_aligned16(b)) return HD_ERR_ALIGN;
+  const int64_t T = (int64_t)N * M;
+  const int64_t per_block = (int64_t)kIouThreads * 4 * kIouIters;
+  const int64_t gx = (T + per_block - 1) / per_block;
+  if (gx > 0x7fffffff || B > 65535) return HD_ERR_SHAPE;
+  dim3 grid((unsigned)gx, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (T % 4 == 0) && hd_aligned16(out);
+  const bool lds = M <= kIouLdsMaxM;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#define HD_LAUNCH_PIOU(L, V) \
+  hipLaunchKernelGGL((pairwise_iou_kernel<L, V>), grid, dim3(kIouThreads), 0, s, a4, a_bstride / 4, b4, m_valid, N, M, out)
+  if (lds && vec) HD_LAUNCH_PIOU(true, true);
+  else if (lds) HD_LAUNCH_PIOU(true, false);
+  else if (vec) HD_LAUNCH_PIOU(false, true);
+  else HD_LAUNCH_PIOU(false, false);
+#undef HD_LAUNCH_PIOU
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" size_t hd_iou_assign_workspace_bytes(int B, int N, int M) {
+  (void)N;
+  if (B <= 0 || M <= 0) return 0;
+  return (size_t)B * (size_t)M * sizeof(unsigned long long);
+}
+
+extern "C" hd_status hd_iou_assign(const float* a, int64_t a_bstride, const float* b,
+                                   const int32_t* m_valid, int B, int N, int M, float* max_iou,
+                                   int32_t* argmax, float* gt_max_iou, int32_t* gt_argmax,
+                                   void* workspace, size_t workspace_bytes, hd_stream stream) {
+  if (B < 0 || N < 0 || M < 0 || (a_bstride & 3)) return HD_ERR_SHAPE;
+  if (B == 0) return HD_OK;
+  if (B > 65535) return HD_ERR_SHAPE;
+  const bool with_gt = gt_max_iou != nullptr || gt_argmax != nullptr;
+  if (with_gt && (!gt_max_iou || !gt_argmax)) return HD_ERR_NULL;
+  if (N > 0 && (!a || !max_iou || !argmax)) return HD_ERR_NULL;
+  if (M > 0 && !b) return HD_ERR_NULL;
+  if ((a && !hd_aligned16(a)) || (b && !hd_aligned16(b))) return HD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* keys = nullptr;
+  if (with_gt && M > 0) {
+    if (!workspace || workspace_bytes < hd_iou_assign_workspace_bytes(B, N, M)) return HD_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 7u) return HD_ERR_ALIGN;
+    keys = reinterpret_cast<unsigned long long*>(workspace);
+    if (hipMemsetAsync(keys, 0, (size_t)B * M * sizeof(unsigned long long), s) != hipSuccess) return HD_ERR_LAUNCH;
+  }
+  if (N > 0) {
+    int gx = (N + kAssignThreads - 1) / kAssignThreads;
+    // enough workgroups to fill 256 CUs several times over, grid-stride beyond that
+    const int cap = max(1, 4096 / B);
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, (unsigned)B);
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    int chunk = 0;
+    do {
+      if (with_gt)
+        hipLaunchKernelGGL((iou_assign_kernel<true>), grid, dim3(kAssignThreads), 0, s, a4, a_bstride / 4, b4,
+                           m_valid, N, M, chunk, max_iou, argmax, keys);
+      else
+        hipLaunchKernelGGL((iou_assign_kernel<false>), grid, dim3(kAssignThreads), 0, s, a4, a_bstride / 4, b4,
+                           m_valid, N, M, chunk, max_iou, argmax, keys);
+      HD_RETURN_IF_LAUNCH_FAILED();
+      chunk += kAssignLdsMaxM;
+    } while (chunk < M);
+  }
+  if (with_gt && M > 0) {
+    int total = B * M;
+    hipLaunchKernelGGL(iou_assign_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, keys, m_valid, B, N,
+                       M, gt_max_iou, gt_argmax);
+    HD_RETURN_IF_LAUNCH_FAILED();
+  }
+  return HD_OK;
+}

@@ -1,0 +1,26 @@
+// lib.hip — library-level entry points (version, status text, device probe).
+#include "hd_common.h"
+
+extern "C" int hd_abi_version(void) { return 1; }
+
+extern "C" const char* hd_status_str(hd_status s) {
+  switch (s) {
+    case HD_OK: return "ok";
+    case HD_ERR_NULL: return "required pointer is NULL";
+    case HD_ERR_SHAPE: return "size/shape argument out of range";
+    case HD_ERR_ALIGN: return "pointer not aligned as documented";
+    case HD_ERR_WORKSPACE: return "workspace missing or too small";
+    case HD_ERR_LAUNCH: return "HIP launch failed";
+    case HD_ERR_NO_DEVICE: return "no HIP device visible";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int hd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}

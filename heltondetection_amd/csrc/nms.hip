@@ -1,0 +1,185 @@
+// nms.hip — hd_nms_batched and hd_yolo_nms on top of the shared engine (hd_nms_core.h).
+// SURVEY.md §8a rows "RPN proposal top-K + NMS" (class-agnostic / per-level) and "Per-class NMS".
+#include "hd_nms_core.h"
+
+using namespace hdnms;
+
+namespace {
+
+// ---- hd_nms_batched: keys straight from the caller's scores ---------------------------------
+__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ scores,
+                                                       const int32_t* __restrict__ n_valid, int N, float score_thr,
+                                                       CoreWs w) {
+  const int b = blockIdx.y;
+  const int nv = n_valid ? min(n_valid[b], N) : N;
+  u64* keys = w.keys + (size_t)b * w.key_cap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    const float s = scores[(size_t)b * N + i];
+    if (s > score_thr) {  // NaN fails
+      const int pos = atomicAdd(&w.n_keys[b], 1);
+      keys[pos] = make_key(s, (uint32_t)i);
+    }
+  }
+}
+
+// ---- hd_yolo_nms ----------------------------------------------------------------------------
+// One wave per decoded row: lane 0..63 scan the class scores (coalesced), wave arg-max with
+// ties -> lowest class.  Rows failing the objectness gate cost one broadcast load.
+__global__ __launch_bounds__(256) void yolo_cand_kernel(const float* __restrict__ dec, int n, int no, float conf_thr,
+                                                        CoreWs w, float4* __restrict__ cand_box,
+                                                        int32_t* __restrict__ cand_cls,
+                                                        float* __restrict__ cand_conf) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  u64* keys = w.keys + (size_t)b * w.key_cap;
+  for (int i = wave; i < n; i += n_waves) {
+    const float* r = dec + ((size_t)b * n + i) * no;
+    const float obj = r[4];
+    if (!(obj > conf_thr)) continue;  // wave-uniform
+    float best = -1.0f;
+    int bc = 0;
+    for (int c = 5 + lane; c < no; c += 64) {
+      const float v = r[c];
+      if (v > best) {
+        best = v;
+        bc = c - 5;
+      }
+    }
+    // arg-max across lanes, ties -> lower class index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oc = __shfl_xor(bc, o, 64);
+      if (ob > best || (ob == best && oc < bc)) {
+        best = ob;
+        bc = oc;
+      }
+    }
+    const float conf = obj * best;
+    if (lane == 0 && conf > conf_thr) {
+      const float cx = r[0], cy = r[1], bw = r[2], bh = r[3];
+      cand_box[(size_t)b * n + i] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
+      cand_cls[(size_t)b * n + i] = bc;
+      cand_conf[(size_t)b * n + i] = conf;
+      const int pos = atomicAdd(&w.n_keys[b], 1);
+      keys[pos] = make_key(conf, (uint32_t)i);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void yolo_det_kernel(const int32_t* __restrict__ keep,
+                                                       const int32_t* __restrict__ det_count, int n, int max_det,
+                                                       const float4* __restrict__ cand_box,
+                                                       const int32_t* __restrict__ cand_cls,
+                                                       const float* __restrict__ cand_conf, float* __restrict__ det) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < max_det; k += gridDim.x * blockDim.x) {
+    float* d = det + ((size_t)b * max_det + k) * 6;
+    if (k < det_count[b]) {
+      const int i = keep[(size_t)b * max_det + k];
+      const float4 bx = cand_box[(size_t)b * n + i];
+      d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w;
+      d[4] = cand_conf[(size_t)b * n + i];
+      d[5] = (float)cand_cls[(size_t)b * n + i];
+    } else {
+      d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0f;
+    }
+  }
+}
+
+struct YoloWs {
+  float4* cand_box;
+  int32_t* cand_cls;
+  float* cand_conf;
+  int32_t* keep;
+  size_t core_off, bytes;
+};
+
+inline YoloWs yolo_layout(void* base, int B, int n, int max_det) {
+  YoloWs y;
+  size_t off = 0;
+  char* p = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += hd_align_up(bytes, 256);
+    return r;
+  };
+  y.cand_box = reinterpret_cast<float4*>(take((size_t)B * n * sizeof(float4)));
+  y.cand_cls = reinterpret_cast<int32_t*>(take((size_t)B * n * sizeof(int32_t)));
+  y.cand_conf = reinterpret_cast<float*>(take((size_t)B * n * sizeof(float)));
+  y.keep = reinterpret_cast<int32_t*>(take((size_t)B * (max_det > 0 ? max_det : 1) * sizeof(int32_t)));
+  y.core_off = off;
+  y.bytes = off;
+  return y;
+}
+
+}  // namespace
+
+extern "C" size_t hd_nms_workspace_bytes(int B, int N, int max_candidates) {
+  if (B <= 0 || N <= 0) return 0;
+  return core_layout(nullptr, B, N, max_candidates).bytes;
+}
+
+extern "C" hd_status hd_nms_batched(const float* boxes, const float* scores, const int32_t* cls,
+                                    const int32_t* n_valid, int B, int N, float score_thr, float iou_thr,
+                                    int max_candidates, int max_out, int32_t* keep, int32_t* keep_count,
+                                    void* workspace, size_t workspace_bytes, hd_stream stream) {
+  if (B < 0 || N < 0 || max_out < 0) return HD_ERR_SHAPE;
+  if (B == 0) return HD_OK;
+  if (B > 65535) return HD_ERR_SHAPE;
+  if (!keep_count || (max_out > 0 && !keep)) return HD_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0 || max_out == 0) {
+    if (hipMemsetAsync(keep_count, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+    if (max_out > 0 && hipMemsetAsync(keep, 0xFF, (size_t)B * max_out * sizeof(int32_t), s) != hipSuccess)
+      return HD_ERR_LAUNCH;
+    return HD_OK;
+  }
+  if (!boxes || !scores) return HD_ERR_NULL;
+  if (!hd_aligned16(boxes)) return HD_ERR_ALIGN;
+  CoreWs w = core_layout(workspace, B, N, max_candidates);
+  if (w.cap > kMaxCand) return HD_ERR_SHAPE;
+  if (!workspace || workspace_bytes < w.bytes) return HD_ERR_WORKSPACE;
+  if (!hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  int gx = (N + 255) / 256;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(nms_keys_kernel, dim3(gx, B), dim3(256), 0, s, scores, n_valid, N, score_thr, w);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return run_core(w, B, reinterpret_cast<const float4*>(boxes), cls, (long long)N, iou_thr, max_out, keep,
+                  keep_count, s);
+}
+
+extern "C" size_t hd_yolo_nms_workspace_bytes(int B, int n, int max_nms, int max_det) {
+  if (B <= 0 || n <= 0 || max_det <= 0) return 0;
+  YoloWs y = yolo_layout(nullptr, B, n, max_det);
+  return y.bytes + core_layout(nullptr, B, n, max_nms).bytes;
+}
+
+extern "C" hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float conf_thr, float iou_thr,
+                                 int max_nms, int max_det, float* det, int32_t* det_count, void* workspace,
+                                 size_t workspace_bytes, hd_stream stream) {
+  if (B <= 0 || n <= 0 || no < 6 || max_det <= 0 || max_det > (1 << 20) || B > 65535) return HD_ERR_SHAPE;
+  if (!dec || !det || !det_count) return HD_ERR_NULL;
+  if (!workspace) return HD_ERR_WORKSPACE;
+  if (!hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  YoloWs y = yolo_layout(workspace, B, n, max_det);
+  CoreWs w = core_layout(reinterpret_cast<char*>(workspace) + y.core_off, B, n, max_nms);
+  if (w.cap > kMaxCand) return HD_ERR_SHAPE;
+  if (workspace_bytes < y.bytes + w.bytes) return HD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  int gx = (n + 3) / 4;  // 4 waves per block, one row per wave per iteration
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(yolo_cand_kernel, dim3(gx, B), dim3(256), 0, s, dec, n, no, conf_thr, w, y.cand_box, y.cand_cls,
+                     y.cand_conf);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  hd_status st = run_core(w, B, y.cand_box, y.cand_cls, (long long)n, iou_thr, max_det, y.keep, det_count, s);
+  if (st != HD_OK) return st;
+  hipLaunchKernelGGL(yolo_det_kernel, dim3((max_det + 255) / 256, B), dim3(256), 0, s, y.keep, det_count, n, max_det,
+                     y.cand_box, y.cand_cls, y.cand_conf, det);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}

@@ -1,0 +1,189 @@
+// rpn.hip — RPN proposal generation (reference README.md:8; SURVEY.md §8a "RPN proposal top-K + NMS").
+//
+//   rpn_topk_kernel   one 1024-lane workgroup per (level, image): exact top-k of the objectness
+//                     logits by MSB-first radix select on the 64-bit key (logit bits, ~index) —
+//                     8-bit digits, LDS histogram per pass, early exit as soon as the remaining
+//                     bucket is taken whole (4 passes + 1 select pass for distinct logits).  The
+//                     selected anchors are decoded, clipped, size-filtered and appended as NMS
+//                     candidates; nothing of the other N-k anchors is ever written.
+//   engine            hd_nms_core.h with class id = pyramid level (per-level NMS), max_out =
+//                     post_nms_topk.
+//   rpn_emit_kernel   gathers the kept boxes, sigmoid(logit) scores, zero padding.
+//
+// Ties: keys are (logit, lower anchor index first) everywhere, which equals the oracle's
+// "per-level rank order, then candidate order" because levels are concatenated in index order.
+#include "hd_ciou.h"
+#include "hd_nms_core.h"
+
+using namespace hdnms;
+
+namespace {
+
+struct RpnLevels {
+  int n_levels;
+  int off[HD_MAX_LEVELS + 1];
+};
+
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(const float* __restrict__ logits,
+                                                        const float4* __restrict__ deltas,
+                                                        const float4* __restrict__ anchors, int NA, RpnLevels lv,
+                                                        int pre_nms_topk, float min_size, float img_h, float img_w,
+                                                        CoreWs w, float4* __restrict__ cand_box,
+                                                        int32_t* __restrict__ cand_cls) {
+  __shared__ int s_hist[256];
+  __shared__ u64 s_prefix;
+  __shared__ int s_need;
+  __shared__ int s_done;
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int off = lv.off[l], n = lv.off[l + 1] - lv.off[l];
+  const int k = n < pre_nms_topk ? n : pre_nms_topk;
+  const float* lg = logits + (size_t)b * NA;
+  u64 thr = 0ull;  // select keys >= thr
+  if (k < n) {
+    u64 prefix = 0ull, pmask = 0ull;
+    int need = k;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      for (int i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 key = make_key(lg[off + i], (uint32_t)(off + i));
+        if ((key & pmask) == prefix) atomicAdd(&s_hist[(int)((key >> shift) & 255ull)], 1);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int above = 0, d = 255;
+        for (; d > 0; --d) {
+          if (above + s_hist[d] >= need) break;
+          above += s_hist[d];
+        }
+        s_need = need - above;
+        s_prefix = prefix | ((u64)d << shift);
+        s_done = (s_hist[d] == need - above) ? 1 : 0;
+      }
+      __syncthreads();
+      need = s_need;
+      prefix = s_prefix;
+      pmask |= 255ull << shift;
+      const int done = s_done;
+      __syncthreads();
+      if (done) break;
+    }
+    thr = prefix;
+  }
+  u64* keys = w.keys + (size_t)b * w.key_cap;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int gi = off + i;
+    const float v = lg[gi];
+    const u64 key = make_key(v, (uint32_t)gi);
+    if (key >= thr) {
+      const float4 bx = hd_delta_decode(anchors[gi], deltas[(size_t)b * NA + gi], img_h, img_w);
+      if ((bx.z - bx.x >= min_size) && (bx.w - bx.y >= min_size)) {
+        cand_box[(size_t)b * NA + gi] = bx;
+        cand_cls[(size_t)b * NA + gi] = l;
+        const int pos = atomicAdd(&w.n_keys[b], 1);
+        if (pos < w.key_cap) keys[pos] = key;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rpn_emit_kernel(const int32_t* __restrict__ keep,
+                                                       const int32_t* __restrict__ count, int NA, int post,
+                                                       const float4* __restrict__ cand_box,
+                                                       const float* __restrict__ logits, float4* __restrict__ rois,
+                                                       float* __restrict__ roi_scores) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < post; k += gridDim.x * blockDim.x) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = 0.0f;
+    if (k < count[b]) {
+      const int gi = keep[(size_t)b * post + k];
+      r = cand_box[(size_t)b * NA + gi];
+      sc = hd_sigmoid(logits[(size_t)b * NA + gi]);
+    }
+    rois[(size_t)b * post + k] = r;
+    roi_scores[(size_t)b * post + k] = sc;
+  }
+}
+
+struct RpnWs {
+  float4* cand_box;
+  int32_t* cand_cls;
+  int32_t* keep;
+  size_t core_off, bytes;
+};
+
+inline RpnWs rpn_layout(void* base, int B, int NA, int post) {
+  RpnWs r;
+  size_t off = 0;
+  char* p = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    char* q = p ? p + off : nullptr;
+    off += hd_align_up(bytes, 256);
+    return q;
+  };
+  r.cand_box = reinterpret_cast<float4*>(take((size_t)B * NA * sizeof(float4)));
+  r.cand_cls = reinterpret_cast<int32_t*>(take((size_t)B * NA * sizeof(int32_t)));
+  r.keep = reinterpret_cast<int32_t*>(take((size_t)B * (post > 0 ? post : 1) * sizeof(int32_t)));
+  r.core_off = off;
+  r.bytes = off;
+  return r;
+}
+
+// upper bound of NMS candidates per image: every level contributes at most pre_nms_topk; the
+// per-level sizes are not part of the workspace query, so bound by min(NA, n_levels*pre).
+inline int cand_bound(int NA, int n_levels, int pre) {
+  long long c = (long long)n_levels * pre;
+  return (int)(c < NA ? c : NA);
+}
+
+}  // namespace
+
+extern "C" size_t hd_rpn_proposals_workspace_bytes(int B, int NA, int n_levels, int pre_nms_topk,
+                                                   int post_nms_topk) {
+  if (B <= 0 || NA <= 0 || n_levels <= 0 || pre_nms_topk <= 0 || post_nms_topk <= 0) return 0;
+  const int nk = cand_bound(NA, n_levels, pre_nms_topk);
+  return rpn_layout(nullptr, B, NA, post_nms_topk).bytes + core_layout(nullptr, B, nk, 0).bytes;
+}
+
+extern "C" hd_status hd_rpn_proposals(const float* logits, const float* deltas, const float* anchors, int B,
+                                      int NA, int n_levels, const int* level_sizes, int pre_nms_topk,
+                                      int post_nms_topk, float iou_thr, float min_size, float img_h, float img_w,
+                                      float* rois, float* roi_scores, int32_t* count, void* workspace,
+                                      size_t workspace_bytes, hd_stream stream) {
+  if (B <= 0 || NA <= 0 || n_levels <= 0 || n_levels > HD_MAX_LEVELS || pre_nms_topk <= 0 || post_nms_topk <= 0 ||
+      B > 65535)
+    return HD_ERR_SHAPE;
+  if (!logits || !deltas || !anchors || !level_sizes || !rois || !roi_scores || !count) return HD_ERR_NULL;
+  if (!hd_aligned16(deltas) || !hd_aligned16(anchors) || !hd_aligned16(rois)) return HD_ERR_ALIGN;
+  RpnLevels lv;
+  lv.n_levels = n_levels;
+  int off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    if (level_sizes[l] <= 0) return HD_ERR_SHAPE;
+    lv.off[l] = off;
+    off += level_sizes[l];
+  }
+  for (int l = n_levels; l <= HD_MAX_LEVELS; ++l) lv.off[l] = off;
+  if (off != NA) return HD_ERR_SHAPE;
+  const int nk = cand_bound(NA, n_levels, pre_nms_topk);
+  if (!workspace) return HD_ERR_WORKSPACE;
+  if (!hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  RpnWs r = rpn_layout(workspace, B, NA, post_nms_topk);
+  CoreWs w = core_layout(reinterpret_cast<char*>(workspace) + r.core_off, B, nk, 0);
+  if (w.cap > kMaxCand) return HD_ERR_SHAPE;
+  if (workspace_bytes < r.bytes + w.bytes) return HD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  hipLaunchKernelGGL(rpn_topk_kernel, dim3(n_levels, B), dim3(1024), 0, s, logits,
+                     reinterpret_cast<const float4*>(deltas), reinterpret_cast<const float4*>(anchors), NA, lv,
+                     pre_nms_topk, min_size, img_h, img_w, w, r.cand_box, r.cand_cls);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  hd_status st = run_core(w, B, r.cand_box, r.cand_cls, (long long)NA, iou_thr, post_nms_topk, r.keep, count, s);
+  if (st != HD_OK) return st;
+  hipLaunchKernelGGL(rpn_emit_kernel, dim3((post_nms_topk + 255) / 256, B), dim3(256), 0, s, r.keep, count, NA,
+                     post_nms_topk, r.cand_box, logits, reinterpret_cast<float4*>(rois), roi_scores);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}

@@ -1,0 +1,410 @@
+"""Tensor-level front end of the HIP C-ABI (include/hd_ops.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every op below
+hands raw pointers to libhd_ops.so.  There is NO CPU path: tensors must live on a HIP device
+and the library must have been built (``__graft_entry__.build()``), otherwise these raise.
+
+The op set mirrors what a detector framework of the reference's kind plugs into its
+heads/assigners/post-processing (reference README.md:8-9,19,65): anchors, pairwise IoU +
+assignment, delta codec, NMS, RPN proposals, RoIAlign, YOLOv5 decode / build-targets / loss,
+CIoU, per-class NMS, WBF.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import RoiLevels, YoloLevels, YoloLossCfg, check
+
+_F32, _I32 = torch.float32, torch.int32
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype, name: str, contiguous: bool = True) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HdError(f"{name}: expected a tensor on a HIP device (there is no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.HdError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _ws(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
+    if nbytes <= 0:
+        return None, 0
+    t = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+    return t, t.numel()
+
+
+# ------------------------------------------------------------------------------- anchors
+def anchor_base(sizes: Sequence[float], ratios: Sequence[float]) -> torch.Tensor:
+    """Host helper: [len(ratios)*len(sizes), 4] base anchors (CPU tensor)."""
+    lib = _lib.load()
+    s = (C.c_float * len(sizes))(*sizes)
+    r = (C.c_float * len(ratios))(*ratios)
+    out = (C.c_float * (4 * len(sizes) * len(ratios)))()
+    check(lib.hd_anchor_base(s, len(sizes), r, len(ratios), out), "hd_anchor_base")
+    return torch.tensor(list(out), dtype=_F32).view(-1, 4)
+
+
+def anchor_grid(feat_hw: Sequence[Tuple[int, int]], strides: Sequence[float], base_anchors: torch.Tensor,
+                offset: float = 0.5, device="cuda") -> torch.Tensor:
+    """base_anchors: CPU [L, A, 4]. Returns device [sum H*W*A, 4] (level, y, x, anchor order)."""
+    lib = _lib.load()
+    L, A = base_anchors.shape[0], base_anchors.shape[1]
+    fh = (C.c_int * L)(*[int(h) for h, _ in feat_hw])
+    fw = (C.c_int * L)(*[int(w) for _, w in feat_hw])
+    st = (C.c_float * L)(*[float(s) for s in strides])
+    base = base_anchors.to(_F32).contiguous().cpu()
+    n = sum(int(h) * int(w) for h, w in feat_hw) * A
+    out = torch.empty((n, 4), dtype=_F32, device=device)
+    check(lib.hd_anchor_grid(L, fh, fw, st, C.c_void_p(base.data_ptr()), A, float(offset), _ptr(out), _stream(out)),
+          "hd_anchor_grid")
+    return out
+
+
+# ------------------------------------------------------------------------------- IoU
+def pairwise_iou(a: torch.Tensor, b: torch.Tensor, m_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a [B,N,4] or [N,4] (shared across the batch), b [B,M,4] -> [B,N,M]; padded columns = -1."""
+    lib = _lib.load()
+    b = _need(b, _F32, "b")
+    a = _need(a, _F32, "a")
+    B, M = b.shape[0], b.shape[1]
+    shared = a.dim() == 2
+    N = a.shape[-2]
+    if m_valid is not None:
+        m_valid = _need(m_valid, _I32, "m_valid")
+    out = torch.empty((B, N, M), dtype=_F32, device=b.device)
+    check(lib.hd_pairwise_iou(_ptr(a), 0 if shared else N * 4, _ptr(b), _ptr(m_valid), B, N, M, _ptr(out), _stream(b)),
+          "hd_pairwise_iou")
+    return out
+
+
+def iou_assign(a: torch.Tensor, b: torch.Tensor, m_valid: Optional[torch.Tensor] = None, with_gt: bool = True):
+    """Fused max/argmax. Returns (max_iou [B,N], argmax [B,N], gt_max_iou [B,M], gt_argmax [B,M])."""
+    lib = _lib.load()
+    b = _need(b, _F32, "b")
+    a = _need(a, _F32, "a")
+    B, M = b.shape[0], b.shape[1]
+    shared = a.dim() == 2
+    N = a.shape[-2]
+    if m_valid is not None:
+        m_valid = _need(m_valid, _I32, "m_valid")
+    dev = b.device
+    mx = torch.empty((B, N), dtype=_F32, device=dev)
+    am = torch.empty((B, N), dtype=_I32, device=dev)
+    gmx = torch.empty((B, M), dtype=_F32, device=dev) if with_gt else None
+    gam = torch.empty((B, M), dtype=_I32, device=dev) if with_gt else None
+    ws, wsb = _ws(lib.hd_iou_assign_workspace_bytes(B, N, M) if with_gt else 0, dev)
+    check(lib.hd_iou_assign(_ptr(a), 0 if shared else N * 4, _ptr(b), _ptr(m_valid), B, N, M, _ptr(mx), _ptr(am),
+                            _ptr(gmx), _ptr(gam), _ptr(ws), wsb, _stream(b)), "hd_iou_assign")
+    return mx, am, gmx, gam
+
+
+# ------------------------------------------------------------------------------- codec
+def box_encode(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    src, dst = _need(src, _F32, "src"), _need(dst, _F32, "dst")
+    out = torch.empty_like(src)
+    check(lib.hd_box_encode(_ptr(src), _ptr(dst), src.numel() // 4, _ptr(out), _stream(src)), "hd_box_encode")
+    return out
+
+
+def box_decode(anchors: torch.Tensor, deltas: torch.Tensor, img_h: float = 0.0, img_w: float = 0.0) -> torch.Tensor:
+    lib = _lib.load()
+    anchors, deltas = _need(anchors, _F32, "anchors"), _need(deltas, _F32, "deltas")
+    out = torch.empty_like(deltas)
+    check(lib.hd_box_decode(_ptr(anchors), _ptr(deltas), deltas.numel() // 4, float(img_h), float(img_w), _ptr(out),
+                            _stream(deltas)), "hd_box_decode")
+    return out
+
+
+# ------------------------------------------------------------------------------- NMS
+def nms_batched(boxes: torch.Tensor, scores: torch.Tensor, cls: Optional[torch.Tensor] = None,
+                n_valid: Optional[torch.Tensor] = None, score_thr: float = float("-inf"), iou_thr: float = 0.5,
+                max_candidates: int = 0, max_out: Optional[int] = None):
+    """Exact greedy NMS per image. Returns (keep [B,max_out] int32 padded -1, count [B] int32)."""
+    lib = _lib.load()
+    boxes, scores = _need(boxes, _F32, "boxes"), _need(scores, _F32, "scores")
+    B, N = scores.shape
+    max_out = N if max_out is None else int(max_out)
+    if cls is not None:
+        cls = _need(cls, _I32, "cls")
+    if n_valid is not None:
+        n_valid = _need(n_valid, _I32, "n_valid")
+    dev = boxes.device
+    keep = torch.empty((B, max_out), dtype=_I32, device=dev)
+    cnt = torch.empty((B,), dtype=_I32, device=dev)
+    ws, wsb = _ws(lib.hd_nms_workspace_bytes(B, N, max_candidates), dev)
+    check(lib.hd_nms_batched(_ptr(boxes), _ptr(scores), _ptr(cls), _ptr(n_valid), B, N, float(score_thr),
+                             float(iou_thr), int(max_candidates), max_out, _ptr(keep), _ptr(cnt), _ptr(ws), wsb,
+                             _stream(boxes)), "hd_nms_batched")
+    return keep, cnt
+
+
+def rpn_proposals(logits: torch.Tensor, deltas: torch.Tensor, anchors: torch.Tensor, level_sizes: Sequence[int],
+                  pre_nms_topk: int, post_nms_topk: int, iou_thr: float, min_size: float, img_h: float, img_w: float):
+    """Returns (rois [B,post,4], scores [B,post], count [B])."""
+    lib = _lib.load()
+    logits, deltas, anchors = _need(logits, _F32, "logits"), _need(deltas, _F32, "deltas"), _need(anchors, _F32, "anchors")
+    B, NA = logits.shape
+    L = len(level_sizes)
+    ls = (C.c_int * L)(*[int(v) for v in level_sizes])
+    dev = logits.device
+    rois = torch.empty((B, post_nms_topk, 4), dtype=_F32, device=dev)
+    sc = torch.empty((B, post_nms_topk), dtype=_F32, device=dev)
+    cnt = torch.empty((B,), dtype=_I32, device=dev)
+    ws, wsb = _ws(lib.hd_rpn_proposals_workspace_bytes(B, NA, L, pre_nms_topk, post_nms_topk), dev)
+    check(lib.hd_rpn_proposals(_ptr(logits), _ptr(deltas), _ptr(anchors), B, NA, L, ls, int(pre_nms_topk),
+                               int(post_nms_topk), float(iou_thr), float(min_size), float(img_h), float(img_w),
+                               _ptr(rois), _ptr(sc), _ptr(cnt), _ptr(ws), wsb, _stream(logits)), "hd_rpn_proposals")
+    return rois, sc, cnt
+
+
+# ------------------------------------------------------------------------------- RoIAlign
+def _roi_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], k_min: int, canonical_scale: float,
+                canonical_level: int) -> RoiLevels:
+    st = RoiLevels()
+    st.n_levels = len(feats)
+    for l, f in enumerate(feats):
+        if not f.is_cuda or f.dtype != _F32 or f.dim() != 4:
+            raise _lib.HdError("roi_align: features must be float32 [B,C,H,W] tensors on a HIP device")
+        st.feat[l] = f.data_ptr()
+        st.h[l], st.w[l] = f.shape[2], f.shape[3]
+        st.spatial_scale[l] = float(scales[l])
+        st.sb[l], st.sc[l], st.sh[l], st.sw[l] = f.stride(0), f.stride(1), f.stride(2), f.stride(3)
+    st.k_min = int(k_min)
+    st.canonical_scale = float(canonical_scale)
+    st.canonical_level = int(canonical_level)
+    return st
+
+
+def roi_level_map(rois: torch.Tensor, k_min: int, n_levels: int, canonical_scale: float = 224.0,
+                  canonical_level: int = 4) -> torch.Tensor:
+    lib = _lib.load()
+    rois = _need(rois, _F32, "rois")
+    out = torch.empty((rois.shape[0],), dtype=_I32, device=rois.device)
+    check(lib.hd_roi_level_map(_ptr(rois), rois.shape[0], k_min, n_levels, float(canonical_scale), canonical_level,
+                               _ptr(out), _stream(rois)), "hd_roi_level_map")
+    return out
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, P, scales, sampling_ratio, aligned, k_min, canonical_scale, canonical_level,
+                channels_last_out, *feats):
+        lib = _lib.load()
+        rois = _need(rois.detach(), _F32, "rois")
+        feats_d = [f.detach() for f in feats]
+        st = _roi_levels(feats_d, scales, k_min, canonical_scale, canonical_level)
+        R, Cc = rois.shape[0], feats[0].shape[1]
+        out = torch.empty((R, Cc, P, P), dtype=_F32, device=rois.device,
+                          memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
+        check(lib.hd_roi_align_fwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
+                                   _ptr(out), out.stride(0), out.stride(1), out.stride(2), out.stride(3),
+                                   _stream(rois)), "hd_roi_align_fwd")
+        ctx.save_for_backward(rois)
+        ctx.meta = (P, tuple(scales), sampling_ratio, aligned, k_min, canonical_scale, canonical_level,
+                    [(tuple(f.shape), f.is_contiguous(memory_format=torch.channels_last)) for f in feats])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (rois,) = ctx.saved_tensors
+        P, scales, sampling_ratio, aligned, k_min, cs, cl, shapes = ctx.meta
+        grad_out = _need(grad_out, _F32, "grad_out", contiguous=False)
+        grads = [torch.empty(shape, dtype=_F32, device=rois.device,
+                             memory_format=torch.channels_last if cl_fmt else torch.contiguous_format).zero_()
+                 for shape, cl_fmt in shapes]
+        st = _roi_levels(grads, scales, k_min, cs, cl)
+        R, Cc = rois.shape[0], shapes[0][0][1]
+        check(lib.hd_roi_align_bwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
+                                   _ptr(grad_out), grad_out.stride(0), grad_out.stride(1), grad_out.stride(2),
+                                   grad_out.stride(3), _stream(rois)), "hd_roi_align_bwd")
+        return (None,) * 9 + tuple(grads)
+
+
+def roi_align(feats: Sequence[torch.Tensor], rois: torch.Tensor, P: int, scales: Sequence[float],
+              sampling_ratio: int = 2, aligned: bool = True, k_min: int = 2, canonical_scale: float = 224.0,
+              canonical_level: int = 4, channels_last_out: bool = False) -> torch.Tensor:
+    """feats: list of [B,C,H,W] (any strides; channels-last is the fast layout); rois [R,5] -> [R,C,P,P]."""
+    return _RoIAlignFn.apply(rois, int(P), tuple(scales), int(sampling_ratio), bool(aligned), int(k_min),
+                             float(canonical_scale), int(canonical_level), bool(channels_last_out), *feats)
+
+
+# ------------------------------------------------------------------------------- YOLOv5
+def _yolo_levels(preds: Sequence[torch.Tensor], strides: Sequence[float], anchors) -> YoloLevels:
+    """preds: list of [B, na, H, W, no] views (any strides). anchors: [L][na][2] pixels."""
+    st = YoloLevels()
+    st.n_levels = len(preds)
+    st.na = preds[0].shape[1]
+    st.no = preds[0].shape[4]
+    for l, p in enumerate(preds):
+        if not p.is_cuda or p.dtype != _F32 or p.dim() != 5:
+            raise _lib.HdError("yolo ops: predictions must be float32 [B,na,H,W,no] tensors on a HIP device")
+        st.pred[l] = p.data_ptr()
+        st.h[l], st.w[l] = p.shape[2], p.shape[3]
+        st.stride[l] = float(strides[l])
+        for a in range(st.na):
+            st.anchor_w[l][a] = float(anchors[l][a][0])
+            st.anchor_h[l][a] = float(anchors[l][a][1])
+        st.sb[l], st.sa[l], st.sy[l], st.sx[l], st.so[l] = p.stride()
+    return st
+
+
+def yolo_decode(preds: Sequence[torch.Tensor], strides, anchors) -> torch.Tensor:
+    lib = _lib.load()
+    st = _yolo_levels(preds, strides, anchors)
+    B = preds[0].shape[0]
+    n = sum(p.shape[1] * p.shape[2] * p.shape[3] for p in preds)
+    out = torch.empty((B, n, st.no), dtype=_F32, device=preds[0].device)
+    check(lib.hd_yolo_decode(C.byref(st), B, _ptr(out), _stream(out)), "hd_yolo_decode")
+    return out
+
+
+def yolo_assign(shapes: Sequence[Tuple[int, int, int, int]], strides, anchors, gt_boxes: torch.Tensor,
+                gt_cls: torch.Tensor, m_valid: torch.Tensor, anchor_t: float = 4.0):
+    """shapes: per level (na, H, W, no). Returns slot_cell [L,S] i32, slot_tbox [L,S,4] f32, slot_cls [L,S] i32."""
+    lib = _lib.load()
+    gt_boxes, gt_cls, m_valid = _need(gt_boxes, _F32, "gt_boxes"), _need(gt_cls, _I32, "gt_cls"), _need(m_valid, _I32, "m_valid")
+    B, M = gt_cls.shape
+    st = YoloLevels()
+    st.n_levels, st.na, st.no = len(shapes), shapes[0][0], shapes[0][3]
+    for l, (na, H, W, no) in enumerate(shapes):
+        st.h[l], st.w[l] = H, W
+        st.stride[l] = float(strides[l])
+        for a in range(na):
+            st.anchor_w[l][a] = float(anchors[l][a][0])
+            st.anchor_h[l][a] = float(anchors[l][a][1])
+    L, S = len(shapes), 5 * shapes[0][0] * B * M
+    dev = gt_boxes.device
+    cell = torch.empty((L, S), dtype=_I32, device=dev)
+    tbox = torch.empty((L, S, 4), dtype=_F32, device=dev)
+    cls = torch.empty((L, S), dtype=_I32, device=dev)
+    check(lib.hd_yolo_assign(C.byref(st), _ptr(gt_boxes), _ptr(gt_cls), _ptr(m_valid), B, M, float(anchor_t),
+                             _ptr(cell), _ptr(tbox), _ptr(cls), _stream(gt_boxes)), "hd_yolo_assign")
+    return cell, tbox, cls
+
+
+def _loss_cfg(box_gain, obj_gain, cls_gain, balance) -> YoloLossCfg:
+    cfg = YoloLossCfg()
+    cfg.box_gain, cfg.obj_gain, cfg.cls_gain = float(box_gain), float(obj_gain), float(cls_gain)
+    for l, v in enumerate(balance):
+        cfg.balance[l] = float(v)
+    return cfg
+
+
+class _YoloLossFn(torch.autograd.Function):
+    """total loss (scalar) + detached components; gradients flow to the raw head outputs."""
+
+    @staticmethod
+    def forward(ctx, strides, anchors, slots, M, gains, balance, *preds):
+        lib = _lib.load()
+        preds_d = [p.detach() for p in preds]
+        st = _yolo_levels(preds_d, strides, anchors)
+        B = preds[0].shape[0]
+        slot_cell, slot_tbox, slot_cls = slots
+        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
+        dev = preds[0].device
+        out = torch.empty((4,), dtype=_F32, device=dev)
+        ws, wsb = _ws(lib.hd_yolo_loss_workspace_bytes(C.byref(st), B), dev)
+        check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
+                                   C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
+        ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d)
+        ctx.meta = (strides, anchors, int(M), gains, balance, wsb)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_parts):
+        lib = _lib.load()
+        slot_cell, slot_tbox, slot_cls, ws, *preds = ctx.saved_tensors
+        strides, anchors, M, gains, balance, wsb = ctx.meta
+        st = _yolo_levels(preds, strides, anchors)
+        # gradient tensors keep the producer's memory order (dense channels-last fast path)
+        grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=p.device) for p in preds]
+        gst = _yolo_levels(grads, strides, anchors)
+        B = preds[0].shape[0]
+        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
+        gs = grad_total.detach().to(_F32).reshape(1).contiguous()
+        check(lib.hd_yolo_loss_bwd(C.byref(st), C.byref(gst), B, M, _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
+                                   C.byref(cfg), _ptr(gs), _ptr(ws), wsb, _stream(gs)), "hd_yolo_loss_bwd")
+        return (None,) * 6 + tuple(grads)
+
+
+def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, box_gain: float = 0.05,
+              obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4)):
+    """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached)."""
+    return _YoloLossFn.apply(tuple(strides), tuple(tuple(tuple(a) for a in lv) for lv in anchors), slots, int(M),
+                             (box_gain, obj_gain, cls_gain), tuple(balance), *preds)
+
+
+class _CIoUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        lib = _lib.load()
+        p, t = _need(pred.detach(), _F32, "pred"), _need(target.detach(), _F32, "target")
+        out = torch.empty((p.shape[0],), dtype=_F32, device=p.device)
+        check(lib.hd_ciou_fwd(_ptr(p), _ptr(t), p.shape[0], _ptr(out), _stream(p)), "hd_ciou_fwd")
+        ctx.save_for_backward(p, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        p, t = ctx.saved_tensors
+        g = _need(grad, _F32, "grad")
+        out = torch.empty_like(p)
+        check(lib.hd_ciou_bwd(_ptr(p), _ptr(t), _ptr(g), p.shape[0], _ptr(out), _stream(p)), "hd_ciou_bwd")
+        return out, None
+
+
+def ciou(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """CIoU of matched xyxy pairs [P,4] -> [P]; differentiable w.r.t. pred."""
+    return _CIoUFn.apply(pred, target)
+
+
+def yolo_nms(dec: torch.Tensor, conf_thr: float = 0.25, iou_thr: float = 0.45, max_nms: int = 30000,
+             max_det: int = 300):
+    """dec [B,n,no] decoded rows -> (det [B,max_det,6], count [B])."""
+    lib = _lib.load()
+    dec = _need(dec, _F32, "dec")
+    B, n, no = dec.shape
+    dev = dec.device
+    det = torch.empty((B, max_det, 6), dtype=_F32, device=dev)
+    cnt = torch.empty((B,), dtype=_I32, device=dev)
+    ws, wsb = _ws(lib.hd_yolo_nms_workspace_bytes(B, n, int(max_nms), int(max_det)), dev)
+    check(lib.hd_yolo_nms(_ptr(dec), B, n, no, float(conf_thr), float(iou_thr), int(max_nms), int(max_det), _ptr(det),
+                          _ptr(cnt), _ptr(ws), wsb, _stream(dec)), "hd_yolo_nms")
+    return det, cnt
+
+
+# ------------------------------------------------------------------------------- WBF
+def wbf(boxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, model_weight: torch.Tensor,
+        k_valid: Optional[torch.Tensor], weight_sum: float, iou_thr: float = 0.55, skip_thr: float = 0.0):
+    """boxes [B,K,4], scores/labels/model_weight [B,K] -> (out [B,K,6], count [B])."""
+    lib = _lib.load()
+    boxes, scores = _need(boxes, _F32, "boxes"), _need(scores, _F32, "scores")
+    labels, mw = _need(labels, _I32, "labels"), _need(model_weight, _F32, "model_weight")
+    if k_valid is not None:
+        k_valid = _need(k_valid, _I32, "k_valid")
+    B, K = scores.shape
+    dev = boxes.device
+    out = torch.empty((B, K, 6), dtype=_F32, device=dev)
+    cnt = torch.empty((B,), dtype=_I32, device=dev)
+    ws, wsb = _ws(lib.hd_wbf_workspace_bytes(B, K), dev)
+    check(lib.hd_wbf(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(mw), _ptr(k_valid), B, K, float(weight_sum),
+                     float(iou_thr), float(skip_thr), _ptr(out), _ptr(cnt), _ptr(ws), wsb, _stream(boxes)), "hd_wbf")
+    return out, cnt

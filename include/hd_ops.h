@@ -79,12 +79,15 @@ hd_status hd_anchor_grid(int n_levels, const int* feat_h, const int* feat_w, con
 
 /* ---- pairwise IoU (assigners; SURVEY.md §8a "Batched pairwise IoU") -------- */
 
-/* Materialised IoU.  a: [B,N,4], b: [B,M,4], m_valid: [B] int32 or NULL (all M valid),
- * out: [B,N,M].  Columns m >= m_valid[b] are written as -1.
+/* Materialised IoU.  a: [B,N,4] with element stride a_bstride between images (N*4 when dense,
+ * 0 to share one set of boxes, e.g. the anchors, across the batch), b: [B,M,4],
+ * m_valid: [B] int32 or NULL (all M valid), out: [B,N,M].
+ * Columns m >= m_valid[b] are written as -1.
  * iou = inter / (area_a + area_b - inter), 0 when the union is <= 0.
  * a, b must be 16-byte aligned. */
-hd_status hd_pairwise_iou(const float* a, const float* b, const int32_t* m_valid, int B, int N,
-                          int M, float* out, hd_stream stream);
+hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const float* b,
+                          const int32_t* m_valid, int B, int N, int M, float* out,
+                          hd_stream stream);
 
 /* Fused IoU + row max/argmax (per box in a) + column max/argmax (per box in b),
  * without materialising [B,N,M].
@@ -92,10 +95,10 @@ hd_status hd_pairwise_iou(const float* a, const float* b, const int32_t* m_valid
  *   gt_max_iou[B,M], gt_argmax[B,M]: best a for each b (ties -> lowest n); -1/-1 for padded b.
  * gt_* may both be NULL to skip the column reduction (then workspace may be NULL). */
 size_t hd_iou_assign_workspace_bytes(int B, int N, int M);
-hd_status hd_iou_assign(const float* a, const float* b, const int32_t* m_valid, int B, int N,
-                        int M, float* max_iou, int32_t* argmax, float* gt_max_iou,
-                        int32_t* gt_argmax, void* workspace, size_t workspace_bytes,
-                        hd_stream stream);
+hd_status hd_iou_assign(const float* a, int64_t a_bstride, const float* b,
+                        const int32_t* m_valid, int B, int N, int M, float* max_iou,
+                        int32_t* argmax, float* gt_max_iou, int32_t* gt_argmax, void* workspace,
+                        size_t workspace_bytes, hd_stream stream);
 
 /* ---- box delta codec (RPN / RoI head regression targets) ------------------- */
 
@@ -250,7 +253,7 @@ hd_status hd_ciou_bwd(const float* pred, const float* target, const float* grad_
  * conf = obj*max_cls > conf_thr (best class only), per-class NMS (iou_thr), best `max_det`.
  * det [B,max_det,6] = (x1,y1,x2,y2,conf,cls), zero padded; det_count [B].
  * Candidate order = conf descending, ties -> lower row index; at most max_nms candidates. */
-size_t hd_yolo_nms_workspace_bytes(int B, int n, int max_nms);
+size_t hd_yolo_nms_workspace_bytes(int B, int n, int max_nms, int max_det);
 hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float conf_thr, float iou_thr,
                       int max_nms, int max_det, float* det, int32_t* det_count, void* workspace,
                       size_t workspace_bytes, hd_stream stream);
