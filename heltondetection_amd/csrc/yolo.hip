@@ -360,78 +360,77 @@ __global__ void yolo_loss_finalize_kernel(const hd_yolo_levels lv, const LevelIn
   loss_out[3] = fc;
 }
 
-// Dense gradient, fast path: the gradient tensor of level l is one contiguous block in memory
-// order (b, y, x, a, c)  [sx = na*no, sa = no, so = 1, sy = W*sx, sb = H*sy].  Each lane writes
-// 4 consecutive floats (16-byte store); the only non-zero is channel 4 (objectness).
-__global__ __launch_bounds__(256) void yolo_grad_dense_nhwc_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
-                                                                   const LevelIndex ix, int B, int l,
-                                                                   const hd_yolo_loss_cfg cfg,
-                                                                   const float* __restrict__ grad_scale,
-                                                                   const float* __restrict__ tobj) {
+// Dense gradient of every level in ONE launch (grid.y = level).  Fast path per level when the
+// gradient tensor is one contiguous block in memory order (b, y, x, a, c)  [sx = na*no, sa = no,
+// so = 1, sy = W*sx, sb = H*sy]: each lane writes 4 consecutive floats (16-byte store); the only
+// non-zero is channel 4 (objectness).  Other layouts: one lane per (cell, channel).
+struct DenseFlags {
+  int fast[HD_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void yolo_grad_dense_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
+                                                              const LevelIndex ix, const DenseFlags flags, int B,
+                                                              const hd_yolo_loss_cfg cfg,
+                                                              const float* __restrict__ grad_scale,
+                                                              const float* __restrict__ tobj) {
+  const int l = blockIdx.y;
   const int no = lv.no, na = lv.na, H = lv.h[l], W = lv.w[l];
   const long long cells = (long long)B * na * H * W;
   const long long total = cells * no;
   const float gobj = grad_scale[0] * (float)B * cfg.obj_gain * cfg.balance[l] / (float)cells;
   const float* to = tobj + ix.first_cell[l];
   float* g = glv.pred[l];
-  for (long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; f0 < total;
-       f0 += (long long)gridDim.x * blockDim.x * 4) {
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    long long mrow = f0 / no;  // memory-order cell index: ((b*H + y)*W + x)*na + a
-    int c = (int)(f0 - mrow * no);
-    // the 4 elements span at most 2 cells; channel 4 occurs at most once (no >= 5)
-    int k4 = 4 - c;            // offset of channel 4 of cell mrow
-    if (k4 < 0) { k4 += no; ++mrow; }
-    if (k4 < 4 && f0 + k4 < total) {
-      const int a = (int)(mrow % na);
-      long long t = mrow / na;
-      const int x = (int)(t % W);
-      t /= W;
-      const int y = (int)(t % H);
-      const int b = (int)(t / H);
-      const long long cell = (((long long)b * na + a) * H + y) * W + x;
-      const float xo = lv.pred[l][b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l] + 4 * lv.so[l]];
-      r[k4] = gobj * (hd_sigmoid(xo) - to[cell]);
+  if (flags.fast[l]) {
+    for (long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; f0 < total;
+         f0 += (long long)gridDim.x * blockDim.x * 4) {
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      long long mrow = f0 / no;  // memory-order cell index: ((b*H + y)*W + x)*na + a
+      int c = (int)(f0 - mrow * no);
+      // the 4 elements span at most 2 cells; channel 4 occurs at most once (no >= 5)
+      int k4 = 4 - c;  // offset of channel 4 of cell mrow
+      if (k4 < 0) {
+        k4 += no;
+        ++mrow;
+      }
+      if (k4 < 4 && f0 + k4 < total) {
+        const int a = (int)(mrow % na);
+        long long t = mrow / na;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const long long cell = (((long long)b * na + a) * H + y) * W + x;
+        const float xo = lv.pred[l][b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l] + 4 * lv.so[l]];
+        r[k4] = gobj * (hd_sigmoid(xo) - to[cell]);
+      }
+      if (f0 + 3 < total) {
+        *reinterpret_cast<float4*>(g + f0) = make_float4(r[0], r[1], r[2], r[3]);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (f0 + k < total) g[f0 + k] = r[k];
+      }
     }
-    if (f0 + 3 < total) {
-      *reinterpret_cast<float4*>(g + f0) = make_float4(r[0], r[1], r[2], r[3]);
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (f0 + k < total) g[f0 + k] = r[k];
+  } else {
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total;
+         f += (long long)gridDim.x * blockDim.x) {
+      const long long cell = f / no;
+      const int c = (int)(f - cell * no);
+      int a;
+      const long long goff = cell_offset(glv, l, (int)cell, &a);
+      float v = 0.0f;
+      if (c == 4) {
+        const long long off = cell_offset(lv, l, (int)cell, &a);
+        v = gobj * (hd_sigmoid(lv.pred[l][off + 4 * lv.so[l]]) - to[cell]);
+      }
+      g[goff + c * glv.so[l]] = v;
     }
   }
 }
 
-// Dense gradient, generic strides: one lane per (cell, channel).
-__global__ __launch_bounds__(256) void yolo_grad_dense_generic_kernel(const hd_yolo_levels lv,
-                                                                      const hd_yolo_levels glv, const LevelIndex ix,
-                                                                      int B, int l, const hd_yolo_loss_cfg cfg,
-                                                                      const float* __restrict__ grad_scale,
-                                                                      const float* __restrict__ tobj) {
-  const int no = lv.no;
-  const long long cells = ix.first_cell[l + 1] - ix.first_cell[l];
-  const long long total = cells * no;
-  const float gobj = grad_scale[0] * (float)B * cfg.obj_gain * cfg.balance[l] / (float)cells;
-  const float* to = tobj + ix.first_cell[l];
-  for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total;
-       f += (long long)gridDim.x * blockDim.x) {
-    const long long cell = f / no;
-    const int c = (int)(f - cell * no);
-    int a;
-    const long long goff = cell_offset(glv, l, (int)cell, &a);
-    float v = 0.0f;
-    if (c == 4) {
-      const long long off = cell_offset(lv, l, (int)cell, &a);
-      v = gobj * (hd_sigmoid(lv.pred[l][off + 4 * lv.so[l]]) - to[cell]);
-    }
-    glv.pred[l][goff + c * glv.so[l]] = v;
-  }
-}
-
-inline bool is_dense_nhwc(const hd_yolo_levels& g, int l) {
+inline bool is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
   const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l];
   return g.so[l] == 1 && g.sa[l] == no && g.sx[l] == na * no && g.sy[l] == W * na * no &&
-         g.sb[l] == H * W * na * no && hd_aligned16(g.pred[l]);
+         (B == 1 || g.sb[l] == H * W * na * no) && hd_aligned16(g.pred[l]);
 }
 
 inline unsigned cap_grid(long long work_items, int per_block) {
@@ -518,39 +517,74 @@ extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, co
   return HD_OK;
 }
 
-extern "C" hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
-                                      const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
-                                      const hd_yolo_loss_cfg* cfg, const float* grad_scale, const void* workspace,
-                                      size_t workspace_bytes, hd_stream stream) {
+static hd_status bwd_common_checks(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                   const hd_yolo_loss_cfg* cfg, const float* grad_scale, const void* workspace,
+                                   size_t workspace_bytes) {
   hd_status st = check_levels(lv, B);
   if (st != HD_OK) return st;
   st = check_levels(grad_lv, B);
   if (st != HD_OK) return st;
-  if (!cfg || !grad_scale || (M > 0 && (!slot_cell || !slot_tbox || !slot_cls))) return HD_ERR_NULL;
-  if (M < 0 || grad_lv->n_levels != lv->n_levels || grad_lv->na != lv->na || grad_lv->no != lv->no)
-    return HD_ERR_SHAPE;
-  const size_t need = hd_yolo_loss_workspace_bytes(lv, B);
-  if (!workspace || workspace_bytes < need) return HD_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
+  if (!cfg || !grad_scale) return HD_ERR_NULL;
+  if (grad_lv->n_levels != lv->n_levels || grad_lv->na != lv->na || grad_lv->no != lv->no) return HD_ERR_SHAPE;
+  for (int l = 0; l < lv->n_levels; ++l)
+    if (grad_lv->h[l] != lv->h[l] || grad_lv->w[l] != lv->w[l]) return HD_ERR_SHAPE;
+  if (!workspace || workspace_bytes < hd_yolo_loss_workspace_bytes(lv, B)) return HD_ERR_WORKSPACE;
+  return HD_OK;
+}
+
+extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                            const hd_yolo_loss_cfg* cfg, const float* grad_scale,
+                                            const void* workspace, size_t workspace_bytes, hd_stream stream) {
+  hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
+  if (st != HD_OK) return st;
+  const LevelIndex ix = make_index(*lv, B);
+  const float* tobj = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + kAccBytes);
+  DenseFlags flags;
+  long long max_total = 0;
+  bool any_fast = false;
+  for (int l = 0; l < HD_MAX_LEVELS; ++l) flags.fast[l] = 0;
+  for (int l = 0; l < lv->n_levels; ++l) {
+    flags.fast[l] = is_dense_nhwc(*grad_lv, l, B) ? 1 : 0;
+    any_fast = any_fast || flags.fast[l];
+    const long long total = (ix.first_cell[l + 1] - ix.first_cell[l]) * lv->no;
+    max_total = std::max(max_total, flags.fast[l] ? (total + 3) / 4 : total);
+  }
+  // one workgroup covers 256 work items per sweep; cap at 16 workgroups per CU and grid-stride the rest
+  long long gx = (max_total + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(yolo_grad_dense_kernel, dim3((unsigned)gx, (unsigned)lv->n_levels), dim3(256), 0,
+                     (hipStream_t)stream, *lv, *grad_lv, ix, flags, B, *cfg, grad_scale, tobj);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                                          const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
+                                          const hd_yolo_loss_cfg* cfg, const float* grad_scale,
+                                          const void* workspace, size_t workspace_bytes, hd_stream stream) {
+  hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
+  if (st != HD_OK) return st;
+  if (M < 0) return HD_ERR_SHAPE;
+  if (M == 0) return HD_OK;
+  if (!slot_cell || !slot_tbox || !slot_cls) return HD_ERR_NULL;
   const LevelIndex ix = make_index(*lv, B);
   float* acc = reinterpret_cast<float*>(const_cast<void*>(workspace));
   float* tobj = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes);
-  for (int l = 0; l < lv->n_levels; ++l) {
-    const long long total = (ix.first_cell[l + 1] - ix.first_cell[l]) * lv->no;
-    if (is_dense_nhwc(*grad_lv, l))
-      hipLaunchKernelGGL(yolo_grad_dense_nhwc_kernel, dim3(cap_grid(total, 1024)), dim3(256), 0, s, *lv, *grad_lv, ix,
-                         B, l, *cfg, grad_scale, tobj);
-    else
-      hipLaunchKernelGGL(yolo_grad_dense_generic_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, s, *lv, *grad_lv,
-                         ix, B, l, *cfg, grad_scale, tobj);
-    HD_RETURN_IF_LAUNCH_FAILED();
-  }
   const long long S = (long long)5 * lv->na * B * M;
-  if (S > 0) {
-    dim3 grid((unsigned)((S + 255) / 256), (unsigned)lv->n_levels);
-    hipLaunchKernelGGL((yolo_pos_kernel<true>), grid, dim3(256), 0, s, *lv, *grad_lv, ix, B, S, slot_cell,
-                       reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj);
-    HD_RETURN_IF_LAUNCH_FAILED();
-  }
+  dim3 grid((unsigned)((S + 255) / 256), (unsigned)lv->n_levels);
+  hipLaunchKernelGGL((yolo_pos_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *lv, *grad_lv, ix, B, S,
+                     slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj);
+  HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
+}
+
+extern "C" hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                                      const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
+                                      const hd_yolo_loss_cfg* cfg, const float* grad_scale, const void* workspace,
+                                      size_t workspace_bytes, hd_stream stream) {
+  hd_status st = hd_yolo_loss_bwd_dense(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes, stream);
+  if (st != HD_OK) return st;
+  return hd_yolo_loss_bwd_pos(lv, grad_lv, B, M, slot_cell, slot_tbox, slot_cls, cfg, grad_scale, workspace,
+                              workspace_bytes, stream);
 }

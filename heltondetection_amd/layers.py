@@ -1,0 +1,82 @@
+"""Conv building blocks shared by the backbones and necks (plain torch.nn; the convolutions run
+on MIOpen/MFMA through PyTorch-ROCm as BASELINE.json's north_star prescribes)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def autopad(k: int, p=None) -> int:
+    return k // 2 if p is None else p
+
+
+class ConvBNAct(nn.Module):
+    """Conv2d(bias=False) + BatchNorm2d + activation (SiLU for the YOLOv5 family, ReLU for ResNet)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
+        self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = ConvBNAct(c1, c_, 1, 1)
+        self.cv2 = ConvBNAct(c_, c2, 3, 1)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        y = self.cv2(self.cv1(x))
+        return x + y if self.add else y
+
+
+class C3(nn.Module):
+    """CSP bottleneck with 3 convolutions (YOLOv5 v6.x)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = ConvBNAct(c1, c_, 1, 1)
+        self.cv2 = ConvBNAct(c1, c_, 1, 1)
+        self.cv3 = ConvBNAct(2 * c_, c2, 1, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+
+class C2f(nn.Module):
+    """YOLOv8-style CSP block (used by the 'YOLOv8-style' PAFPN of the FasterRCNN family, README.md:8)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, e=0.5, act="silu"):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = ConvBNAct(c1, 2 * self.c, 1, 1, act=act)
+        self.cv2 = ConvBNAct((2 + n) * self.c, c2, 1, 1, act=act)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, e=1.0) for _ in range(n))
+
+    def forward(self, x):
+        y = list(self.cv1(x).chunk(2, 1))
+        y.extend(m(y[-1]) for m in self.m)
+        return self.cv2(torch.cat(y, 1))
+
+
+class SPPF(nn.Module):
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = ConvBNAct(c1, c_, 1, 1)
+        self.cv2 = ConvBNAct(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def forward(self, x):
+        x = self.cv1(x)
+        y1 = self.m(x)
+        y2 = self.m(y1)
+        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))

@@ -1,0 +1,101 @@
+"""Necks (reference README.md:8-9,65): YOLOv5 PAFPN; FPN and a YOLOv8-style PAFPN (256 output
+channels) for FasterRCNN, each with a P2-only variant flag.  Plain torch.nn (MIOpen convs)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import C2f, C3, ConvBNAct
+from .registry import NECKS
+
+
+@NECKS.register()
+class YOLOv5PAFPN(nn.Module):
+    """v6.1 head layers 10-23: top-down + bottom-up over (P3, P4, P5)."""
+
+    def __init__(self, in_channels: Sequence[int], depth: float = 0.33):
+        super().__init__()
+        c3, c4, c5 = in_channels
+        n = max(round(3 * depth), 1)
+        self.lat5 = ConvBNAct(c5, c4, 1, 1)
+        self.td4 = C3(2 * c4, c4, n, shortcut=False)
+        self.lat4 = ConvBNAct(c4, c3, 1, 1)
+        self.td3 = C3(2 * c3, c3, n, shortcut=False)
+        self.down3 = ConvBNAct(c3, c3, 3, 2)
+        self.bu4 = C3(2 * c3, c4, n, shortcut=False)
+        self.down4 = ConvBNAct(c4, c4, 3, 2)
+        self.bu5 = C3(2 * c4, c5, n, shortcut=False)
+        self.out_channels = (c3, c4, c5)
+
+    def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
+        p3, p4, p5 = feats
+        l5 = self.lat5(p5)
+        t4 = self.td4(torch.cat((F.interpolate(l5, scale_factor=2.0, mode="nearest"), p4), 1))
+        l4 = self.lat4(t4)
+        o3 = self.td3(torch.cat((F.interpolate(l4, scale_factor=2.0, mode="nearest"), p3), 1))
+        o4 = self.bu4(torch.cat((self.down3(o3), l4), 1))
+        o5 = self.bu5(torch.cat((self.down4(o4), l5), 1))
+        return [o3, o4, o5]
+
+
+@NECKS.register()
+class FPN(nn.Module):
+    """Feature Pyramid Network over (C2..C5) -> (P2..P5) [+P6 by stride-2 subsampling for the RPN]."""
+
+    def __init__(self, in_channels: Sequence[int], out_channels: int = 256, extra_level: bool = True,
+                 p2_only: bool = False):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels)
+        self.output = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+        self.extra_level = extra_level
+        self.p2_only = p2_only  # "P2" variants: only level P2 reaches the heads (README.md:65)
+        self.out_channels = out_channels
+
+    def forward(self, feats):
+        lat = [l(f) for l, f in zip(self.lateral, feats)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[-2:], mode="nearest")
+        outs = [o(x) for o, x in zip(self.output, lat)]
+        if self.p2_only:
+            return outs[:1]
+        if self.extra_level:
+            outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
+        return outs
+
+
+@NECKS.register()
+class PAFPN(nn.Module):
+    """YOLOv8-style PAFPN with a fixed output width (256; README.md:8): 1x1 laterals to `out_channels`,
+    C2f top-down fusion, strided-conv + C2f bottom-up fusion."""
+
+    def __init__(self, in_channels: Sequence[int], out_channels: int = 256, n: int = 1, extra_level: bool = True,
+                 p2_only: bool = False, act: str = "silu"):
+        super().__init__()
+        L = len(in_channels)
+        self.lateral = nn.ModuleList(ConvBNAct(c, out_channels, 1, 1, act=act) for c in in_channels)
+        self.td = nn.ModuleList(C2f(2 * out_channels, out_channels, n, act=act) for _ in range(L - 1))
+        self.down = nn.ModuleList(ConvBNAct(out_channels, out_channels, 3, 2, act=act) for _ in range(L - 1))
+        self.bu = nn.ModuleList(C2f(2 * out_channels, out_channels, n, act=act) for _ in range(L - 1))
+        self.extra_level = extra_level
+        self.p2_only = p2_only
+        self.out_channels = out_channels
+
+    def forward(self, feats):
+        lat = [l(f) for l, f in zip(self.lateral, feats)]
+        L = len(lat)
+        td = [None] * L
+        td[L - 1] = lat[L - 1]
+        for i in range(L - 2, -1, -1):
+            up = F.interpolate(td[i + 1], size=lat[i].shape[-2:], mode="nearest")
+            td[i] = self.td[i](torch.cat((up, lat[i]), 1))
+        outs = [td[0]]
+        for i in range(1, L):
+            outs.append(self.bu[i - 1](torch.cat((self.down[i - 1](outs[-1]), td[i]), 1)))
+        if self.p2_only:
+            return outs[:1]
+        if self.extra_level:
+            outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
+        return outs

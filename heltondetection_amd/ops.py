@@ -40,6 +40,47 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+# ---- optional HIP-event timing of individual C-ABI launches (bench.py's roofline leg) ---------
+# Events are recorded on the stream the kernel is launched on (torch's current stream, the one
+# handed to the C ABI), immediately around the call; nothing is synchronised here.
+_TIMED: dict = {}
+
+
+def enable_timing(*names: str) -> None:
+    _TIMED.clear()
+    for n in names:
+        _TIMED[n] = []
+
+
+def disable_timing() -> None:
+    _TIMED.clear()
+
+
+def collect_timing() -> dict:
+    """After a device synchronise: {name: [ms, ...]} for every timed launch since enable_timing()."""
+    return {n: [a.elapsed_time(b) for a, b in ev] for n, ev in _TIMED.items()}
+
+
+class _timed:
+    __slots__ = ("name", "start")
+
+    def __init__(self, name: str):
+        self.name = name if name in _TIMED else None
+
+    def __enter__(self):
+        if self.name is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            _TIMED[self.name].append((self.start, end))
+        return False
+
+
 def _ws(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
     if nbytes <= 0:
         return None, 0
@@ -86,8 +127,9 @@ def pairwise_iou(a: torch.Tensor, b: torch.Tensor, m_valid: Optional[torch.Tenso
     if m_valid is not None:
         m_valid = _need(m_valid, _I32, "m_valid")
     out = torch.empty((B, N, M), dtype=_F32, device=b.device)
-    check(lib.hd_pairwise_iou(_ptr(a), 0 if shared else N * 4, _ptr(b), _ptr(m_valid), B, N, M, _ptr(out), _stream(b)),
-          "hd_pairwise_iou")
+    with _timed("pairwise_iou"):
+        check(lib.hd_pairwise_iou(_ptr(a), 0 if shared else N * 4, _ptr(b), _ptr(m_valid), B, N, M, _ptr(out),
+                                  _stream(b)), "hd_pairwise_iou")
     return out
 
 
@@ -270,7 +312,8 @@ def yolo_decode(preds: Sequence[torch.Tensor], strides, anchors) -> torch.Tensor
     B = preds[0].shape[0]
     n = sum(p.shape[1] * p.shape[2] * p.shape[3] for p in preds)
     out = torch.empty((B, n, st.no), dtype=_F32, device=preds[0].device)
-    check(lib.hd_yolo_decode(C.byref(st), B, _ptr(out), _stream(out)), "hd_yolo_decode")
+    with _timed("yolo_decode"):
+        check(lib.hd_yolo_decode(C.byref(st), B, _ptr(out), _stream(out)), "hd_yolo_decode")
     return out
 
 
@@ -320,8 +363,9 @@ class _YoloLossFn(torch.autograd.Function):
         dev = preds[0].device
         out = torch.empty((4,), dtype=_F32, device=dev)
         ws, wsb = _ws(lib.hd_yolo_loss_workspace_bytes(C.byref(st), B), dev)
-        check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
-                                   C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
+        with _timed("yolo_loss_fwd"):
+            check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
+                                       C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
         ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d)
         ctx.meta = (strides, anchors, int(M), gains, balance, wsb)
         ctx.mark_non_differentiable(out)
@@ -339,8 +383,12 @@ class _YoloLossFn(torch.autograd.Function):
         B = preds[0].shape[0]
         cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
         gs = grad_total.detach().to(_F32).reshape(1).contiguous()
-        check(lib.hd_yolo_loss_bwd(C.byref(st), C.byref(gst), B, M, _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
-                                   C.byref(cfg), _ptr(gs), _ptr(ws), wsb, _stream(gs)), "hd_yolo_loss_bwd")
+        with _timed("yolo_loss_bwd_dense"):
+            check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(ws), wsb,
+                                             _stream(gs)), "hd_yolo_loss_bwd_dense")
+        check(lib.hd_yolo_loss_bwd_pos(C.byref(st), C.byref(gst), B, M, _ptr(slot_cell), _ptr(slot_tbox),
+                                       _ptr(slot_cls), C.byref(cfg), _ptr(gs), _ptr(ws), wsb, _stream(gs)),
+              "hd_yolo_loss_bwd_pos")
         return (None,) * 6 + tuple(grads)
 
 

@@ -236,6 +236,18 @@ hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_
                            const float* grad_scale, const void* workspace,
                            size_t workspace_bytes, hd_stream stream);
 
+/* The two stages of hd_yolo_loss_bwd as separate launches (same arguments): _dense writes the
+ * whole gradient tensor (zeros + objectness term; the HBM-bound 4*B*n*no-byte write), _pos then
+ * adds the box/class terms of the matched cells with float atomics. */
+hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                 const hd_yolo_loss_cfg* cfg, const float* grad_scale,
+                                 const void* workspace, size_t workspace_bytes, hd_stream stream);
+hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                               const int32_t* slot_cell, const float* slot_tbox,
+                               const int32_t* slot_cls, const hd_yolo_loss_cfg* cfg,
+                               const float* grad_scale, const void* workspace,
+                               size_t workspace_bytes, hd_stream stream);
+
 /* ---- CIoU on matched pairs (SURVEY.md §8a "CIoU loss fwd + bwd") ----------- */
 
 /* pred, target [P,4] xyxy; ciou [P]; loss = 1 - ciou is left to the caller.
