@@ -1,0 +1,188 @@
+"""The CPU checker checked: oracle/hd_oracle.c against the committed golden vectors and against the
+independent restatement oracle/torch_ref.py, plus algebraic properties (hypothesis).
+Parity is UNPINNED to the reference (no source in the snapshot): these tests pin the
+oracle to itself over time and to a second implementation."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from oracle import c_oracle as co, torch_ref as tr
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_v1.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_golden_anchors(gold):
+    base = np.stack([co.anchor_base(s, [0.5, 1.0, 2.0]) for s in ([32.0], [64.0], [128.0])])
+    assert np.array_equal(base, gold["anchor_base"])
+    assert np.array_equal(co.anchor_grid([12, 6, 3], [12, 6, 3], [8, 16, 32], base, 0.5), gold["anchor_grid"])
+
+
+def test_golden_iou_and_assign(gold):
+    assert np.array_equal(co.pairwise_iou(gold["iou_a"], gold["iou_b"], gold["iou_mv"]), gold["iou_out"])
+    r = co.iou_assign(gold["iou_a"], gold["iou_b"], gold["iou_mv"])
+    for x, k in zip(r, ("asg_max", "asg_arg", "asg_gmax", "asg_garg")):
+        assert np.array_equal(x, gold[k])
+    t = tr.iou_assign(torch.from_numpy(gold["iou_a"]), torch.from_numpy(gold["iou_b"]), torch.from_numpy(gold["iou_mv"]))
+    for x, k in zip(t, ("asg_max", "asg_arg", "asg_gmax", "asg_garg")):
+        assert np.array_equal(x.numpy(), gold[k])
+
+
+def test_golden_nms(gold):
+    keep, cnt = co.nms_batched(gold["nms_boxes"], gold["nms_scores"], gold["nms_cls"], None, 0.1, 0.5, 0, 64)
+    assert np.array_equal(keep, gold["nms_keep"]) and np.array_equal(cnt, gold["nms_count"])
+    k2, c2 = tr.nms_batched(torch.from_numpy(gold["nms_boxes"]), torch.from_numpy(gold["nms_scores"]),
+                            torch.from_numpy(gold["nms_cls"]), None, 0.1, 0.5, 0, 64)
+    assert np.array_equal(k2.numpy(), gold["nms_keep"])
+
+
+def test_golden_rpn(gold):
+    rois, sc, cnt = co.rpn_proposals(gold["rpn_logits"], gold["rpn_deltas"], gold["anchor_grid"], [432, 108, 27], 100, 40,
+                                     0.7, 2.0, 96.0, 96.0)
+    assert np.array_equal(cnt, gold["rpn_count"])
+    assert np.array_equal(rois, gold["rpn_rois"]) and np.array_equal(sc, gold["rpn_scores"])
+
+
+def test_golden_roi_align(gold):
+    feats = [gold["roi_f0"], gold["roi_f1"], gold["roi_f2"]]
+    out = co.roi_align_fwd(feats, gold["roi_rois"], 3, [1 / 8, 1 / 16, 1 / 32], 2, True, 3, 56.0, 4)
+    assert np.array_equal(out, gold["roi_out"])
+    assert np.array_equal(co.roi_level_map(gold["roi_rois"], 3, 3, 56.0, 4), gold["roi_levels"])
+    # layout independence of the restatement itself
+    out2 = co.roi_align_fwd(feats, gold["roi_rois"], 3, [1 / 8, 1 / 16, 1 / 32], 2, True, 3, 56.0, 4, layout="nhwc")
+    assert np.array_equal(out, out2)
+
+
+def test_golden_yolo(gold):
+    preds = [gold["y_p0"], gold["y_p1"], gold["y_p2"]]
+    assert np.array_equal(co.yolo_decode(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS), gold["y_dec"])
+    cell, tbox, cls = co.yolo_assign(H.yolo_shapes(64, 9), H.YOLO_STRIDES, H.YOLO_ANCHORS, gold["y_gtb"], gold["y_gtc"],
+                                     gold["y_mv"], 4.0)
+    assert np.array_equal(cell, gold["y_cell"]) and np.array_equal(tbox, gold["y_tbox"]) and np.array_equal(cls, gold["y_cls"])
+    loss, grads, _, _ = co.yolo_loss(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, cls, 12)
+    assert np.allclose(loss, gold["y_loss"], rtol=1e-6, atol=0)
+    for g, k in zip(grads, ("y_g0", "y_g1", "y_g2")):
+        assert np.allclose(g, gold[k], rtol=1e-6, atol=1e-9)
+    det, cnt = co.yolo_nms(gold["y_dec"], 0.3, 0.45, 500, 20)
+    assert np.array_equal(det, gold["y_det"]) and np.array_equal(cnt, gold["y_dcnt"])
+
+
+def test_golden_ciou_and_wbf(gold):
+    assert np.array_equal(co.ciou_fwd(gold["ciou_p"], gold["ciou_t"]), gold["ciou_out"])
+    assert np.array_equal(co.ciou_bwd(gold["ciou_p"], gold["ciou_t"], np.ones(64, np.float32)), gold["ciou_grad"])
+    out, cnt = co.wbf(gold["wbf_boxes"], gold["wbf_scores"], gold["wbf_labels"], np.ones_like(gold["wbf_scores"]), None,
+                      3.0, 0.55, 0.05)
+    assert np.array_equal(out, gold["wbf_out"]) and np.array_equal(cnt, gold["wbf_count"])
+
+
+# ---------------------------------------------------------------- cross-implementation, fresh seeds
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_c_vs_torch_restatement_random(seed):
+    a = H.boxes_batch(2, 257, 320, seed)
+    b = H.boxes_batch(2, 13, 320, seed + 100)
+    mv = torch.tensor([13, 4], dtype=torch.int32)
+    assert np.array_equal(co.pairwise_iou(a.numpy(), b.numpy(), mv.numpy()), tr.pairwise_iou(a, b, mv).numpy())
+    boxes = H.clustered_boxes(2, 400, 320, seed + 200)
+    scores = H.distinct_scores(2, 400, seed + 300)
+    k1, c1 = co.nms_batched(boxes.numpy(), scores.numpy(), None, None, 0.2, 0.45, 0, 50)
+    k2, c2 = tr.nms_batched(boxes, scores, None, None, 0.2, 0.45, 0, 50)
+    assert np.array_equal(k1, k2.numpy()) and np.array_equal(c1, c2.numpy())
+
+
+def test_yolo_loss_grad_vs_autograd():
+    preds = H.yolo_preds(2, 96, 11, 5)
+    from heltondetection_amd import synthetic as syn
+    gtb, gtc, mv = syn.make_targets(2, 96, syn.make_generator(6), "coco", 6, 16)
+    shapes = H.yolo_shapes(96, 11)
+    cell, tbox, cls = co.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb.numpy(), gtc.numpy(), mv.numpy())
+    loss, grads, _, _ = co.yolo_loss([p.numpy() for p in preds], H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, cls, 16)
+    pt = [p.clone().requires_grad_(True) for p in preds]
+    lt = tr.yolo_loss(pt, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb, gtc, mv)
+    lt[0].backward()
+    assert abs(float(lt[0].detach()) - loss[0]) / abs(loss[0]) < 1e-5
+    for g, p in zip(grads, pt):
+        assert H.rel_err(g, p.grad.numpy()) < 1e-4
+
+
+def test_roi_align_backward_is_adjoint_of_forward():
+    """<RoIAlign(f), g> == <f, RoIAlign^T(g)> for the C restatement (forward is linear in f)."""
+    rng = np.random.default_rng(0)
+    feats = [rng.standard_normal((2, 5, 24 // s, 24 // s)).astype(np.float32) for s in (1, 2)]
+    rois = np.array([[0, 2.0, 3.0, 17.0, 20.0], [1, 0.0, 0.0, 23.9, 23.9], [1, 5.5, 5.5, 6.0, 6.2]], np.float32)
+    out = co.roi_align_fwd(feats, rois, 4, [1.0, 0.5], 2, True, 2, 8.0, 2)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    gf = co.roi_align_bwd([f.shape for f in feats], rois, g, [1.0, 0.5], 2, True, 2, 8.0, 2)
+    lhs = float((out.astype(np.float64) * g).sum())
+    rhs = float(sum((a.astype(np.float64) * b).sum() for a, b in zip(feats, gf)))
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+# ---------------------------------------------------------------- properties
+box = st.tuples(st.floats(0, 100, width=32), st.floats(0, 100, width=32), st.floats(0.5, 60, width=32),
+                st.floats(0.5, 60, width=32)).map(lambda t: [t[0], t[1], t[0] + t[2], t[1] + t[3]])
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(box, min_size=1, max_size=12), st.lists(box, min_size=1, max_size=6))
+def test_iou_symmetry_range_and_ciou_bound(a, b):
+    A = np.array([a], np.float32)
+    Bx = np.array([b], np.float32)
+    i1 = co.pairwise_iou(A, Bx)
+    i2 = co.pairwise_iou(Bx, A)
+    assert np.array_equal(i1[0], i2[0].T)            # bit-symmetric
+    assert (i1 >= 0).all() and (i1 <= 1.0 + 1e-6).all()
+    n = min(len(a), len(b))
+    ci = co.ciou_fwd(A[0, :n], Bx[0, :n])
+    assert (ci <= np.diag(i1[0])[:n] + 1e-5).all()    # CIoU <= IoU
+    self_iou = co.pairwise_iou(A, A)
+    assert np.allclose(np.diag(self_iou[0]), 1.0, atol=1e-6)
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.lists(box, min_size=2, max_size=40), st.integers(0, 2 ** 31 - 1))
+def test_nms_idempotent_and_permutation_invariant(bx, seed):
+    rng = np.random.default_rng(seed)
+    boxes = np.array([bx], np.float32)
+    n = boxes.shape[1]
+    scores = rng.permutation(n).astype(np.float32)[None] / n + 0.01   # distinct
+    keep, cnt = co.nms_batched(boxes, scores, None, None, 0.0, 0.5, 0, n)
+    k = keep[0, : cnt[0]]
+    keep2, cnt2 = co.nms_batched(boxes[:, k], scores[:, k], None, None, 0.0, 0.5, 0, len(k))
+    assert cnt2[0] == len(k) and np.array_equal(keep2[0, : cnt2[0]], np.arange(len(k)))
+    perm = rng.permutation(n)
+    keep3, cnt3 = co.nms_batched(boxes[:, perm], scores[:, perm], None, None, 0.0, 0.5, 0, n)
+    assert cnt3[0] == cnt[0] and np.array_equal(perm[keep3[0, : cnt3[0]]], k)
+
+
+def test_roi_align_constant_and_ramp_features():
+    f = np.full((1, 2, 16, 16), 3.5, np.float32)
+    rois = np.array([[0, 2.0, 2.0, 12.0, 11.0], [0, 4.2, 3.1, 9.7, 13.3]], np.float32)
+    out = co.roi_align_fwd([f], rois, 5, [1.0], 2, True, 2, 224.0, 4)
+    assert np.allclose(out, 3.5, atol=1e-6)
+    ramp = np.tile(np.arange(16, dtype=np.float32)[None, None, None, :], (1, 1, 16, 1))
+    out = co.roi_align_fwd([ramp], rois[:1], 5, [1.0], 2, True, 2, 224.0, 4)
+    centers = 2.0 - 0.5 + (np.arange(5) + 0.5) * 2.0  # bilinear sampling of a linear ramp is exact
+    assert np.allclose(out[0, 0, 0], centers, atol=1e-5)
+
+
+def test_edge_cases_empty_and_degenerate():
+    z = np.zeros((1, 0, 4), np.float32)
+    assert co.pairwise_iou(z, z).shape == (1, 0, 0)
+    mx, am, gmx, gam = co.iou_assign(np.zeros((1, 3, 4), np.float32), np.zeros((1, 2, 4), np.float32), np.array([0], np.int32))
+    assert (mx == -1).all() and (am == -1).all() and (gmx == -1).all() and (gam == -1).all()
+    keep, cnt = co.nms_batched(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4), np.float32), None, np.array([0], np.int32), -1.0, 0.5, 0, 4)
+    assert cnt[0] == 0 and (keep == -1).all()
+    # zero-area boxes: IoU 0, never suppress each other
+    b = np.array([[[5, 5, 5, 5], [5, 5, 5, 5]]], np.float32)
+    assert (co.pairwise_iou(b, b) == 0).all()
+    keep, cnt = co.nms_batched(b, np.array([[0.9, 0.8]], np.float32), None, None, 0.0, 0.5, 0, 2)
+    assert cnt[0] == 2
