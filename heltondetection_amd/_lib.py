@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -86,9 +86,9 @@ SIGNATURES = {
     "hd_yolo_assign": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "hd_yolo_loss_workspace_bytes": (_Z, [_P, _I]),
     "hd_yolo_loss_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "hd_yolo_loss_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "hd_yolo_loss_bwd_dense": (_I, [_P, _P, _I, _P, _P, _P, _Z, _P]),
-    "hd_yolo_loss_bwd_pos": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd_dense": (_I, [_P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd_pos": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "hd_ciou_fwd": (_I, [_P, _P, _L, _P, _P]),
     "hd_ciou_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
     "hd_yolo_nms_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -93,6 +93,44 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
   }
 }
 
+// Lane = column variant for M >= 48.  A wave owns 64 consecutive b boxes (one per lane, held in
+// registers with their areas for the whole kernel) and walks the rows of its workgroup's row
+// tile; the a box of a row is wave-uniform (scalar loads), so per output there is no LDS access,
+// no index arithmetic and no per-lane a-box traffic: just the IoU arithmetic and one 4-byte
+// store per lane, 256 B contiguous per wave store (full-rate per MI355X_MICROARCH "plain stores
+// of the same shape").  The 4 waves of a workgroup cover column chunks round-robin, so a
+// workgroup writes whole rows of the [N, M] output.
+constexpr int kColRows = 64;
+
+__global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __restrict__ a, int64_t a_bstride4,
+                                                                const float4* __restrict__ b,
+                                                                const int32_t* __restrict__ m_valid, int N, int M,
+                                                                float* __restrict__ out) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mv = m_valid ? min(m_valid[img], M) : M;
+  const int n0 = blockIdx.x * kColRows;
+  const int n1 = min(N, n0 + kColRows);
+  const float4* __restrict__ aa = a + (int64_t)img * a_bstride4;
+  const float4* __restrict__ bb = b + (int64_t)img * M;
+  float* __restrict__ o = out + (int64_t)img * N * M;
+  const int nchunks = (M + 63) >> 6;
+  for (int chunk = wave; chunk < nchunks; chunk += 4) {
+    const int m = (chunk << 6) + lane;
+    const bool col_ok = m < M;
+    const bool col_valid = m < mv;
+    const float4 gb = col_ok ? bb[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float garea = hd_box_area(gb);
+    float* __restrict__ oc = o + m;
+#pragma unroll 4
+    for (int n = n0; n < n1; ++n) {
+      const float4 ab = aa[n];  // wave-uniform
+      const float v = col_valid ? hd_iou_full(ab, hd_box_area(ab), gb, garea) : -1.0f;
+      if (col_ok) oc[(int64_t)n * M] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 
 constexpr int kAssignThreads = 256;
@@ -207,11 +245,20 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
   if (!a || !b || !out) return HD_ERR_NULL;
   if (!hd_aligned16(a) || !hd_aligned16(b)) return HD_ERR_ALIGN;
   const int64_t T = (int64_t)N * M;
+  if (B > 65535) return HD_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const float4* a4c = reinterpret_cast<const float4*>(a);
+  const float4* b4c = reinterpret_cast<const float4*>(b);
+  if (M >= 48) {  // >= 75 % lane use in the last column chunk
+    dim3 cgrid((unsigned)((N + kColRows - 1) / kColRows), (unsigned)B);
+    hipLaunchKernelGGL(pairwise_iou_cols_kernel, cgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M, out);
+    HD_RETURN_IF_LAUNCH_FAILED();
+    return HD_OK;
+  }
   const int64_t per_block = (int64_t)kIouThreads * 4 * kIouIters;
   const int64_t gx = (T + per_block - 1) / per_block;
-  if (gx > 0x7fffffff || B > 65535) return HD_ERR_SHAPE;
+  if (gx > 0x7fffffff) return HD_ERR_SHAPE;
   dim3 grid((unsigned)gx, (unsigned)B);
-  hipStream_t s = (hipStream_t)stream;
   const bool vec = (T % 4 == 0) && hd_aligned16(out);
   const bool lds = M <= kIouLdsMaxM;
   const float4* a4 = reinterpret_cast<const float4*>(a);

@@ -55,74 +55,77 @@ inline hd_status check_levels(const hd_yolo_levels* lv, int B) {
 }
 
 // ------------------------------------------------------------------------------------ decode
+//
+// One workgroup = 64 consecutive output rows of one (level, image, anchor) group, staged through
+// an LDS tile: the gather side reads each input row (`no` contiguous floats when so == 1) with
+// consecutive lanes on consecutive channels, applies the decode formula, and drops the value at
+// its output position in LDS; the store side then streams the tile out linearly with 16-byte
+// stores (1 KiB per wave store).  Per-row index work (y, x, input offset) is done once per row
+// by 64 lanes, not per element; the element -> (row, channel) split is one multiply.
+constexpr int kDecRows = 64;
 
-__global__ __launch_bounds__(256) void yolo_decode_kernel(const hd_yolo_levels lv, const LevelIndex ix, int B,
-                                                          float* __restrict__ out) {
-  const int no = lv.no;
+struct DecodePlan {
+  int first_block[HD_MAX_LEVELS + 1];  // first workgroup of each level
+  int tiles[HD_MAX_LEVELS];            // ceil(H*W / kDecRows)
+};
+
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const hd_yolo_levels lv, const LevelIndex ix,
+                                                          const DecodePlan plan, int B, float* __restrict__ out) {
+  extern __shared__ float s_tile[];  // [kDecRows * no] + row tables
+  const int no = lv.no, na = lv.na;
+  long long* s_off = reinterpret_cast<long long*>(s_tile + (size_t)kDecRows * no + (((size_t)kDecRows * no) & 1));
+  int* s_x = reinterpret_cast<int*>(s_off + kDecRows);
+  int* s_y = s_x + kDecRows;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < HD_MAX_LEVELS; ++k)
+    if (k < lv.n_levels && (int)blockIdx.x >= plan.first_block[k]) l = k;
+  int rem = (int)blockIdx.x - plan.first_block[l];
+  const int tile = rem % plan.tiles[l];
+  rem /= plan.tiles[l];
+  const int a = rem % na;
+  const int b = rem / na;
+  const int H = lv.h[l], W = lv.w[l], HW = H * W;
+  const int row0 = tile * kDecRows;
+  const int rows = min(kDecRows, HW - row0);
+  if (threadIdx.x < rows) {
+    const int rr = row0 + threadIdx.x;
+    const int y = rr / W, x = rr - y * W;
+    s_x[threadIdx.x] = x;
+    s_y[threadIdx.x] = y;
+    s_off[threadIdx.x] = b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l];
+  }
+  __syncthreads();
+  const float* __restrict__ pr = lv.pred[l];
+  const long long so = lv.so[l];
+  const float stride = lv.stride[l], aw = lv.anchor_w[l][a], ah = lv.anchor_h[l][a];
+  const float inv_no = 1.0f / (float)no;
+  const int elems = rows * no;
+  for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+    int r = (int)(((float)i + 0.5f) * inv_no);
+    int c = i - r * no;
+    if (c < 0) { --r; c += no; }
+    if (c >= no) { ++r; c -= no; }
+    const float s = hd_sigmoid(pr[s_off[r] + c * so]);
+    float v;
+    if (c == 0) v = (s * 2.0f - 0.5f + (float)s_x[r]) * stride;
+    else if (c == 1) v = (s * 2.0f - 0.5f + (float)s_y[r]) * stride;
+    else if (c == 2) v = (s * 2.0f) * (s * 2.0f) * aw;
+    else if (c == 3) v = (s * 2.0f) * (s * 2.0f) * ah;
+    else v = s;
+    s_tile[i] = v;
+  }
+  __syncthreads();
   const long long n_total = ix.first_row[lv.n_levels];
-  const long long total = (long long)B * n_total * no;
-  for (long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; f0 < total;
-       f0 += (long long)gridDim.x * blockDim.x * 4) {
-    float r[4];
-    long long grow = f0 / no;  // global row = b*n_total + row
-    int c = (int)(f0 - grow * no);
-    // decode (b, level, a, y, x) of the first element, then step
-    int b = (int)(grow / n_total);
-    long long row = grow - (long long)b * n_total;
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < HD_MAX_LEVELS; ++k)
-      if (k < lv.n_levels && row >= ix.first_row[k]) l = k;
-    long long rr = row - ix.first_row[l];
-    int W = lv.w[l], H = lv.h[l];
-    int x = (int)(rr % W);
-    long long t = rr / W;
-    int y = (int)(t % H);
-    int a = (int)(t / H);
-    const float* p = lv.pred[l] + b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (f0 + k < total) {
-        const float s = hd_sigmoid(p[c * lv.so[l]]);
-        float v;
-        if (c == 0) v = (s * 2.0f - 0.5f + (float)x) * lv.stride[l];
-        else if (c == 1) v = (s * 2.0f - 0.5f + (float)y) * lv.stride[l];
-        else if (c == 2) v = (s * 2.0f) * (s * 2.0f) * lv.anchor_w[l][a];
-        else if (c == 3) v = (s * 2.0f) * (s * 2.0f) * lv.anchor_h[l][a];
-        else v = s;
-        r[k] = v;
-        if (++c == no) {  // next row: advance (x, y, a, level, b)
-          c = 0;
-          ++row;
-          if (++x == W) {
-            x = 0;
-            if (++y == H) {
-              y = 0;
-              if (++a == lv.na) {
-                a = 0;
-                ++l;
-                if (l == lv.n_levels) {
-                  l = 0;
-                  ++b;
-                  row = 0;
-                }
-                W = lv.w[l];
-                H = lv.h[l];
-              }
-            }
-          }
-          if (b < B) p = lv.pred[l] + b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l];
-        }
-      } else {
-        r[k] = 0.0f;
-      }
-    }
-    if (f0 + 3 < total) {
-      *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (f0 + k < total) out[f0 + k] = r[k];
-    }
+  float* __restrict__ o = out + (((long long)b * n_total + ix.first_row[l] + (long long)a * HW + row0) * no);
+  if ((reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
+    const int words = elems >> 2;
+    const float4* t4 = reinterpret_cast<const float4*>(s_tile);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    for (int q = threadIdx.x; q < words; q += blockDim.x) o4[q] = t4[q];
+    for (int i = (words << 2) + threadIdx.x; i < elems; i += blockDim.x) o[i] = s_tile[i];
+  } else {
+    for (int i = threadIdx.x; i < elems; i += blockDim.x) o[i] = s_tile[i];
   }
 }
 
@@ -188,22 +191,47 @@ __global__ __launch_bounds__(256) void yolo_assign_kernel(const hd_yolo_levels l
 }
 
 // ------------------------------------------------------------------------------------ loss
+//
+// tobj (objectness targets) lives in the workspace, one float per cell.  Its index order per
+// level follows the MEMORY order of the prediction tensor when that tensor is dense channels-last
+// ([B,H,W,na,no] contiguous: index m = ((b*H + y)*W + x)*na + a, so the objectness logit of cell
+// m sits at pred[m*no + 4] and both the objectness pass and the dense gradient pass stream
+// linearly with no index decomposition), and the logical order ((b*na + a)*H + y)*W + x
+// otherwise.  Forward and backward derive the flag from the same `lv`, so they always agree.
 
-struct CellRef {
-  const float* p;
-  int a;
+struct LevelFlags {
+  int pred_dense[HD_MAX_LEVELS];  // prediction tensor is dense channels-last
+  int grad_dense[HD_MAX_LEVELS];  // gradient tensor is dense channels-last (bwd only)
 };
 
-__device__ __forceinline__ long long cell_offset(const hd_yolo_levels& lv, int l, int cell, int* a_out) {
+inline bool is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
+  const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l];
+  return g.so[l] == 1 && g.sa[l] == no && g.sx[l] == na * no && g.sy[l] == W * na * no &&
+         (B == 1 || g.sb[l] == H * W * na * no) && hd_aligned16(g.pred[l]);
+}
+
+struct CellPos {
+  int b, a, gj, gi;
+};
+
+__device__ __forceinline__ CellPos cell_decompose(const hd_yolo_levels& lv, int l, int cell) {
   const int W = lv.w[l], H = lv.h[l];
-  const int gi = cell % W;
+  CellPos c;
+  c.gi = cell % W;
   int r = cell / W;
-  const int gj = r % H;
+  c.gj = r % H;
   r /= H;
-  const int a = r % lv.na;
-  const int b = r / lv.na;
-  *a_out = a;
-  return b * lv.sb[l] + a * lv.sa[l] + gj * lv.sy[l] + gi * lv.sx[l];
+  c.a = r % lv.na;
+  c.b = r / lv.na;
+  return c;
+}
+
+__device__ __forceinline__ long long cell_offset(const hd_yolo_levels& lv, int l, const CellPos c) {
+  return c.b * lv.sb[l] + c.a * lv.sa[l] + c.gj * lv.sy[l] + c.gi * lv.sx[l];
+}
+
+__device__ __forceinline__ int tobj_index(const hd_yolo_levels& lv, int l, int dense, const CellPos c, int cell) {
+  return dense ? ((c.b * lv.h[l] + c.gj) * lv.w[l] + c.gi) * lv.na + c.a : cell;
 }
 
 // box part of one positive: sigmoids, xywh (cell units) -> xyxy
@@ -222,25 +250,40 @@ __device__ __forceinline__ float4 tbox_xyxy(const float4 tb) {
   return make_float4(tb.x - tb.z * 0.5f, tb.y - tb.w * 0.5f, tb.x + tb.z * 0.5f, tb.y + tb.w * 0.5f);
 }
 
-// grid: (ceil(S/256), n_levels); each wave owns 64 consecutive slots of one level
+// Matched-cell terms.  grid: (ceil(S / (4 waves * 8 slots)), n_levels).  A wave owns 8 consecutive
+// slots (short serial chain: the per-slot work is a dependent gather + CIoU), finds the matched
+// ones with one ballot and spends all 64 lanes on the `no` channels of each matched cell.
+// Backward accumulates the bias gradient (sum over cells, per channel) in LDS first and issues
+// one global atomic per touched channel per workgroup.
+constexpr int kSlotsPerWave = 8;
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
-                                                       const LevelIndex ix, int B, long long S,
+                                                       const LevelIndex ix, const LevelFlags fl, int B, long long S,
                                                        const int32_t* __restrict__ slot_cell,
                                                        const float4* __restrict__ slot_tbox,
                                                        const int32_t* __restrict__ slot_cls,
                                                        const hd_yolo_loss_cfg cfg,
                                                        const float* __restrict__ grad_scale, float* __restrict__ acc,
-                                                       float* __restrict__ tobj) {
+                                                       float* __restrict__ tobj, float* __restrict__ grad_bias,
+                                                       const float* __restrict__ obj_part, int n_part) {
+  extern __shared__ float s_gb[];  // [na*no] bias-gradient partials (BWD with grad_bias only)
   const int l = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int no = lv.no, nc = lv.no - 5;
+  const int wave = threadIdx.x >> 6;
+  const int no = lv.no, nc = lv.no - 5, na = lv.na;
+  const bool do_bias = BWD && grad_bias != nullptr;
+  if (do_bias) {
+    for (int i = threadIdx.x; i < na * no; i += blockDim.x) s_gb[i] = 0.0f;
+    __syncthreads();
+  }
+  const long long s0 = ((long long)blockIdx.x * 4 + wave) * kSlotsPerWave;
+  const long long s = s0 + lane;
   const long long so = lv.so[l];
   const float st = lv.stride[l];
   int32_t my_cell = -1, my_cls = 0;
   float4 my_tb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (s < S) {
+  if (lane < kSlotsPerWave && s < S) {
     my_cell = slot_cell[(long long)l * S + s];
     if (my_cell >= 0) {
       my_cls = slot_cls[(long long)l * S + s];
@@ -268,10 +311,9 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
     tb.y = __shfl(my_tb.y, j, 64);
     tb.z = __shfl(my_tb.z, j, 64);
     tb.w = __shfl(my_tb.w, j, 64);
-    int a;
-    const long long off = cell_offset(lv, l, cell, &a);
-    const float* p = lv.pred[l] + off;
-    const float aw = lv.anchor_w[l][a] / st, ah = lv.anchor_h[l][a] / st;
+    const CellPos cp = cell_decompose(lv, l, cell);
+    const float* p = lv.pred[l] + cell_offset(lv, l, cp);
+    const float aw = lv.anchor_w[l][cp.a] / st, ah = lv.anchor_h[l][cp.a] / st;
     // every lane evaluates the (wave-uniform) box term; lanes then split the class channels
     float sg[4];
     const float4 pb = yolo_pbox(p[0], p[so], p[2 * so], p[3 * so], aw, ah, sg);
@@ -287,24 +329,31 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
       cnt += 1.0f;
       if (lane == 0) {
         const float cl = ci > 0.0f ? ci : 0.0f;
-        atomicMax(reinterpret_cast<int*>(tobj + ix.first_cell[l] + cell), __float_as_int(cl));
+        const int ti = tobj_index(lv, l, fl.pred_dense[l], cp, cell);
+        atomicMax(reinterpret_cast<int*>(tobj + ix.first_cell[l] + ti), __float_as_int(cl));
       }
     } else {
       float gc[4];
       hd_ciou<true>(pb, tx, gc);
-      float* g = glv.pred[l] + cell_offset(glv, l, cell, &a);
+      float* g = glv.pred[l] + cell_offset(glv, l, cp);
       const long long gso = glv.so[l];
-      if (lane == 0) {
+      if (lane < 4) {
         const float gpx = -(gc[0] + gc[2]), gpy = -(gc[1] + gc[3]);
         const float gpw = -(gc[2] - gc[0]) * 0.5f, gph = -(gc[3] - gc[1]) * 0.5f;
-        atomicAdd(g + 0 * gso, gbox * gpx * 2.0f * sg[0] * (1.0f - sg[0]));
-        atomicAdd(g + 1 * gso, gbox * gpy * 2.0f * sg[1] * (1.0f - sg[1]));
-        atomicAdd(g + 2 * gso, gbox * gpw * 8.0f * sg[2] * sg[2] * (1.0f - sg[2]) * aw);
-        atomicAdd(g + 3 * gso, gbox * gph * 8.0f * sg[3] * sg[3] * (1.0f - sg[3]) * ah);
+        float v;
+        if (lane == 0) v = gbox * gpx * 2.0f * sg[0] * (1.0f - sg[0]);
+        else if (lane == 1) v = gbox * gpy * 2.0f * sg[1] * (1.0f - sg[1]);
+        else if (lane == 2) v = gbox * gpw * 8.0f * sg[2] * sg[2] * (1.0f - sg[2]) * aw;
+        else v = gbox * gph * 8.0f * sg[3] * sg[3] * (1.0f - sg[3]) * ah;
+        atomicAdd(g + lane * gso, v);
+        if (do_bias) atomicAdd(&s_gb[cp.a * no + lane], v);
       }
       if (nc > 1)
-        for (int c = lane; c < nc; c += 64)
-          atomicAdd(g + (5 + c) * gso, gcls * (hd_sigmoid(p[(5 + c) * so]) - (c == tc ? 1.0f : 0.0f)));
+        for (int c = lane; c < nc; c += 64) {
+          const float v = gcls * (hd_sigmoid(p[(5 + c) * so]) - (c == tc ? 1.0f : 0.0f));
+          atomicAdd(g + (5 + c) * gso, v);
+          if (do_bias) atomicAdd(&s_gb[cp.a * no + 5 + c], v);
+        }
     }
   }
   if (!BWD && lane == 0 && cnt > 0.0f) {
@@ -312,30 +361,48 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
     atomicAdd(acc + l * 4 + 1, cnt);
     atomicAdd(acc + l * 4 + 2, sum_cls);
   }
-  (void)no;
+  if (do_bias) {
+    // workgroup 0 of each level folds in the dense kernel's per-workgroup objectness partials
+    if (blockIdx.x == 0 && obj_part != nullptr) {
+      for (int a = 0; a < na; ++a) {
+        float v = 0.0f;
+        for (int k = threadIdx.x; k < n_part; k += blockDim.x) v += obj_part[((size_t)l * n_part + k) * na + a];
+        v = hd_wave_sum(v);
+        if (lane == 0) atomicAdd(&s_gb[a * no + 4], v);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < na * no; i += blockDim.x) {
+      const float v = s_gb[i];
+      if (v != 0.0f) atomicAdd(grad_bias + (long long)l * na * no + i, v);
+    }
+  }
 }
 
 // objectness BCE over every cell of one level; grid (blocks, n_levels)
-__global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels lv, const LevelIndex ix, int B,
-                                                           const float* __restrict__ tobj, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels lv, const LevelIndex ix,
+                                                           const LevelFlags fl, int B, const float* __restrict__ tobj,
+                                                           float* __restrict__ acc) {
   __shared__ float s_part[4];
   const int l = blockIdx.y;
-  const long long cells = ix.first_cell[l + 1] - ix.first_cell[l];
+  const int cells = (int)(ix.first_cell[l + 1] - ix.first_cell[l]);
   const float* to = tobj + ix.first_cell[l];
+  const float* pr = lv.pred[l];
   float sum = 0.0f;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells;
-       c += (long long)gridDim.x * blockDim.x) {
-    int a;
-    const long long off = cell_offset(lv, l, (int)c, &a);
-    sum += hd_bce_logits(lv.pred[l][off + 4 * lv.so[l]], to[c]);
+  if (fl.pred_dense[l]) {
+    const int no = lv.no;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < cells; m += gridDim.x * blockDim.x)
+      sum += hd_bce_logits(pr[(long long)m * no + 4], to[m]);
+  } else {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += gridDim.x * blockDim.x) {
+      const CellPos cp = cell_decompose(lv, l, c);
+      sum += hd_bce_logits(pr[cell_offset(lv, l, cp) + 4 * lv.so[l]], to[c]);
+    }
   }
   sum = hd_wave_sum(sum);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    atomicAdd(acc + l * 4 + 3, tot);
-  }
+  if (threadIdx.x == 0) atomicAdd(acc + l * 4 + 3, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
 __global__ void yolo_loss_finalize_kernel(const hd_yolo_levels lv, const LevelIndex ix, int B,
@@ -360,77 +427,102 @@ __global__ void yolo_loss_finalize_kernel(const hd_yolo_levels lv, const LevelIn
   loss_out[3] = fc;
 }
 
-// Dense gradient of every level in ONE launch (grid.y = level).  Fast path per level when the
-// gradient tensor is one contiguous block in memory order (b, y, x, a, c)  [sx = na*no, sa = no,
-// so = 1, sy = W*sx, sb = H*sy]: each lane writes 4 consecutive floats (16-byte store); the only
-// non-zero is channel 4 (objectness).  Other layouts: one lane per (cell, channel).
-struct DenseFlags {
-  int fast[HD_MAX_LEVELS];
-};
-
+// Dense gradient of every level in ONE launch (grid.y = level): zeros everywhere except the
+// objectness channel.  Fast path (gradient AND prediction dense channels-last): the tensor is cut
+// into units of 4 cells = `no` 16-byte words; a lane produces one word, so a wave stores 1 KiB
+// contiguous.  Channel 4 of cell j of a unit falls in word (j*no+4)>>2, component (j*no+4)&3 — the
+// only lanes that load anything (objectness logit + tobj, both linear in the cell index).
+// All index arithmetic is 32-bit; there is one unsigned division per word.
 __global__ __launch_bounds__(256) void yolo_grad_dense_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
-                                                              const LevelIndex ix, const DenseFlags flags, int B,
+                                                              const LevelIndex ix, const LevelFlags fl, int B,
                                                               const hd_yolo_loss_cfg cfg,
                                                               const float* __restrict__ grad_scale,
-                                                              const float* __restrict__ tobj) {
+                                                              const float* __restrict__ tobj,
+                                                              float* __restrict__ grad_bias /* partials */) {
+  __shared__ float s_gb[HD_MAX_ANCHORS];
   const int l = blockIdx.y;
-  const int no = lv.no, na = lv.na, H = lv.h[l], W = lv.w[l];
-  const long long cells = (long long)B * na * H * W;
-  const long long total = cells * no;
+  const int no = lv.no, na = lv.na;
+  const uint32_t cells = (uint32_t)(ix.first_cell[l + 1] - ix.first_cell[l]);
   const float gobj = grad_scale[0] * (float)B * cfg.obj_gain * cfg.balance[l] / (float)cells;
   const float* to = tobj + ix.first_cell[l];
+  const float* pr = lv.pred[l];
   float* g = glv.pred[l];
-  if (flags.fast[l]) {
-    for (long long f0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; f0 < total;
-         f0 += (long long)gridDim.x * blockDim.x * 4) {
+  if (threadIdx.x < HD_MAX_ANCHORS) s_gb[threadIdx.x] = 0.0f;
+  __syncthreads();
+  if (fl.grad_dense[l] && fl.pred_dense[l]) {
+    const uint32_t units = cells >> 2;
+    const uint32_t words = units * (uint32_t)no;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    const uint32_t w1 = (uint32_t)(no + 4) >> 2, w2 = (uint32_t)(2 * no + 4) >> 2, w3 = (uint32_t)(3 * no + 4) >> 2;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < words; q += gridDim.x * blockDim.x) {
+      const uint32_t u = q / (uint32_t)no;
+      const uint32_t t = q - u * (uint32_t)no;
       float r[4] = {0.f, 0.f, 0.f, 0.f};
-      long long mrow = f0 / no;  // memory-order cell index: ((b*H + y)*W + x)*na + a
-      int c = (int)(f0 - mrow * no);
-      // the 4 elements span at most 2 cells; channel 4 occurs at most once (no >= 5)
-      int k4 = 4 - c;  // offset of channel 4 of cell mrow
-      if (k4 < 0) {
-        k4 += no;
-        ++mrow;
+      int j = -1;
+      if (t == 1u) j = 0;
+      else if (t == w1) j = 1;
+      else if (t == w2) j = 2;
+      else if (t == w3) j = 3;
+      if (j >= 0) {
+        const uint32_t m = u * 4u + (uint32_t)j;
+        const float v = gobj * (hd_sigmoid(pr[(size_t)m * no + 4]) - to[m]);
+        r[(j * no + 4) & 3] = v;
+        if (grad_bias) atomicAdd(&s_gb[m % (uint32_t)na], v);
       }
-      if (k4 < 4 && f0 + k4 < total) {
-        const int a = (int)(mrow % na);
-        long long t = mrow / na;
-        const int x = (int)(t % W);
-        t /= W;
-        const int y = (int)(t % H);
-        const int b = (int)(t / H);
-        const long long cell = (((long long)b * na + a) * H + y) * W + x;
-        const float xo = lv.pred[l][b * lv.sb[l] + a * lv.sa[l] + y * lv.sy[l] + x * lv.sx[l] + 4 * lv.so[l]];
-        r[k4] = gobj * (hd_sigmoid(xo) - to[cell]);
-      }
-      if (f0 + 3 < total) {
-        *reinterpret_cast<float4*>(g + f0) = make_float4(r[0], r[1], r[2], r[3]);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (f0 + k < total) g[f0 + k] = r[k];
+      g4[q] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    // cells not covered by whole units (cells % 4, at most 3): scalar tail by the first workgroup
+    if (blockIdx.x == 0) {
+      const uint32_t tail = (cells - units * 4u) * (uint32_t)no;
+      for (uint32_t i = threadIdx.x; i < tail; i += blockDim.x) {
+        const uint32_t m = units * 4u + i / (uint32_t)no;
+        const uint32_t c = i % (uint32_t)no;
+        float v = 0.0f;
+        if (c == 4u) {
+          v = gobj * (hd_sigmoid(pr[(size_t)m * no + 4]) - to[m]);
+          if (grad_bias) atomicAdd(&s_gb[m % (uint32_t)na], v);
+        }
+        g[(size_t)m * no + c] = v;
       }
     }
   } else {
+    const long long total = (long long)cells * no;
     for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total;
          f += (long long)gridDim.x * blockDim.x) {
-      const long long cell = f / no;
-      const int c = (int)(f - cell * no);
-      int a;
-      const long long goff = cell_offset(glv, l, (int)cell, &a);
+      const int cell = (int)(f / no);
+      const int c = (int)(f - (long long)cell * no);
+      const CellPos cp = cell_decompose(lv, l, cell);
       float v = 0.0f;
       if (c == 4) {
-        const long long off = cell_offset(lv, l, (int)cell, &a);
-        v = gobj * (hd_sigmoid(lv.pred[l][off + 4 * lv.so[l]]) - to[cell]);
+        const int ti = tobj_index(lv, l, fl.pred_dense[l], cp, cell);
+        v = gobj * (hd_sigmoid(pr[cell_offset(lv, l, cp) + 4 * lv.so[l]]) - to[ti]);
+        if (grad_bias) atomicAdd(&s_gb[cp.a], v);
       }
-      g[goff + c * glv.so[l]] = v;
+      g[cell_offset(glv, l, cp) + c * glv.so[l]] = v;
     }
+  }
+  // per-workgroup partial of the objectness bias gradient: plain store, reduced by yolo_pos_kernel<true>
+  // (no zero-init, and no same-address global atomics: 3 x 4096 of those serialise to ~65 us)
+  if (grad_bias) {
+    __syncthreads();
+    if (threadIdx.x < na) grad_bias[((size_t)l * gridDim.x + blockIdx.x) * na + threadIdx.x] = s_gb[threadIdx.x];
   }
 }
 
-inline bool is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
-  const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l];
-  return g.so[l] == 1 && g.sa[l] == no && g.sx[l] == na * no && g.sy[l] == W * na * no &&
-         (B == 1 || g.sb[l] == H * W * na * no) && hd_aligned16(g.pred[l]);
+constexpr int kDenseMaxBlocks = 4096;  // 16 workgroups per CU per level, grid-stride beyond
+
+// Workgroups per level of the dense-gradient launch: 256 work items per workgroup sweep.
+inline unsigned dense_grid_x(const hd_yolo_levels& lv, const LevelFlags& fl, const LevelIndex& ix) {
+  long long max_items = 0;
+  for (int l = 0; l < lv.n_levels; ++l) {
+    const long long total = (ix.first_cell[l + 1] - ix.first_cell[l]) * lv.no;
+    const bool fast = fl.grad_dense[l] && fl.pred_dense[l];
+    max_items = std::max(max_items, fast ? (total + 3) / 4 : total);
+  }
+  long long gx = (max_items + 255) / 256;
+  if (gx > kDenseMaxBlocks) gx = kDenseMaxBlocks;
+  if (gx < 1) gx = 1;
+  return (unsigned)gx;
 }
 
 inline unsigned cap_grid(long long work_items, int per_block) {
@@ -438,6 +530,15 @@ inline unsigned cap_grid(long long work_items, int per_block) {
   if (b < 1) b = 1;
   if (b > 4096) b = 4096;
   return (unsigned)b;
+}
+
+inline LevelFlags make_flags(const hd_yolo_levels& lv, const hd_yolo_levels* glv, int B) {
+  LevelFlags f;
+  for (int l = 0; l < HD_MAX_LEVELS; ++l) {
+    f.pred_dense[l] = (l < lv.n_levels && is_dense_nhwc(lv, l, B)) ? 1 : 0;
+    f.grad_dense[l] = (glv && l < lv.n_levels && is_dense_nhwc(*glv, l, B)) ? 1 : 0;
+  }
+  return f;
 }
 
 }  // namespace
@@ -448,9 +549,22 @@ extern "C" hd_status hd_yolo_decode(const hd_yolo_levels* lv, int B, float* out,
   if (!out) return HD_ERR_NULL;
   if (!hd_aligned16(out)) return HD_ERR_ALIGN;
   const LevelIndex ix = make_index(*lv, B);
-  const long long total = (long long)B * ix.first_row[lv->n_levels] * lv->no;
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3(cap_grid(total, 1024)), dim3(256), 0, (hipStream_t)stream, *lv, ix, B,
-                     out);
+  DecodePlan plan;
+  long long blocks = 0;
+  for (int l = 0; l <= HD_MAX_LEVELS; ++l) {
+    plan.first_block[l] = (int)blocks;
+    if (l < lv->n_levels) {
+      plan.tiles[l] = (lv->h[l] * lv->w[l] + kDecRows - 1) / kDecRows;
+      blocks += (long long)plan.tiles[l] * lv->na * B;
+    } else if (l < HD_MAX_LEVELS) {
+      plan.tiles[l] = 1;
+    }
+  }
+  if (blocks > 0x7fffffffLL) return HD_ERR_SHAPE;
+  const size_t lds = ((size_t)kDecRows * lv->no + 1) * sizeof(float) + kDecRows * (sizeof(long long) + 2 * sizeof(int));
+  if (lds > 64 * 1024) return HD_ERR_SHAPE;  // no > ~250 channels would need a smaller row tile
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *lv, ix, plan,
+                     B, out);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -475,13 +589,23 @@ extern "C" hd_status hd_yolo_assign(const hd_yolo_levels* lv, const float* gt_bo
   return HD_OK;
 }
 
-// workspace = [acc: 256 B][tobj: total cells * 4 B]
+// workspace = [acc: 256 B][bias-gradient partials: n_levels * kDenseMaxBlocks * na floats]
+//             [tobj: total cells * 4 B]
 static constexpr size_t kAccBytes = 256;
 
+static size_t part_bytes(const hd_yolo_levels* lv) {
+  return hd_align_up((size_t)lv->n_levels * kDenseMaxBlocks * lv->na * sizeof(float), 256);
+}
+
 extern "C" size_t hd_yolo_loss_workspace_bytes(const hd_yolo_levels* lv, int B) {
-  if (!lv || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS || B <= 0) return 0;
+  if (!lv || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS || B <= 0 || lv->na <= 0) return 0;
   const LevelIndex ix = make_index(*lv, B);
-  return kAccBytes + hd_align_up((size_t)ix.first_cell[lv->n_levels] * sizeof(float), 256);
+  return kAccBytes + part_bytes(lv) + hd_align_up((size_t)ix.first_cell[lv->n_levels] * sizeof(float), 256);
+}
+
+static dim3 pos_grid(long long S, int n_levels) {
+  const long long per_block = 4 * kSlotsPerWave;
+  return dim3((unsigned)((S + per_block - 1) / per_block), (unsigned)n_levels);
 }
 
 extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, const int32_t* slot_cell,
@@ -497,20 +621,23 @@ extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, co
   if (!hd_aligned16(workspace) || (M > 0 && !hd_aligned16(slot_tbox))) return HD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const LevelIndex ix = make_index(*lv, B);
+  const LevelFlags fl = make_flags(*lv, nullptr, B);
   float* acc = reinterpret_cast<float*>(workspace);
-  float* tobj = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kAccBytes);
-  if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return HD_ERR_LAUNCH;
+  float* tobj = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kAccBytes + part_bytes(lv));
+  if (hipMemsetAsync(acc, 0, kAccBytes, s) != hipSuccess) return HD_ERR_LAUNCH;
+  if (hipMemsetAsync(tobj, 0, (size_t)ix.first_cell[lv->n_levels] * sizeof(float), s) != hipSuccess)
+    return HD_ERR_LAUNCH;
   const long long S = (long long)5 * lv->na * B * M;
   if (S > 0) {
-    dim3 grid((unsigned)((S + 255) / 256), (unsigned)lv->n_levels);
-    hipLaunchKernelGGL((yolo_pos_kernel<false>), grid, dim3(256), 0, s, *lv, *lv, ix, B, S, slot_cell,
-                       reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, (const float*)nullptr, acc, tobj);
+    hipLaunchKernelGGL((yolo_pos_kernel<false>), pos_grid(S, lv->n_levels), dim3(256), 0, s, *lv, *lv, ix, fl, B, S,
+                       slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, (const float*)nullptr,
+                       acc, tobj, (float*)nullptr, (const float*)nullptr, 0);
     HD_RETURN_IF_LAUNCH_FAILED();
   }
   long long max_cells = 0;
   for (int l = 0; l < lv->n_levels; ++l) max_cells = std::max(max_cells, ix.first_cell[l + 1] - ix.first_cell[l]);
-  dim3 ogrid(cap_grid(max_cells, 256 * 4), (unsigned)lv->n_levels);
-  hipLaunchKernelGGL(yolo_obj_fwd_kernel, ogrid, dim3(256), 0, s, *lv, ix, B, tobj, acc);
+  dim3 ogrid(cap_grid(max_cells, 256 * 2), (unsigned)lv->n_levels);
+  hipLaunchKernelGGL(yolo_obj_fwd_kernel, ogrid, dim3(256), 0, s, *lv, ix, fl, B, tobj, acc);
   HD_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, s, *lv, ix, B, *cfg, acc, loss_out);
   HD_RETURN_IF_LAUNCH_FAILED();
@@ -534,57 +661,56 @@ static hd_status bwd_common_checks(const hd_yolo_levels* lv, const hd_yolo_level
 
 extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
                                             const hd_yolo_loss_cfg* cfg, const float* grad_scale,
-                                            const void* workspace, size_t workspace_bytes, hd_stream stream) {
+                                            float* grad_bias, const void* workspace, size_t workspace_bytes,
+                                            hd_stream stream) {
   hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
   if (st != HD_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
   const LevelIndex ix = make_index(*lv, B);
-  const float* tobj = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + kAccBytes);
-  DenseFlags flags;
-  long long max_total = 0;
-  bool any_fast = false;
-  for (int l = 0; l < HD_MAX_LEVELS; ++l) flags.fast[l] = 0;
-  for (int l = 0; l < lv->n_levels; ++l) {
-    flags.fast[l] = is_dense_nhwc(*grad_lv, l, B) ? 1 : 0;
-    any_fast = any_fast || flags.fast[l];
-    const long long total = (ix.first_cell[l + 1] - ix.first_cell[l]) * lv->no;
-    max_total = std::max(max_total, flags.fast[l] ? (total + 3) / 4 : total);
-  }
-  // one workgroup covers 256 work items per sweep; cap at 16 workgroups per CU and grid-stride the rest
-  long long gx = (max_total + 255) / 256;
-  if (gx > 4096) gx = 4096;
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(yolo_grad_dense_kernel, dim3((unsigned)gx, (unsigned)lv->n_levels), dim3(256), 0,
-                     (hipStream_t)stream, *lv, *grad_lv, ix, flags, B, *cfg, grad_scale, tobj);
+  const LevelFlags fl = make_flags(*lv, grad_lv, B);
+  const float* tobj =
+      reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + kAccBytes + part_bytes(lv));
+  float* part = grad_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes)
+                          : nullptr;
+  const unsigned gx = dense_grid_x(*lv, fl, ix);
+  hipLaunchKernelGGL(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
+                     B, *cfg, grad_scale, tobj, part);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
 extern "C" hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
                                           const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
-                                          const hd_yolo_loss_cfg* cfg, const float* grad_scale,
+                                          const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
                                           const void* workspace, size_t workspace_bytes, hd_stream stream) {
   hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
   if (st != HD_OK) return st;
   if (M < 0) return HD_ERR_SHAPE;
-  if (M == 0) return HD_OK;
-  if (!slot_cell || !slot_tbox || !slot_cls) return HD_ERR_NULL;
+  if (M == 0 && !grad_bias) return HD_OK;
+  if (M > 0 && (!slot_cell || !slot_tbox || !slot_cls)) return HD_ERR_NULL;
   const LevelIndex ix = make_index(*lv, B);
-  float* acc = reinterpret_cast<float*>(const_cast<void*>(workspace));
-  float* tobj = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes);
+  const LevelFlags fl = make_flags(*lv, grad_lv, B);
+  char* wsb = reinterpret_cast<char*>(const_cast<void*>(workspace));
+  float* acc = reinterpret_cast<float*>(wsb);
+  const float* part = reinterpret_cast<const float*>(wsb + kAccBytes);
+  float* tobj = reinterpret_cast<float*>(wsb + kAccBytes + part_bytes(lv));
   const long long S = (long long)5 * lv->na * B * M;
-  dim3 grid((unsigned)((S + 255) / 256), (unsigned)lv->n_levels);
-  hipLaunchKernelGGL((yolo_pos_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *lv, *grad_lv, ix, B, S,
-                     slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj);
+  const size_t lds = grad_bias ? (size_t)lv->na * lv->no * sizeof(float) : 0;
+  dim3 grid = S > 0 ? pos_grid(S, lv->n_levels) : dim3(1, (unsigned)lv->n_levels);  // M == 0: partial reduce only
+  hipLaunchKernelGGL((yolo_pos_kernel<true>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl, B, S,
+                     slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj,
+                     grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
 extern "C" hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
                                       const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
-                                      const hd_yolo_loss_cfg* cfg, const float* grad_scale, const void* workspace,
-                                      size_t workspace_bytes, hd_stream stream) {
-  hd_status st = hd_yolo_loss_bwd_dense(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes, stream);
+                                      const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                                      const void* workspace, size_t workspace_bytes, hd_stream stream) {
+  hd_status st =
+      hd_yolo_loss_bwd_dense(lv, grad_lv, B, cfg, grad_scale, grad_bias, workspace, workspace_bytes, stream);
   if (st != HD_OK) return st;
-  return hd_yolo_loss_bwd_pos(lv, grad_lv, B, M, slot_cell, slot_tbox, slot_cls, cfg, grad_scale, workspace,
-                              workspace_bytes, stream);
+  return hd_yolo_loss_bwd_pos(lv, grad_lv, B, M, slot_cell, slot_tbox, slot_cls, cfg, grad_scale, grad_bias,
+                              workspace, workspace_bytes, stream);
 }

@@ -40,6 +40,7 @@ class YOLOv5Head(nn.Module):
         self.cls_gain = cls_gain * self.nc / 80.0 * 3.0 / self.nl
         self.obj_gain = obj_gain * (img_size / 640.0) ** 2 * 3.0 / self.nl
         self.balance = tuple(balance)
+        self.bias_grad_in_loss = True
         self._init_bias()
 
     def _init_bias(self):
@@ -52,7 +53,10 @@ class YOLOv5Head(nn.Module):
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         views = []
         for conv, f in zip(self.m, feats):
-            y = conv(f).float()
+            # bias.detach(): the bias gradient comes from the loss kernels (ops.yolo_loss(biases=...)),
+            # not from a framework reduction over the dense [B, na*no, H, W] gradient
+            bias = conv.bias.detach() if (self.training and self.bias_grad_in_loss) else conv.bias
+            y = F.conv2d(f, conv.weight, bias).float()
             if not y.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous(memory_format=torch.channels_last)
             B, _, H, W = y.shape
@@ -62,8 +66,9 @@ class YOLOv5Head(nn.Module):
     def loss(self, preds, gt_boxes, gt_cls, m_valid):
         shapes = [(self.na, p.shape[2], p.shape[3], self.no) for p in preds]
         slots = self.assigner(shapes, self.strides, self.anchors, gt_boxes, gt_cls, m_valid)
+        biases = [c.bias for c in self.m] if (self.training and self.bias_grad_in_loss) else None
         return ops.yolo_loss(preds, self.strides, self.anchors, slots, gt_cls.shape[1], self.box_gain, self.obj_gain,
-                             self.cls_gain, self.balance)
+                             self.cls_gain, self.balance, biases=biases)
 
     @torch.no_grad()
     def predict(self, preds, conf_thr=0.25, iou_thr=0.45, max_nms=30000, max_det=300):

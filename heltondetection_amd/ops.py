@@ -350,11 +350,14 @@ def _loss_cfg(box_gain, obj_gain, cls_gain, balance) -> YoloLossCfg:
 
 
 class _YoloLossFn(torch.autograd.Function):
-    """total loss (scalar) + detached components; gradients flow to the raw head outputs."""
+    """total loss (scalar) + detached components; gradients flow to the raw head outputs and, when
+    the Detect-conv biases are passed along, straight to those biases (sum over cells computed
+    inside the HIP kernels, so autograd never reduces the dense gradient for the bias)."""
 
     @staticmethod
-    def forward(ctx, strides, anchors, slots, M, gains, balance, *preds):
+    def forward(ctx, strides, anchors, slots, M, gains, balance, n_pred, *tensors):
         lib = _lib.load()
+        preds, biases = tensors[:n_pred], tensors[n_pred:]
         preds_d = [p.detach() for p in preds]
         st = _yolo_levels(preds_d, strides, anchors)
         B = preds[0].shape[0]
@@ -367,7 +370,8 @@ class _YoloLossFn(torch.autograd.Function):
             check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
                                        C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
         ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d)
-        ctx.meta = (strides, anchors, int(M), gains, balance, wsb)
+        ctx.meta = (strides, anchors, int(M), gains, balance, wsb, n_pred,
+                    [(tuple(b.shape), b.dtype) for b in biases])
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
@@ -375,7 +379,7 @@ class _YoloLossFn(torch.autograd.Function):
     def backward(ctx, grad_total, _grad_parts):
         lib = _lib.load()
         slot_cell, slot_tbox, slot_cls, ws, *preds = ctx.saved_tensors
-        strides, anchors, M, gains, balance, wsb = ctx.meta
+        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta = ctx.meta
         st = _yolo_levels(preds, strides, anchors)
         # gradient tensors keep the producer's memory order (dense channels-last fast path)
         grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=p.device) for p in preds]
@@ -383,20 +387,30 @@ class _YoloLossFn(torch.autograd.Function):
         B = preds[0].shape[0]
         cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
         gs = grad_total.detach().to(_F32).reshape(1).contiguous()
+        gbias = None
+        if bias_meta:
+            gbias = torch.zeros((len(preds), st.na * st.no), dtype=_F32, device=gs.device)
         with _timed("yolo_loss_bwd_dense"):
-            check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(ws), wsb,
-                                             _stream(gs)), "hd_yolo_loss_bwd_dense")
+            check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias),
+                                             _ptr(ws), wsb, _stream(gs)), "hd_yolo_loss_bwd_dense")
         check(lib.hd_yolo_loss_bwd_pos(C.byref(st), C.byref(gst), B, M, _ptr(slot_cell), _ptr(slot_tbox),
-                                       _ptr(slot_cls), C.byref(cfg), _ptr(gs), _ptr(ws), wsb, _stream(gs)),
-              "hd_yolo_loss_bwd_pos")
-        return (None,) * 6 + tuple(grads)
+                                       _ptr(slot_cls), C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws), wsb,
+                                       _stream(gs)), "hd_yolo_loss_bwd_pos")
+        bias_grads = tuple(gbias[l].view(shape).to(dtype) for l, (shape, dtype) in enumerate(bias_meta))
+        return (None,) * 7 + tuple(grads) + bias_grads
 
 
 def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, box_gain: float = 0.05,
-              obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4)):
-    """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached)."""
+              obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4),
+              biases: Optional[Sequence[torch.Tensor]] = None):
+    """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached).
+
+    ``biases``: optionally the per-level Detect-conv bias parameters ([na*no] each) whose values are
+    already folded into ``preds`` (the conv ran with ``bias.detach()``); their gradients are then
+    produced by the loss kernels."""
+    biases = tuple(biases) if biases is not None else ()
     return _YoloLossFn.apply(tuple(strides), tuple(tuple(tuple(a) for a in lv) for lv in anchors), slots, int(M),
-                             (box_gain, obj_gain, cls_gain), tuple(balance), *preds)
+                             (box_gain, obj_gain, cls_gain), tuple(balance), len(preds), *preds, *biases)
 
 
 class _CIoUFn(torch.autograd.Function):

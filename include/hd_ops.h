@@ -228,24 +228,30 @@ hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, const int32_t
                            const hd_yolo_loss_cfg* cfg, float* loss_out, void* workspace,
                            size_t workspace_bytes, hd_stream stream);
 /* Loss backward: writes d(total)/d(pred) * grad_scale[0] densely into grad_lv->pred[l]
- * (same strides as lv).  workspace must be the one hd_yolo_loss_fwd filled.
- * grad_scale: device [1] float (upstream gradient of `total`). */
+ * (any strides; dense channels-last is the fast path).  workspace must be the one
+ * hd_yolo_loss_fwd filled.  grad_scale: device [1] float (upstream gradient of `total`).
+ * grad_bias: NULL, or device [n_levels, na*no], ZEROED BY THE CALLER, into which the
+ * sum-over-cells of the gradient per head channel is accumulated (= the gradient of the Detect
+ * conv's bias; computed here so the framework need not reduce the dense gradient). */
 hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
                            const int32_t* slot_cell, const float* slot_tbox,
                            const int32_t* slot_cls, const hd_yolo_loss_cfg* cfg,
-                           const float* grad_scale, const void* workspace,
+                           const float* grad_scale, float* grad_bias, const void* workspace,
                            size_t workspace_bytes, hd_stream stream);
 
 /* The two stages of hd_yolo_loss_bwd as separate launches (same arguments): _dense writes the
- * whole gradient tensor (zeros + objectness term; the HBM-bound 4*B*n*no-byte write), _pos then
- * adds the box/class terms of the matched cells with float atomics. */
+ * whole gradient tensor (zeros + objectness term; the HBM-bound 4*B*n*no-byte write) and leaves
+ * per-workgroup objectness bias partials in the workspace; _pos (must follow _dense on the same
+ * stream, same grad_lv) adds the box/class terms of the matched cells with float atomics and
+ * folds everything into grad_bias. */
 hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
                                  const hd_yolo_loss_cfg* cfg, const float* grad_scale,
-                                 const void* workspace, size_t workspace_bytes, hd_stream stream);
+                                 float* grad_bias, const void* workspace, size_t workspace_bytes,
+                                 hd_stream stream);
 hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
                                const int32_t* slot_cell, const float* slot_tbox,
                                const int32_t* slot_cls, const hd_yolo_loss_cfg* cfg,
-                               const float* grad_scale, const void* workspace,
+                               const float* grad_scale, float* grad_bias, const void* workspace,
                                size_t workspace_bytes, hd_stream stream);
 
 /* ---- CIoU on matched pairs (SURVEY.md §8a "CIoU loss fwd + bwd") ----------- */

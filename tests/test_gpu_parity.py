@@ -284,7 +284,8 @@ def test_yolo_loss_fwd_bwd(gpu, ops, no, layout):
             conv.requires_grad_(True)
             pd.append(conv)
     views = pd if layout == "dense" else [c.view(B, 3, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in pd]
-    total, parts = ops.yolo_loss(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, 24)
+    biases = [torch.zeros(3 * no, device=gpu, requires_grad=True) for _ in preds]  # values already in preds
+    total, parts = ops.yolo_loss(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, 24, biases=biases)
     (total * 0.5).backward()
     assert H.max_rel_elem(parts.cpu().numpy(), r_loss, 1e-6) < TOL
     for l, p in enumerate(pd):
@@ -292,6 +293,9 @@ def test_yolo_loss_fwd_bwd(gpu, ops, no, layout):
         if layout != "dense":
             g = g.view(B, 3, no, g.shape[2], g.shape[3]).permute(0, 1, 3, 4, 2)
         assert H.rel_err(g.cpu().numpy(), r_grads[l]) < TOL
+        # bias gradient = sum of the dense gradient over (b, y, x), per (anchor, channel)
+        ref_b = r_grads[l].astype(np.float64).sum(axis=(0, 2, 3)).reshape(-1)
+        assert H.rel_err(biases[l].grad.cpu().numpy(), ref_b) < TOL
 
 
 def test_yolo_nms(gpu, ops):
