@@ -45,3 +45,57 @@ class YOLOv5(nn.Module):
 
 def build_detector(cfg: Dict) -> nn.Module:
     return DETECTORS.build(cfg)
+
+
+@DETECTORS.register()
+class FasterRCNN(nn.Module):
+    """Two-stage detector (README.md:8,65): ResNet50 + FPN | PAFPN (256 ch) [+ P2-only variants] + RPN +
+    RoIAlign head (standard | Decoupled)."""
+
+    def __init__(self, backbone: Optional[Dict] = None, neck: Optional[Dict] = None, rpn_head: Optional[Dict] = None,
+                 roi_head: Optional[Dict] = None, num_classes: int = 80):
+        super().__init__()
+        self.backbone = BACKBONES.build(backbone or dict(type="ResNet50"))
+        self.neck = NECKS.build(neck or dict(type="PAFPN", out_channels=256), in_channels=self.backbone.out_channels)
+        ch = self.neck.out_channels
+        p2_only = getattr(self.neck, "p2_only", False)
+        if rpn_head is None:
+            rpn_head = dict(type="RPNHead", in_channels=ch)
+            if p2_only:  # the single stride-4 level carries all five anchor scales
+                rpn_head.update(strides=(4,), sizes=[[32.0, 64.0, 128.0, 256.0, 512.0]])
+        self.rpn_head = HEADS.build(rpn_head)
+        if roi_head is None:
+            roi_head = dict(type="RoIHead", in_channels=ch, num_classes=num_classes, decoupled=True)
+            if p2_only:
+                roi_head.update(featmap_strides=(4,))
+        self.roi_head = HEADS.build(roi_head)
+
+    def extract(self, images):
+        return self.neck(self.backbone(images))
+
+    def forward_train(self, images, gt_boxes, gt_cls, m_valid):
+        feats = self.extract(images)
+        img_hw = images.shape[-2:]
+        logits, deltas = self.rpn_head(feats)
+        anchors, level_sizes = self.rpn_head.anchors_for(feats)
+        l_rpn_cls, l_rpn_reg = self.rpn_head.loss(logits, deltas, anchors, gt_boxes, m_valid)
+        rois, _, count = self.rpn_head.proposals(logits, deltas, anchors, level_sizes, img_hw, True)
+        rois5, cls_t, reg_t, ok, is_fg = self.roi_head.sample(rois, count, gt_boxes, gt_cls, m_valid)
+        cls_logits, box_deltas = self.roi_head(feats, rois5)
+        l_cls, l_reg = self.roi_head.loss(cls_logits, box_deltas, cls_t, reg_t, ok, is_fg)
+        total = l_rpn_cls + l_rpn_reg + l_cls + l_reg
+        return total, torch.stack([total.detach(), l_rpn_cls.detach(), l_rpn_reg.detach(), l_cls.detach(), l_reg.detach()])
+
+    @torch.no_grad()
+    def forward_test(self, images):
+        feats = self.extract(images)
+        img_hw = images.shape[-2:]
+        logits, deltas = self.rpn_head(feats)
+        anchors, level_sizes = self.rpn_head.anchors_for(feats)
+        rois, _, count = self.rpn_head.proposals(logits, deltas, anchors, level_sizes, img_hw, False)
+        return self.roi_head.predict(feats, rois, count, img_hw)
+
+    def forward(self, images, gt_boxes=None, gt_cls=None, m_valid=None):
+        if gt_boxes is not None:
+            return self.forward_train(images, gt_boxes, gt_cls, m_valid)
+        return self.forward_test(images)

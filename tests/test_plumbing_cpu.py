@@ -1,0 +1,71 @@
+"""BASELINE.json configs[0]: YOLOv5s 640x640 bs=2 on PyTorch-CPU, synthetic images + random boxes —
+plumbing only (registry -> backbone -> neck -> head -> loss), no GPU.  The product has no CPU ops,
+so the test monkeypatches the two op calls the head makes with the oracle (test infrastructure)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+
+
+def test_registry_builds_all_detectors():
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.registry import ASSIGNERS, BACKBONES, DETECTORS, HEADS, NECKS
+    assert {"YOLOv5", "FasterRCNN"} <= set(DETECTORS.names())
+    assert {"CSPDarknet", "ResNet50"} <= set(BACKBONES.names())
+    assert {"YOLOv5PAFPN", "FPN", "PAFPN"} <= set(NECKS.names())
+    assert {"YOLOv5Head", "RPNHead", "RoIHead"} <= set(HEADS.names())
+    assert {"YOLOv5Assigner", "MaxIoUAssigner"} <= set(ASSIGNERS.names())
+    m = build_detector(dict(type="YOLOv5", variant="s"))
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 7.235) < 0.01   # nominal YOLOv5s size
+    with pytest.raises(KeyError):
+        build_detector(dict(type="NoSuchDetector"))
+
+    from heltondetection_amd.registry import NECKS as N
+
+    @N.register("IdentityNeck")
+    class IdentityNeck(torch.nn.Module):  # user-defined component, selectable by name
+        def __init__(self, in_channels, depth=0.33):
+            super().__init__()
+            self.out_channels = tuple(in_channels)
+
+        def forward(self, feats):
+            return feats
+
+    m2 = build_detector(dict(type="YOLOv5", variant="n", neck=dict(type="IdentityNeck")))
+    assert isinstance(m2.neck, IdentityNeck)
+
+
+@pytest.mark.timeout(600)
+def test_yolov5s_640_bs2_cpu_plumbing(monkeypatch):
+    from heltondetection_amd import ops, synthetic as syn
+    from heltondetection_amd.detectors import build_detector
+
+    captured = {}
+
+    def fake_assign(shapes, strides, anchors, gt_boxes, gt_cls, m_valid, anchor_t=4.0):
+        captured["targets"] = (gt_boxes, gt_cls, m_valid, anchor_t)
+        return None
+
+    def fake_loss(preds, strides, anchors, slots, M, box_gain, obj_gain, cls_gain, balance, biases=None):
+        gtb, gtc, mv, at = captured["targets"]
+        total, lb, lo, lc = tr.yolo_loss(list(preds), strides, anchors, gtb, gtc, mv, at, box_gain, obj_gain, cls_gain, balance)
+        return total, torch.stack([total.detach(), lb, lo, lc])
+
+    monkeypatch.setattr(ops, "yolo_assign", fake_assign)
+    monkeypatch.setattr(ops, "yolo_loss", fake_loss)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=80, img_size=640))
+    model = model.to(memory_format=torch.channels_last).train()
+    model.head.bias_grad_in_loss = False  # CPU plumbing: autograd owns the bias gradient
+    g = syn.make_generator(0)
+    img = syn.make_images(2, 640, g).contiguous(memory_format=torch.channels_last)
+    gtb, gtc, mv = syn.make_targets(2, 640, g, "coco", 80, 40)
+    loss, parts = model.forward_train(img, gtb, gtc, mv)
+    assert torch.isfinite(loss) and parts.shape == (4,)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    preds = model.head(model.extract(img))
+    assert [tuple(p.shape) for p in preds] == [(2, 3, 80, 80, 85), (2, 3, 40, 40, 85), (2, 3, 20, 20, 85)]
+    assert all(p.stride(4) == 1 for p in preds)  # channels-last view, no copy
