@@ -66,9 +66,20 @@ def make_batches(n, B, size, nc, seed, device):
 
 
 def loss_bwd_bytes(B, size, no, na=3, strides=(8, 16, 32)):
-    """Algorithmic bytes of one hd_yolo_loss_bwd_dense launch: write 4*B*n*no, read obj logit + tobj (4+4)*B*n."""
+    """Algorithmic bytes of one hd_yolo_loss_bwd_dense launch: write the dense gradient
+    4*B*n*no and read the objectness residual the forward pass left behind, 4*B*n."""
     n = sum(na * (size // s) ** 2 for s in strides)
-    return 4 * B * n * no + 8 * B * n
+    return 4 * B * n * no + 4 * B * n
+
+
+def pmc_traffic(kernel, **shape):
+    """HBM bytes per launch from the committed PMC run (profiles/r01_pmc_traffic.json), if it was taken
+    on exactly this shape; None otherwise (PMC counters cannot be read from inside bench.py)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[kernel]
+        return rec["traffic_bytes"] if rec["shape"] == shape else None
+    except Exception:
+        return None
 
 
 def usable_cores() -> int:
@@ -220,6 +231,8 @@ def main():
     rank, local, world = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if os.environ.get("HD_DIST_BACKEND") == "gloo":  # rehearsal: every rank on GPU 0
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.manual_seed(0)  # identical init on every rank (also broadcast by GradReducer)
@@ -290,7 +303,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6.29TB/s":
                              round(achieved / HBM_COPY_GBS, 4), "avg_launch_ms": round(k_ms, 5),
-                         "algorithmic_bytes_per_launch": nbytes, "launches_timed": len(ms_list), "traffic": None},
+                         "algorithmic_bytes_per_launch": nbytes, "launches_timed": len(ms_list),
+                         "traffic": pmc_traffic("yolo_grad_dense_kernel", batch=args.batch, size=args.size,
+                                                no=args.classes + 5)},
         }
         log(f"timed region done: {out['value']} images/s")
         if world == 1 and not args.no_micro:
