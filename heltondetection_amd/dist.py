@@ -60,8 +60,11 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, first_bucket_bytes: int = 4 << 20,
-                 process_group=None, broadcast_params: bool = True):
+                 process_group=None, broadcast_params: bool = True, defer_collectives: bool = False):
         self.module = module
+        # defer_collectives: hooks only pack gradients; finish() launches the all-reduces.  Used when
+        # forward+backward are replayed from a hipGraph (collectives stay outside the captured region).
+        self.defer = defer_collectives
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
@@ -98,7 +101,7 @@ class GradReducer:
         torch._foreach_copy_(b.views, grads)
         for p, v in zip(b.params, b.views):
             p.grad = v
-        if self.world > 1:
+        if self.world > 1 and not self.defer:
             if self._avg_native:
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             else:
@@ -128,6 +131,10 @@ class GradReducer:
                 if self.world > 1:
                     op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
                     b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        if self.world > 1 and self.defer:
+            op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
+            for b in self.buckets:
+                b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()

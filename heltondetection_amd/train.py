@@ -19,12 +19,19 @@ def warmup_cosine(step: int, total: int, warmup: int, min_ratio: float = 0.01) -
 
 
 class Trainer:
+    """``use_graph=True`` captures forward + loss + backward + gradient packing into one hipGraph on
+    static input buffers (the step issues ~1500 kernels; replay removes the host launch cost, measured
+    13.3 -> 11.4 ms on YOLOv5s bs16).  The gradient all-reduce and the optimizer stay outside the
+    graph, launched right after the replay, so 1-GPU and N-GPU runs execute the same structure."""
+
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
-                 total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None):
+                 total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
+                 use_graph: bool = False, graph_warmup: int = 3):
         self.model = model
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes)
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph)
         decay, no_decay = [], []
         for n, p in model.named_parameters():
             if not p.requires_grad:
@@ -35,14 +42,53 @@ class Trainer:
                                       {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=(0.937, 0.999),
                                      fused=fused)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: warmup_cosine(s, total_steps, warmup_steps))
+        self._graph = None
+        self._static = None
+        self._static_out = None
+        self._eager_steps = 0
+        self._graph_warmup = graph_warmup
+        self.graph_error = None
 
-    def step(self, images, gt_boxes, gt_cls, m_valid):
+    def _fwd_bwd(self, images, gt_boxes, gt_cls, m_valid):
         self.reducer.prepare()
         use_amp = self.amp_dtype is not None and self.device.type == "cuda"
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
             loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
         loss.backward()
+        return loss.detach(), parts
+
+    def _capture(self, batch):
+        self._static = [t.clone() for t in batch]
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # private-pool warm-up as torch.cuda.graphs prescribes
+            self._fwd_bwd(*self._static)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._fwd_bwd(*self._static)
+        self._graph, self._static_out = g, out
+
+    def step(self, images, gt_boxes, gt_cls, m_valid):
+        batch = (images, gt_boxes, gt_cls, m_valid)
+        if self.use_graph and self._graph is None and self._eager_steps >= self._graph_warmup:
+            try:
+                self._capture(batch)
+            except Exception as e:  # stay correct: fall back to eager and remember why
+                self.graph_error = repr(e)
+                self.use_graph = False
+                self.reducer.defer = False
+                self._graph = None
+                torch.cuda.synchronize(self.device)
+        if self._graph is not None:
+            for dst, src in zip(self._static, batch):
+                dst.copy_(src, non_blocking=True)
+            self._graph.replay()
+            loss, parts = self._static_out
+        else:
+            loss, parts = self._fwd_bwd(*batch)
+            self._eager_steps += 1
         self.reducer.finish()
         self.opt.step()
         self.sched.step()
-        return loss.detach(), parts
+        return loss, parts
