@@ -260,18 +260,36 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    graph_on = trainer._graph is not None
-    if not graph_on:
-        ops.enable_timing("yolo_loss_bwd_dense")  # eager: event-time the kernel inside the timed region
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, parts = trainer.step(*batches[i % len(batches)])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def timed_region():
+        graph_on_ = trainer._graph is not None
+        if not graph_on_:
+            ops.enable_timing("yolo_loss_bwd_dense")  # eager: event-time the kernel inside the timed region
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for i in range(args.steps):
+            loss_, parts_ = trainer.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_, loss_, graph_on_
+
+    elapsed, loss, graph_on = timed_region()
+    ok = torch.isfinite(loss).all().to(torch.int32).reshape(1)
+    if world > 1:  # every rank must take the same branch
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if graph_on and not bool(ok.item()):
+        # safety net for the hipGraph path: never report a number from a corrupted run
+        log("non-finite loss after graph replays: rebuilding the trainer and re-timing eagerly")
+        ops.disable_timing()
+        model = build_detector(dict(type="YOLOv5", variant=args.variant, num_classes=args.classes,
+                                    img_size=args.size)).to(device).to(memory_format=torch.channels_last).train()
+        trainer = Trainer(model, lr=1e-3, amp_dtype=None if args.fp32 else torch.bfloat16,
+                          total_steps=args.steps + args.warmup + 1, warmup_steps=3, device=device, use_graph=False)
+        trainer.graph_error = "non-finite loss under hipGraph replay; re-timed eagerly"
+        for i in range(args.warmup):
+            trainer.step(*batches[i % len(batches)])
+        elapsed, loss, graph_on = timed_region()
     timed_where = "HIP events around every launch inside the timed region"
     if graph_on:
         # a replayed hipGraph carries no event records: time the same launch (same tensors, same stream)

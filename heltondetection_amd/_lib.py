@@ -93,6 +93,14 @@ SIGNATURES = {
     "hd_ciou_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
     "hd_yolo_nms_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "hd_yolo_nms": (_I, [_P, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "hd_maxpool5_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "hd_maxpool5_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "hd_bn_act_replicas": (C.c_int, []),
+    "hd_bn_act_stats": (_I, [_P, _I, _L, _I, _P, _P]),
+    "hd_bn_act_apply": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P]),
+    "hd_bn_act_infer": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _I, _P, _P]),
+    "hd_bn_act_bwd_reduce": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "hd_bn_act_bwd_dx": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "hd_wbf_workspace_bytes": (_Z, [_I, _I]),
     "hd_wbf": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
 }

@@ -74,3 +74,19 @@ __device__ __forceinline__ int hd_wave_sum_i(int v) {
 }
 
 __device__ __forceinline__ int hd_lane() { return threadIdx.x & 63; }
+
+// Device-side fill (32-bit pattern).  Used instead of hipMemsetAsync: a memset becomes a memset
+// NODE when the caller captures the stream into a hipGraph, and on ROCm 7.2 those nodes were
+// observed not to stay ordered with the surrounding kernel nodes once eager launches are
+// interleaved with replays; a plain kernel is ordered like every other launch and
+// costs about the same (~2 us).
+static __global__ __launch_bounds__(256) void hd_fill32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static inline hd_status hd_fill32(void* p, uint32_t v, size_t n_words, hipStream_t s) {
+  if (n_words == 0) return HD_OK;
+  size_t blocks = (n_words + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(hd_fill32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), v, n_words);
+  return hipGetLastError() == hipSuccess ? HD_OK : HD_ERR_LAUNCH;
+}

@@ -391,7 +391,7 @@ extern "C" hd_status hd_iou_assign(const float* a, int64_t a_bstride, const floa
     if (!workspace || workspace_bytes < hd_iou_assign_workspace_bytes(B, N, M)) return HD_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 7u) return HD_ERR_ALIGN;
     keys = reinterpret_cast<unsigned long long*>(workspace);
-    if (hipMemsetAsync(keys, 0, (size_t)B * M * sizeof(unsigned long long), s) != hipSuccess) return HD_ERR_LAUNCH;
+    if (hd_fill32(keys, 0u, (size_t)B * M * 2, s) != HD_OK) return HD_ERR_LAUNCH;
   }
   if (N > 0) {
     int gx = (N + kAssignThreads - 1) / kAssignThreads;

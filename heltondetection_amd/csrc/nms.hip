@@ -132,8 +132,8 @@ extern "C" hd_status hd_nms_batched(const float* boxes, const float* scores, con
   if (!keep_count || (max_out > 0 && !keep)) return HD_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   if (N == 0 || max_out == 0) {
-    if (hipMemsetAsync(keep_count, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
-    if (max_out > 0 && hipMemsetAsync(keep, 0xFF, (size_t)B * max_out * sizeof(int32_t), s) != hipSuccess)
+    if (hd_fill32(keep_count, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
+    if (max_out > 0 && hd_fill32(keep, 0xFFFFFFFFu, (size_t)B * max_out, s) != HD_OK)
       return HD_ERR_LAUNCH;
     return HD_OK;
   }
@@ -143,7 +143,7 @@ extern "C" hd_status hd_nms_batched(const float* boxes, const float* scores, con
   if (w.cap > kMaxCand) return HD_ERR_SHAPE;
   if (!workspace || workspace_bytes < w.bytes) return HD_ERR_WORKSPACE;
   if (!hd_aligned16(workspace)) return HD_ERR_ALIGN;
-  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
   int gx = (N + 255) / 256;
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(nms_keys_kernel, dim3(gx, B), dim3(256), 0, s, scores, n_valid, N, score_thr, w);
@@ -170,7 +170,7 @@ extern "C" hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float c
   if (w.cap > kMaxCand) return HD_ERR_SHAPE;
   if (workspace_bytes < y.bytes + w.bytes) return HD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
   int gx = (n + 3) / 4;  // 4 waves per block, one row per wave per iteration
   if (gx > 1024) gx = 1024;
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(gx, B), dim3(256), 0, s, dec, n, no, conf_thr, w, y.cand_box, y.cand_cls,

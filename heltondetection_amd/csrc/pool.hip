@@ -1,0 +1,204 @@
+// pool.hip — 5x5 / stride 1 / pad 2 max-pool on channels-last tensors (the SPPF block of the
+// YOLOv5 backbone, reference README.md:9), forward + backward.
+//
+// Why hand-written: PyTorch-ROCm's max_pool_backward_nhwc takes ~325 us per call on a
+// [16,256,20,20] bf16 tensor (atomic scatter); SPPF calls it three times per step (1.0 ms of a
+// 12 ms step).  Here the forward records the winning tap (0..24, one byte per element) and the
+// backward is the GATHER form — every input element sums the gradients of the <= 25 outputs whose
+// recorded tap points at it — so there are no atomics and the result is deterministic.
+// Lanes run along channels (8 bf16 or 4 f32 = 16 bytes per lane), so every access is a coalesced
+// 16-byte vector; the 25-tap reuse is served by L1/L2 (the whole tensor is a few MB).
+// Ties: first tap in (dy, dx) scan order wins (strict >), NaN propagates like PyTorch.
+#include <hip/hip_bf16.h>
+
+#include "hd_common.h"
+
+namespace {
+
+template <typename T>
+struct Vec;
+template <>
+struct Vec<float> {
+  static constexpr int N = 4;
+  using Raw = float4;
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    const float4 r = *reinterpret_cast<const float4*>(p);
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Vec<__hip_bfloat16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(__hip_bfloat16* p, const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // values are exact bf16 (max of bf16 inputs) or sums rounded to nearest-even below
+      const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
+      w[i] = (uint32_t)(*reinterpret_cast<const uint16_t*>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&hi)) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__ in, int B, int H, int W, int C,
+                                                           T* __restrict__ out, uint8_t* __restrict__ idx) {
+  constexpr int V = Vec<T>::N;
+  const int cv = C / V;
+  const uint32_t total = (uint32_t)B * H * W * cv;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t c0 = (i % cv) * V;
+    uint32_t r = i / cv;
+    const int x = r % W;
+    r /= W;
+    const int y = r % H;
+    const int b = r / H;
+    float best[V];
+    uint32_t bi[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      best[k] = -INFINITY;
+      bi[k] = 12;  // centre tap if every value is -inf
+    }
+    for (int ty = 0; ty < 5; ++ty) {
+      const int yy = y + ty - 2;
+      if (yy < 0 || yy >= H) continue;
+      for (int tx = 0; tx < 5; ++tx) {
+        const int xx = x + tx - 2;
+        if (xx < 0 || xx >= W) continue;
+        float v[V];
+        Vec<T>::load(in + (((size_t)b * H + yy) * W + xx) * C + c0, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (v[k] > best[k] || v[k] != v[k]) {
+            best[k] = v[k];
+            bi[k] = ty * 5 + tx;
+          }
+      }
+    }
+    const size_t o = (((size_t)b * H + y) * W + x) * C + c0;
+    Vec<T>::store(out + o, best);
+    if (V == 8) {
+      *reinterpret_cast<uint2*>(idx + o) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                      bi[4 % V] | (bi[5 % V] << 8) | (bi[6 % V] << 16) | (bi[7 % V] << 24));
+    } else {
+      *reinterpret_cast<uint32_t*>(idx + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx,
+                                                           int B, int H, int W, int C, T* __restrict__ gin) {
+  constexpr int V = Vec<T>::N;
+  const int cv = C / V;
+  const uint32_t total = (uint32_t)B * H * W * cv;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t c0 = (i % cv) * V;
+    uint32_t r = i / cv;
+    const int x = r % W;
+    r /= W;
+    const int y = r % H;
+    const int b = r / H;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+    // output q = p - (t - 2) used tap t on input p
+    for (int ty = 0; ty < 5; ++ty) {
+      const int qy = y - ty + 2;
+      if (qy < 0 || qy >= H) continue;
+      for (int tx = 0; tx < 5; ++tx) {
+        const int qx = x - tx + 2;
+        if (qx < 0 || qx >= W) continue;
+        const size_t q = (((size_t)b * H + qy) * W + qx) * C + c0;
+        uint32_t taps[V];
+        if (V == 8) {
+          const uint2 t = *reinterpret_cast<const uint2*>(idx + q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            taps[k] = (t.x >> (8 * k)) & 255u;
+            taps[(4 + k) % V] = (t.y >> (8 * k)) & 255u;
+          }
+        } else {
+          const uint32_t t = *reinterpret_cast<const uint32_t*>(idx + q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) taps[k] = (t >> (8 * k)) & 255u;
+        }
+        const uint32_t want = ty * 5 + tx;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < V; ++k) any |= (taps[k] == want);
+        if (!any) continue;
+        float g[V];
+        Vec<T>::load(gout + q, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (taps[k] == want) acc[k] += g[k];
+      }
+    }
+    Vec<T>::store(gin + (((size_t)b * H + y) * W + x) * C + c0, acc);
+  }
+}
+
+inline unsigned pool_grid(long long items) {
+  long long b = (items + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline hd_status pool_checks(const void* a, const void* b, const void* c, int dtype, int B, int H, int W, int C) {
+  if (!a || !b || !c) return HD_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (dtype != 0 && dtype != 1)) return HD_ERR_SHAPE;
+  const int V = dtype == 0 ? 4 : 8;
+  if (C % V != 0 || (long long)B * H * W * (C / V) > 0xffffffffLL) return HD_ERR_SHAPE;
+  if (!hd_aligned16(a) || !hd_aligned16(b) || (reinterpret_cast<uintptr_t>(c) & 7u)) return HD_ERR_ALIGN;
+  return HD_OK;
+}
+
+}  // namespace
+
+extern "C" hd_status hd_maxpool5_fwd(const void* in, int dtype, int B, int H, int W, int C, void* out, uint8_t* idx,
+                                     hd_stream stream) {
+  hd_status st = pool_checks(in, out, idx, dtype, B, H, W, C);
+  if (st != HD_OK) return st;
+  const long long items = (long long)B * H * W * (C / (dtype == 0 ? 4 : 8));
+  if (dtype == 0)
+    hipLaunchKernelGGL((maxpool5_fwd_kernel<float>), dim3(pool_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(in), B, H, W, C, reinterpret_cast<float*>(out), idx);
+  else
+    hipLaunchKernelGGL((maxpool5_fwd_kernel<__hip_bfloat16>), dim3(pool_grid(items)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(in), B, H, W, C,
+                       reinterpret_cast<__hip_bfloat16*>(out), idx);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int B, int H, int W, int C,
+                                     void* grad_in, hd_stream stream) {
+  hd_status st = pool_checks(grad_out, grad_in, idx, dtype, B, H, W, C);
+  if (st != HD_OK) return st;
+  const long long items = (long long)B * H * W * (C / (dtype == 0 ? 4 : 8));
+  if (dtype == 0)
+    hipLaunchKernelGGL((maxpool5_bwd_kernel<float>), dim3(pool_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(grad_out), idx, B, H, W, C, reinterpret_cast<float*>(grad_in));
+  else
+    hipLaunchKernelGGL((maxpool5_bwd_kernel<__hip_bfloat16>), dim3(pool_grid(items)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(grad_out), idx, B, H, W, C,
+                       reinterpret_cast<__hip_bfloat16*>(grad_in));
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}

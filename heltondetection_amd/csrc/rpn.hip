@@ -175,7 +175,7 @@ extern "C" hd_status hd_rpn_proposals(const float* logits, const float* deltas, 
   if (w.cap > kMaxCand) return HD_ERR_SHAPE;
   if (workspace_bytes < r.bytes + w.bytes) return HD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(w.n_keys, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+  if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(n_levels, B), dim3(1024), 0, s, logits,
                      reinterpret_cast<const float4*>(deltas), reinterpret_cast<const float4*>(anchors), NA, lv,
                      pre_nms_topk, min_size, img_h, img_w, w, r.cand_box, r.cand_cls);

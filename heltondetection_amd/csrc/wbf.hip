@@ -189,7 +189,7 @@ extern "C" hd_status hd_wbf(const float* boxes, const float* scores, const int32
   if (!out_count) return HD_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   if (K == 0) {
-    if (hipMemsetAsync(out_count, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return HD_ERR_LAUNCH;
+    if (hd_fill32(out_count, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
     return HD_OK;
   }
   if (!boxes || !scores || !labels || !model_weight || !out) return HD_ERR_NULL;

@@ -631,9 +631,10 @@ extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, co
   const LevelFlags fl = make_flags(*lv, nullptr, B);
   float* acc = reinterpret_cast<float*>(workspace);
   float* tobj = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kAccBytes + part_bytes(lv));
-  if (hipMemsetAsync(acc, 0, kAccBytes, s) != hipSuccess) return HD_ERR_LAUNCH;
-  if (hipMemsetAsync(tobj, 0, (size_t)ix.first_cell[lv->n_levels] * sizeof(float), s) != hipSuccess)
-    return HD_ERR_LAUNCH;
+  // acc and tobj are adjacent except for the partials area: one fill over [acc .. tobj end) would
+  // also clear the (large, unused-in-forward) partials, so fill the two pieces separately
+  if (hd_fill32(acc, 0u, kAccBytes / 4, s) != HD_OK) return HD_ERR_LAUNCH;
+  if (hd_fill32(tobj, 0u, (size_t)ix.first_cell[lv->n_levels], s) != HD_OK) return HD_ERR_LAUNCH;
   const long long S = (long long)5 * lv->na * B * M;
   if (S > 0) {
     hipLaunchKernelGGL((yolo_pos_kernel<false>), pos_grid(S, lv->n_levels), dim3(256), 0, s, *lv, *lv, ix, fl, B, S,

@@ -13,14 +13,27 @@ def autopad(k: int, p=None) -> int:
 class ConvBNAct(nn.Module):
     """Conv2d(bias=False) + BatchNorm2d + activation (SiLU for the YOLOv5 family, ReLU for ResNet)."""
 
+    fused = True  # class-wide switch: run BN+activation as the fused HIP kernels on HIP tensors
+
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
         self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
+        self.act_name = act
+        self._slot = None
 
     def forward(self, x):
-        return self.act(self.bn(self.conv(x)))
+        y = self.conv(x)
+        if self.fused and y.is_cuda:
+            from . import ops  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
+            if ops.bn_act_supported(y):
+                if self._slot is None and self.training:
+                    self._slot = ops.bn_act_slot(y.device, y.shape[1])
+                bn = self.bn
+                return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                  self.act_name, self.training, self._slot)
+        return self.act(self.bn(y))
 
 
 class Bottleneck(nn.Module):
@@ -77,6 +90,11 @@ class SPPF(nn.Module):
 
     def forward(self, x):
         x = self.cv1(x)
-        y1 = self.m(x)
-        y2 = self.m(y1)
-        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+        pool = self.m
+        if self.m.kernel_size == 5 and x.is_cuda:
+            from . import ops  # HIP SPPF pool (arg-max tap forward, gather backward); see csrc/pool.hip
+            if ops.maxpool5_supported(x):
+                pool = ops.maxpool5
+        y1 = pool(x)
+        y2 = pool(y1)
+        return self.cv2(torch.cat((x, y1, y2, pool(y2)), 1))

@@ -470,3 +470,173 @@ def wbf(boxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, model_w
     check(lib.hd_wbf(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(mw), _ptr(k_valid), B, K, float(weight_sum),
                      float(iou_thr), float(skip_thr), _ptr(out), _ptr(cnt), _ptr(ws), wsb, _stream(boxes)), "hd_wbf")
     return out, cnt
+
+
+# ------------------------------------------------------------------------------- SPPF max-pool
+class _MaxPool5Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        dt = {torch.float32: 0, torch.bfloat16: 1}[x.dtype]
+        out = torch.empty_like(x)  # keeps channels-last strides
+        idx = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
+        check(lib.hd_maxpool5_fwd(_ptr(x), dt, B, H, W, Cc, _ptr(out), _ptr(idx), _stream(x)), "hd_maxpool5_fwd")
+        ctx.save_for_backward(idx)
+        ctx.meta = (dt, B, H, W, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        dt, B, H, W, Cc = ctx.meta
+        g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty_like(g)
+        check(lib.hd_maxpool5_bwd(_ptr(g), _ptr(idx), dt, B, H, W, Cc, _ptr(gin), _stream(g)), "hd_maxpool5_bwd")
+        return gin
+
+
+def maxpool5_supported(x: torch.Tensor) -> bool:
+    """HIP path: HIP tensor, dense channels-last, float32 (C % 4 == 0) or bfloat16 (C % 8 == 0)."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0)
+
+
+def maxpool5(x: torch.Tensor) -> torch.Tensor:
+    """5x5 / stride 1 / pad 2 max-pool of a channels-last [B,C,H,W] tensor (SPPF)."""
+    if not maxpool5_supported(x):
+        raise _lib.HdError("maxpool5: needs a dense channels-last float32/bfloat16 HIP tensor")
+    return _MaxPool5Fn.apply(x)
+
+
+# ------------------------------------------------------------------------------- fused BN + act
+_ACT_CODE = {None: 0, "none": 0, "silu": 1, "relu": 2}
+
+
+class _StatArena:
+    """One zero-initialised fp32 arena per device for the per-channel sums the BN kernels accumulate
+    with atomics.  ``reset()`` clears every slot with ONE kernel (the Trainer calls it once per
+    step); a layer that runs twice without a reset in between clears its own slot."""
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks: List[torch.Tensor] = []
+        self.used = 0
+        self.gen = 0
+        self.chunk_elems = 1 << 20
+
+    def alloc(self, n: int) -> "_StatSlot":
+        n = (n + 63) // 64 * 64
+        if not self.chunks or self.used + n > self.chunk_elems:
+            self.chunks.append(torch.zeros(max(self.chunk_elems, n), dtype=_F32, device=self.device))
+            self.used = 0
+        buf = self.chunks[-1][self.used:self.used + n]
+        self.used += n
+        return _StatSlot(self, buf)
+
+    def reset(self):
+        self.gen += 1
+        for c in self.chunks:
+            c.zero_()
+
+
+class _StatSlot:
+    __slots__ = ("arena", "buf", "fwd_gen", "bwd_gen")
+
+    def __init__(self, arena, buf):
+        self.arena, self.buf, self.fwd_gen, self.bwd_gen = arena, buf, -1, -1
+
+
+_ARENAS: dict = {}
+
+
+def _arena(device) -> _StatArena:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _ARENAS:
+        _ARENAS[key] = _StatArena(device)
+    return _ARENAS[key]
+
+
+def bn_arena_reset(device) -> None:
+    """Zero every BN statistics slot on `device` (one kernel).  Call once per training step."""
+    _arena(torch.device(device)).reset()
+
+
+def bn_act_supported(x: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    v = 4 if x.dtype == torch.float32 else 8
+    C = x.shape[1]
+    return C % v == 0 and C // v <= 256 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        R = B * H * W
+        dt = 0 if x.dtype == torch.float32 else 1
+        arena = slot.arena
+        rep = lib.hd_bn_act_replicas()
+        sums = slot.buf[: rep * 2 * Cc]
+        if slot.fwd_gen == arena.gen:   # second forward since the last arena reset: clear our own slot
+            sums.zero_()
+        slot.fwd_gen = arena.gen
+        y = torch.empty_like(x)
+        save = torch.empty((2, Cc), dtype=_F32, device=x.device)
+        st = _stream(x)
+        w, b = weight.detach().float(), bias.detach().float()
+        check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
+        check(lib.hd_bn_act_apply(_ptr(x), dt, R, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
+                                  _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
+                                  _ptr(y), st), "hd_bn_act_apply")
+        ctx.save_for_backward(x, w, b, save)
+        ctx.meta = (dt, R, Cc, int(act), slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, b, save = ctx.saved_tensors
+        dt, R, Cc, act, slot = ctx.meta
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        rep = lib.hd_bn_act_replicas()
+        dsums = slot.buf[rep * 2 * Cc: rep * 4 * Cc]
+        if slot.bwd_gen == slot.arena.gen:
+            dsums.zero_()
+        slot.bwd_gen = slot.arena.gen
+        dx = torch.empty_like(x)
+        dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
+        st = _stream(x)
+        check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
+                                       act, _ptr(dsums), st), "hd_bn_act_bwd_reduce")
+        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), act,
+                                   _ptr(dsums), _ptr(dx), _ptr(dg[0]), _ptr(dg[1]), st), "hd_bn_act_bwd_dx")
+        return dx, dg[0], dg[1], None, None, None, None, None, None
+
+
+def bn_act_slot(device, channels: int) -> _StatSlot:
+    # forward sums + backward sums, each [replicas, 2, C]
+    return _arena(torch.device(device)).alloc(4 * channels * _lib.load().hd_bn_act_replicas())
+
+
+def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: float, act: str, training: bool,
+           slot: Optional[_StatSlot] = None) -> torch.Tensor:
+    """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip)."""
+    if not bn_act_supported(x):
+        raise _lib.HdError("bn_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0")
+    code = _ACT_CODE[act]
+    if training:
+        if slot is None:
+            slot = bn_act_slot(x.device, x.shape[1])
+        return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot)
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    check(lib.hd_bn_act_infer(_ptr(x), 0 if x.dtype == torch.float32 else 1, B * H * W, Cc, _ptr(weight.detach().float()),
+                              _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), code,
+                              _ptr(y), _stream(x)), "hd_bn_act_infer")
+    return y

@@ -26,11 +26,12 @@ class Trainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
-                 use_graph: bool = False, graph_warmup: int = 3):
+                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = True):
         self.model = model
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self.graph_sync = bool(graph_sync)
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph)
         decay, no_decay = [], []
         for n, p in model.named_parameters():
@@ -51,6 +52,9 @@ class Trainer:
 
     def _fwd_bwd(self, images, gt_boxes, gt_cls, m_valid):
         self.reducer.prepare()
+        if self.device.type == "cuda":
+            from . import ops
+            ops.bn_arena_reset(self.device)  # one kernel clears every fused-BN statistics slot
         use_amp = self.amp_dtype is not None and self.device.type == "cuda"
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
             loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
@@ -84,6 +88,12 @@ class Trainer:
             for dst, src in zip(self._static, batch):
                 dst.copy_(src, non_blocking=True)
             self._graph.replay()
+            if self.graph_sync:
+                # ROCm 7.2: memset/copy nodes of a replayed graph are not reliably ordered against work
+                # launched around the replay (MIOpen's conv-backward solvers put hipMemset nodes into the
+                # graph); letting the host run ahead and enqueue the next replay while this one executes
+                # corrupted gradients after 30-80 steps.  Draining the stream here removes the overlap.
+                torch.cuda.current_stream(self.device).synchronize()
             loss, parts = self._static_out
         else:
             loss, parts = self._fwd_bwd(*batch)

@@ -292,6 +292,44 @@ hd_status hd_wbf(const float* boxes, const float* scores, const int32_t* labels,
                  float iou_thr, float skip_thr, float* out, int32_t* out_count, void* workspace,
                  size_t workspace_bytes, hd_stream stream);
 
+/* ---- backbone glue on the path: SPPF max-pool (README.md:9, YOLOv5 backbone) ---------------- */
+
+/* 5x5 / stride 1 / pad 2 max-pool of a dense channels-last tensor [B,H,W,C] (dtype 0 = float32,
+ * C % 4 == 0; 1 = bfloat16, C % 8 == 0).  idx [B,H,W,C] uint8 receives the winning tap
+ * (ty*5+tx; first tap in scan order wins ties).  Backward is the gather form over idx (no
+ * atomics, deterministic): grad_in[p] = sum of grad_out[q] over outputs q whose tap points at p. */
+hd_status hd_maxpool5_fwd(const void* in, int dtype, int B, int H, int W, int C, void* out,
+                          uint8_t* idx, hd_stream stream);
+hd_status hd_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int B, int H, int W,
+                          int C, void* grad_in, hd_stream stream);
+
+/* Fused BatchNorm2d (batch statistics) + activation on a dense channels-last tensor seen as rows
+ * [R = B*H*W, C]; dtype 0 = float32 (C % 4 == 0), 1 = bfloat16 (C % 8 == 0); C/vec <= 256.
+ * act: 0 none, 1 SiLU, 2 ReLU.  gamma/beta/running_* / save_* are float32 [C].
+ * Accumulators are replicated: sums / dsums are [hd_bn_act_replicas(), 2, C] float32.
+ *   forward : _stats accumulates per-channel (sum, sum of squares) into sums (ZEROED BY THE
+ *             CALLER); _apply then writes y = act(gamma*(x-mean)*invstd + beta), saves mean/invstd
+ *             and updates running_mean/var in place when they are non-NULL (momentum, unbiased var).
+ *   infer   : _infer uses the running statistics.
+ *   backward: _bwd_reduce accumulates (sum dz, sum dz*xhat) into dsums (ZEROED BY THE CALLER),
+ *             dz = dy*act'(z) with z recomputed from x; _bwd_dx writes dx and dgamma/dbeta. */
+int hd_bn_act_replicas(void);
+hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C, float* sums, hd_stream stream);
+hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C, const float* sums,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* save_mean,
+                          float* save_invstd, int act, void* y, hd_stream stream);
+hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
+                          const float* beta, const float* running_mean, const float* running_var,
+                          float eps, int act, void* y, hd_stream stream);
+hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dtype, int64_t R, int C,
+                               const float* save_mean, const float* save_invstd, const float* gamma,
+                               const float* beta, int act, float* dsums, hd_stream stream);
+hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, int64_t R, int C,
+                           const float* save_mean, const float* save_invstd, const float* gamma,
+                           const float* beta, int act, const float* dsums, void* dx, float* dgamma,
+                           float* dbeta, hd_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

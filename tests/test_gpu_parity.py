@@ -323,3 +323,65 @@ def test_wbf(gpu, ops):
     ro, rc = co.wbf(boxes.numpy(), scores.numpy(), labels.numpy(), mw.numpy(), kv.numpy(), 2.5, 0.55, 0.05)
     assert np.array_equal(cnt.cpu().numpy(), rc)
     assert np.array_equal(out.cpu().numpy(), ro)
+
+
+# ------------------------------------------------------------------------------- SPPF max-pool
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool5_matches_torch(gpu, ops, dtype):
+    """Checked against PyTorch's own max_pool2d on the CPU (a torch fp32 reference is the right checker
+    for this backbone glue op; values are distinct so arg-max ties cannot differ)."""
+    g = torch.Generator().manual_seed(111)
+    B, C, Hh, Ww = 3, 64, 13, 20
+    x = torch.randn((B, C, Hh, Ww), generator=g)
+    x = (x + torch.arange(x.numel()).view_as(x) * 1e-3).to(dtype).float()   # distinct after rounding
+    xd = x.to(gpu).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.maxpool5(xd)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 5, 1, 2)
+    assert torch.equal(y.float().cpu(), yr.detach())
+    go = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(go.to(gpu).to(dtype).contiguous(memory_format=torch.channels_last))
+    yr.backward(go)
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(xd.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+
+
+# ------------------------------------------------------------------------------- fused BN + act
+@pytest.mark.parametrize("dtype,act,C", [(torch.float32, "silu", 32), (torch.bfloat16, "silu", 64),
+                                          (torch.float32, "relu", 48), (torch.bfloat16, None, 256)])
+def test_bn_act_matches_torch(gpu, ops, dtype, act, C):
+    """Backbone glue: checked against PyTorch's BatchNorm2d + activation in float64 on the CPU."""
+    g = torch.Generator().manual_seed(121)
+    B, Hh, Ww = 4, 9, 11
+    x = (torch.randn((B, C, Hh, Ww), generator=g) * 1.5 + 0.3).to(dtype)
+    w = torch.rand(C, generator=g) + 0.5
+    b = torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.zeros(C), torch.ones(C)
+    go = torch.randn((B, C, Hh, Ww), generator=g).to(dtype)
+    # reference (float64)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    z = torch.nn.functional.batch_norm(xr, rmr, rvr, wr, br, True, 0.03, 1e-3)
+    yr = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}[act](z)
+    yr.backward(go.double())
+    # HIP
+    xd = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    rmd, rvd = rm.to(gpu), rv.to(gpu)
+    ops.bn_arena_reset(gpu)
+    y = ops.bn_act(xd, wd, bd, rmd, rvd, 1e-3, 0.03, act, True)
+    y.backward(go.to(gpu).contiguous(memory_format=torch.channels_last))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert H.rel_err(xd.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+    assert H.rel_err(wd.grad.cpu().numpy(), wr.grad.numpy()) < tol
+    assert H.rel_err(bd.grad.cpu().numpy(), br.grad.numpy()) < tol
+    assert H.rel_err(rmd.cpu().numpy(), rmr.numpy()) < 1e-4 and H.rel_err(rvd.cpu().numpy(), rvr.numpy()) < 1e-4
+    # second pass without an arena reset must still be right (slot self-clears), and inference mode
+    y2 = ops.bn_act(xd.detach(), wd, bd, rmd.clone(), rvd.clone(), 1e-3, 0.03, act, True)
+    assert H.rel_err(y2.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    yi = ops.bn_act(xd.detach(), wd, bd, rmd, rvd, 1e-3, 0.03, act, False)
+    zi = torch.nn.functional.batch_norm(x.double(), rmd.cpu().double(), rvd.cpu().double(), w.double(), b.double(), False, 0.03, 1e-3)
+    yir = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}[act](zi)
+    assert H.rel_err(yi.float().cpu().numpy(), yir.numpy()) < tol
