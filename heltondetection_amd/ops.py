@@ -413,6 +413,40 @@ def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, bo
                              (box_gain, obj_gain, cls_gain), tuple(balance), len(preds), *preds, *biases)
 
 
+def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,
+                             iters: int = 20) -> List[float]:
+    """Measurement helper for bench.py: runs the loss forward once on `preds`, then launches
+    hd_yolo_loss_bwd_dense `iters` times back-to-back on the current stream with a HIP event pair around
+    every launch (the stream stays saturated, so an event pair spans the kernel and nothing else).
+    Returns the per-launch milliseconds after a device synchronise."""
+    lib = _lib.load()
+    preds = [p.detach() for p in preds]
+    st = _yolo_levels(preds, strides, anchors)
+    B = preds[0].shape[0]
+    cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
+    dev = preds[0].device
+    out = torch.empty((4,), dtype=_F32, device=dev)
+    ws, wsb = _ws(lib.hd_yolo_loss_workspace_bytes(C.byref(st), B), dev)
+    s = _stream(out)
+    check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slots[0]), _ptr(slots[1]), _ptr(slots[2]), C.byref(cfg),
+                               _ptr(out), _ptr(ws), wsb, s), "hd_yolo_loss_fwd")
+    grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=dev) for p in preds]
+    gst = _yolo_levels(grads, strides, anchors)
+    gs = torch.ones(1, dtype=_F32, device=dev)
+    gbias = torch.zeros((len(preds), st.na * st.no), dtype=_F32, device=dev)
+    evs = []
+    for i in range(iters + 3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws),
+                                         wsb, s), "hd_yolo_loss_bwd_dense")
+        b.record()
+        if i >= 3:
+            evs.append((a, b))
+    torch.cuda.synchronize(dev)
+    return [a.elapsed_time(b) for a, b in evs]
+
+
 class _CIoUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
