@@ -393,7 +393,7 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C,
   if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec, C / V, 2048);
+  const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   const float inv_R = 1.0f / (float)R;
   const float unbias = R > 1 ? (float)R / (float)(R - 1) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
@@ -417,7 +417,7 @@ extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C,
   if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec, C / V, 2048);
+  const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   hipStream_t s = (hipStream_t)stream;
 #define HD_INFER(T, A, XT)                                                                                         \
   hipLaunchKernelGGL((bn_infer_kernel<XT, A>), dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), \
@@ -463,7 +463,7 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, 
   if (!hd_aligned16(x) || !hd_aligned16(dy) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec, C / V, 2048);
+  const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   const float inv_R = 1.0f / (float)R;
   hipStream_t s = (hipStream_t)stream;
 #define HD_DX(T, A, XT)                                                                                           \

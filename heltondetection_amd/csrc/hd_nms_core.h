@@ -9,10 +9,11 @@
 //   1. nms_sort_gather_kernel   one 1024-lane workgroup per image: zero-pad to a power of two,
 //      bitonic sort (LDS tiles of 4096 keys, global passes only for strides >= 4096), clamp to
 //      max_candidates, gather boxes/classes into sorted order (coalesced for step 2).
-//   2. nms_mask_kernel          64x64 tiles of the upper triangle.  A wave holds 64 column boxes
-//      (one per lane), the 64 row boxes are staged in LDS and broadcast; the suppression test of
-//      one row against the 64 columns is a single v_cmp whose 64-bit result IS the mask word
-//      (the wavefront ballot).  Non-overlapping or other-class pairs exit after ~8 VALU ops.
+//   2. nms_mask_kernel          64x64 tiles of the upper triangle, walked persistently (the tile-pair
+//      count comes from the device-side candidate count).  A wave holds 64 column boxes (one per
+//      lane), the 64 row boxes are staged in LDS and broadcast; the suppression test of one row
+//      against the 64 columns is a single v_cmp whose 64-bit result IS the mask word (the wavefront
+//      ballot).  Non-overlapping or other-class pairs exit after ~8 VALU ops.
 //   3. nms_scan_kernel          one workgroup per image; lane t owns word t of the removed-set.
 //      Per 64-box chunk wave 0 resolves the chunk against its diagonal word with scalar
 //      bit-ops, then all lanes OR the kept rows' words (independent loads).  Stops at max_out.
@@ -24,7 +25,7 @@
 namespace hdnms {
 
 constexpr int kSortThreads = 1024;
-constexpr int kSortTile = 4096;   // keys per LDS tile (32 KiB)
+constexpr int kSortTile = 16384;  // keys per LDS tile: 128 KiB of dynamic LDS (the CU has 160 KiB)
 constexpr int kMaxCand = 65536;   // 1024 lanes x one 64-bit removed-word each
 
 typedef unsigned long long u64;
@@ -54,9 +55,9 @@ __device__ __forceinline__ void bitonic_local(u64* lds, int tile_n, int base, in
 }
 
 // Sorts keys[0..n_pow2) (global memory) descending with the calling workgroup.
-// lds must hold kSortTile keys.  Every thread of the workgroup must call this.
-__device__ __forceinline__ void block_sort_desc(u64* keys, int n_pow2, u64* lds) {
-  const int tile_n = n_pow2 < kSortTile ? n_pow2 : kSortTile;
+// lds must hold min(n_pow2, lds_keys) keys.  Every thread of the workgroup must call this.
+__device__ __forceinline__ void block_sort_desc(u64* keys, int n_pow2, u64* lds, int lds_keys = kSortTile) {
+  const int tile_n = n_pow2 < lds_keys ? n_pow2 : lds_keys;
   if (n_pow2 <= 1) return;
   // stage 1: every tile fully sorted for k <= tile_n (alternating direction by tile index)
   for (int base = 0; base < n_pow2; base += tile_n) {
@@ -135,7 +136,7 @@ inline CoreWs core_layout(void* base, int B, int n_keys_max, int max_candidates)
 static __global__ __launch_bounds__(kSortThreads) void nms_sort_gather_kernel(CoreWs w, const float4* __restrict__ cand_box,
                                                                         const int32_t* __restrict__ cand_cls,
                                                                         long long cand_stride) {
-  __shared__ u64 s_tile[kSortTile];
+  extern __shared__ u64 s_tile[];  // min(key_cap, kSortTile) keys
   const int b = blockIdx.x;
   u64* keys = w.keys + (size_t)b * w.key_cap;
   int n = w.n_keys[b];
@@ -144,7 +145,7 @@ static __global__ __launch_bounds__(kSortThreads) void nms_sort_gather_kernel(Co
   while (n_pow2 < n) n_pow2 <<= 1;
   for (int i = n + threadIdx.x; i < n_pow2; i += blockDim.x) keys[i] = 0ull;
   __syncthreads();
-  block_sort_desc(keys, n_pow2, s_tile);
+  block_sort_desc(keys, n_pow2, s_tile, w.key_cap < kSortTile ? w.key_cap : kSortTile);
   const int nc = n < w.cap ? n : w.cap;
   if (threadIdx.x == 0) w.nc[b] = nc;
   for (int r = threadIdx.x; r < nc; r += blockDim.x) {
@@ -156,43 +157,83 @@ static __global__ __launch_bounds__(kSortThreads) void nms_sort_gather_kernel(Co
 }
 
 // ---- step 2 ---------------------------------------------------------------------------------
-// grid: (ceil(words/4), words, B); block 256 = 4 waves, wave v handles column tile 4*bx + v.
+// Persistent over the ACTUAL work: the number of candidates nc[b] is only known on the device, so the
+// grid is (kMaskBlocks, B) regardless of the capacity and every wave walks the upper-triangle tile
+// pairs p = wave, wave + n_waves, ... of its image (p -> (row tile, column tile) by triangular
+// indexing).  An image with 17 candidates costs one wave one tile; a capacity-sized grid would launch
+// hundreds of thousands of workgroups that only read nc and exit.
+// Per pair: the tile's 64 row boxes (+ areas, classes) go through a wave-private LDS slice and are
+// read back as wave-uniform broadcasts, four rows per iteration so the LDS latency of one row
+// overlaps the tests of the others; the suppression test of one row against the wave's 64 column
+// boxes is one v_cmp whose 64-bit result IS the mask word (the wavefront ballot).
+constexpr int kMaskBlocks = 512;  // x 4 waves per image
+
 static __global__ __launch_bounds__(256) void nms_mask_kernel(CoreWs w, float iou_thr) {
-  __shared__ float4 s_row[64];
-  __shared__ int32_t s_rcls[64];
-  const int b = blockIdx.z;
+  __shared__ float4 s_row[4][64];
+  __shared__ float s_rarea[4][64];
+  __shared__ int32_t s_rcls[4][64];
+  const int b = blockIdx.y;
   const int nc = w.nc[b];
-  const int rt = blockIdx.y;
-  const int row0 = rt * 64;
-  if (row0 >= nc) return;  // whole block exits together
-  const int lane = threadIdx.x & 63;
-  const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int T = (nc + 63) >> 6;
+  const long long P = (long long)T * (T + 1) / 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* sbox = w.sbox + (size_t)b * w.cap;
   const int32_t* scls = w.scls + (size_t)b * w.cap;
-  if (threadIdx.x < 64) {
-    const int r = row0 + threadIdx.x;
-    s_row[threadIdx.x] = r < nc ? sbox[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s_rcls[threadIdx.x] = r < nc ? scls[r] : -1;
+  const long long n_waves = (long long)gridDim.x * 4;
+  for (long long p = (long long)blockIdx.x * 4 + wv; p < P; p += n_waves) {
+    // p = rt*T - rt*(rt-1)/2 + (ct - rt), 0 <= rt <= ct < T
+    int rt = (int)(((double)(2 * T + 1) - sqrt((double)(2 * T + 1) * (double)(2 * T + 1) - 8.0 * (double)p)) * 0.5);
+    if (rt < 0) rt = 0;
+    if (rt > T - 1) rt = T - 1;
+    while (rt > 0 && (long long)rt * T - (long long)rt * (rt - 1) / 2 > p) --rt;
+    while ((long long)(rt + 1) * T - (long long)(rt + 1) * rt / 2 <= p) ++rt;
+    const int ct = rt + (int)(p - ((long long)rt * T - (long long)rt * (rt - 1) / 2));
+    const int row0 = rt * 64;
+    {
+      const int r = row0 + lane;
+      const float4 v = r < nc ? sbox[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_row[wv][lane] = v;
+      s_rarea[wv][lane] = hd_box_area(v);
+      s_rcls[wv][lane] = r < nc ? scls[r] : -1;
+    }
+    __builtin_amdgcn_wave_barrier();  // the slice is private to this wave: no workgroup barrier needed
+    const int col = ct * 64 + lane;
+    const bool col_ok = col < nc;
+    const float4 cb = col_ok ? sbox[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t cc = col_ok ? scls[col] : -2;
+    const float carea = hd_box_area(cb);
+    const int rows = min(64, nc - row0);
+    u64 mine = 0ull;
+    auto test = [&](const float4 rb, const float ra, const int rc) -> bool {
+      if (col_ok && rc == cc && hd_overlaps(rb, cb)) return hd_iou_full(rb, ra, cb, carea) > iou_thr;
+      return false;
+    };
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+      const float4 b0 = s_row[wv][r], b1 = s_row[wv][r + 1], b2 = s_row[wv][r + 2], b3 = s_row[wv][r + 3];
+      const float a0 = s_rarea[wv][r], a1 = s_rarea[wv][r + 1], a2 = s_rarea[wv][r + 2], a3 = s_rarea[wv][r + 3];
+      const int c0 = s_rcls[wv][r], c1 = s_rcls[wv][r + 1], c2 = s_rcls[wv][r + 2], c3 = s_rcls[wv][r + 3];
+      u64 w0 = __ballot(test(b0, a0, c0)), w1 = __ballot(test(b1, a1, c1));
+      u64 w2 = __ballot(test(b2, a2, c2)), w3 = __ballot(test(b3, a3, c3));
+      if (ct == rt) {  // only later boxes can be suppressed by row r
+        w0 &= ~((2ull << r) - 1ull);
+        w1 &= ~((2ull << (r + 1)) - 1ull);
+        w2 &= ~((2ull << (r + 2)) - 1ull);
+        w3 &= ~((2ull << (r + 3)) - 1ull);
+      }
+      if (lane == r) mine = w0;
+      if (lane == r + 1) mine = w1;
+      if (lane == r + 2) mine = w2;
+      if (lane == r + 3) mine = w3;
+    }
+    for (; r < rows; ++r) {
+      u64 word = __ballot(test(s_row[wv][r], s_rarea[wv][r], s_rcls[wv][r]));
+      if (ct == rt) word &= ~((2ull << r) - 1ull);
+      if (lane == r) mine = word;
+    }
+    if (lane < rows) w.mask[((size_t)b * w.cap + row0 + lane) * w.words + ct] = mine;
+    __builtin_amdgcn_wave_barrier();  // all reads of the slice are done before the next pair overwrites it
   }
-  __syncthreads();
-  if (ct < rt || ct * 64 >= nc) return;  // lower triangle / beyond the candidates (wave-uniform)
-  const int col = ct * 64 + lane;
-  const bool col_ok = col < nc;
-  const float4 cb = col_ok ? sbox[col] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int32_t cc = col_ok ? scls[col] : -2;
-  const float carea = hd_box_area(cb);
-  const int rows = min(64, nc - row0);
-  u64 mine = 0ull;
-  for (int r = 0; r < rows; ++r) {
-    const float4 rb = s_row[r];
-    bool sup = false;
-    if (col_ok && s_rcls[r] == cc && hd_overlaps(rb, cb))
-      sup = hd_iou_full(rb, hd_box_area(rb), cb, carea) > iou_thr;
-    u64 word = __ballot(sup);
-    if (ct == rt) word &= ~((2ull << r) - 1ull);  // only later boxes can be suppressed by row r
-    if (lane == r) mine = word;
-  }
-  if (lane < rows) w.mask[((size_t)b * w.cap + row0 + lane) * w.words + ct] = mine;
 }
 
 // ---- step 3 ---------------------------------------------------------------------------------
@@ -217,15 +258,22 @@ static __global__ __launch_bounds__(1024) void nms_scan_kernel(CoreWs w, int max
     if (t < 64) {
       const int row = c * 64 + t;
       const u64 diag = row < nc ? mask[(size_t)row * w.words + c] : 0ull;
-      u64 cur = s_cur;
+      // the whole resolve runs on scalar registers: the chunk's removed-word, the running kept mask and
+      // the diagonal words fetched with v_readlane (a 64-bit __shfl would be an LDS round trip per step)
+      const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+      const u64 cur_v = s_cur;
+      u64 cur = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cur_v >> 32)) << 32) |
+                (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cur_v);
       const int rows = nc - c * 64;
       if (rows < 64) cur |= ~0ull << rows;  // rows past the candidates count as removed
       u64 kept = 0ull;
       u64 avail = ~cur;
       while (avail) {
-        const int j = __ffsll((long long)avail) - 1;
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)avail) - 1);
         kept |= 1ull << j;
-        cur |= __shfl(diag, j, 64);
+        const u64 dj = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                       (u64)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
+        cur |= dj;
         avail = ~cur & ~((2ull << j) - 1ull);
       }
       if ((kept >> t) & 1ull) {
@@ -242,10 +290,21 @@ static __global__ __launch_bounds__(1024) void nms_scan_kernel(CoreWs w, int max
     count = s_count;
     if (count >= max_out) break;
     if (t > c && t < words) {
+      // OR the kept rows' words into this lane's removed-word, 8 independent loads at a time (a plain
+      // one-load-per-iteration loop waits out a full memory latency per kept box)
+      const u64* col = mask + (size_t)c * 64 * w.words + t;
       while (kept) {
-        const int j = __ffsll((long long)kept) - 1;
-        kept &= kept - 1;
-        removed |= mask[(size_t)(c * 64 + j) * w.words + t];
+        int j[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          j[k] = kept ? __ffsll((long long)kept) - 1 : -1;
+          kept &= kept - 1;  // 0 & anything stays 0
+        }
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = j[k] >= 0 ? col[(size_t)j[k] * w.words] : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) removed |= v[k];
       }
     }
     __syncthreads();  // s_cur / s_kept are rewritten next iteration
@@ -259,12 +318,25 @@ static __global__ __launch_bounds__(1024) void nms_scan_kernel(CoreWs w, int max
 inline hd_status run_core(const CoreWs& w, int B, const float4* cand_box, const int32_t* cand_cls,
                           long long cand_stride, float iou_thr, int max_out, int32_t* keep_out,
                           int32_t* keep_count, hipStream_t s) {
-  hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(B), dim3(kSortThreads), 0, s, w, cand_box, cand_cls, cand_stride);
+  const int tile = w.key_cap < kSortTile ? w.key_cap : kSortTile;
+  const size_t sort_lds = (size_t)tile * sizeof(u64);
+  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per process
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_gather_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortTile * (int)sizeof(u64)) != hipSuccess)
+      return HD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(B), dim3(kSortThreads), sort_lds, s, w, cand_box, cand_cls,
+                     cand_stride);
   HD_RETURN_IF_LAUNCH_FAILED();
-  dim3 mgrid((unsigned)((w.words + 3) / 4), (unsigned)w.words, (unsigned)B);
-  hipLaunchKernelGGL(nms_mask_kernel, mgrid, dim3(256), 0, s, w, iou_thr);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskBlocks, (unsigned)B), dim3(256), 0, s, w, iou_thr);
   HD_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(1024), 0, s, w, max_out, keep_out, keep_count);
+  // one lane per 64-candidate mask word; fewer waves make the three barriers per chunk cheaper
+  int scan_threads = ((w.words + 63) / 64) * 64;
+  if (scan_threads < 64) scan_threads = 64;
+  if (scan_threads > 1024) scan_threads = 1024;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(scan_threads), 0, s, w, max_out, keep_out, keep_count);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

@@ -254,20 +254,38 @@ __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
       best = max_iou[(int64_t)img * N + n];
       bidx = argmax[(int64_t)img * N + n];
     }
-    for (int m = (m_chunk0 == 0 ? 1 : 0); m < mc; ++m) {
-      const float4 gb = s_box[m];
-      if (hd_overlaps(ab, gb)) {
-        float v = hd_iou_full(ab, aarea, gb, s_area[m]);
-        if (v > best) {
-          best = v;
-          bidx = m_chunk0 + m;
-        }
-        if (WITH_GT && v > 0.0f) {
-          unsigned long long key = pack_key(v, n);
-          if (key > s_key[m]) atomicMax(&s_key[m], key);
-        }
-      }
+    // 4 b boxes per iteration: the four LDS reads and overlap tests are independent, so the loop is no
+    // longer a chain of (LDS latency -> test -> branch) per pair; the exact IoU (with its IEEE
+    // division) still runs only for overlapping pairs, in index order so ties keep the lowest m.
+    int m = (m_chunk0 == 0 ? 1 : 0);
+    for (; m + 3 < mc; m += 4) {
+      const float4 g0 = s_box[m], g1 = s_box[m + 1], g2 = s_box[m + 2], g3 = s_box[m + 3];
+      const bool o0 = hd_overlaps(ab, g0), o1 = hd_overlaps(ab, g1), o2 = hd_overlaps(ab, g2),
+                 o3 = hd_overlaps(ab, g3);
+      if (!(o0 || o1 || o2 || o3)) continue;
+#define HD_PAIR(OK, G, MM)                                                   \
+  if (OK) {                                                                  \
+    const float v = hd_iou_full(ab, aarea, G, s_area[MM]);                   \
+    if (v > best) {                                                          \
+      best = v;                                                              \
+      bidx = m_chunk0 + (MM);                                                \
+    }                                                                        \
+    if (WITH_GT && v > 0.0f) {                                               \
+      const unsigned long long key = pack_key(v, n);                         \
+      if (key > s_key[MM]) atomicMax(&s_key[MM], key);                       \
+    }                                                                        \
+  }
+      HD_PAIR(o0, g0, m)
+      HD_PAIR(o1, g1, m + 1)
+      HD_PAIR(o2, g2, m + 2)
+      HD_PAIR(o3, g3, m + 3)
     }
+    for (; m < mc; ++m) {
+      const float4 gb = s_box[m];
+      const bool ok = hd_overlaps(ab, gb);
+      HD_PAIR(ok, gb, m)
+    }
+#undef HD_PAIR
     max_iou[(int64_t)img * N + n] = best;
     argmax[(int64_t)img * N + n] = bidx;
   }

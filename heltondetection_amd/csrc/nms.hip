@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__
 }
 
 // ---- hd_yolo_nms ----------------------------------------------------------------------------
-// One wave per decoded row: lane 0..63 scan the class scores (coalesced), wave arg-max with
-// ties -> lowest class.  Rows failing the objectness gate cost one broadcast load.
+// A wave takes 64 consecutive decoded rows: lane i tests the objectness of row base+i (64 loads in
+// flight), one ballot finds the rows that pass, and for each of those all 64 lanes scan the class
+// scores together (coalesced) and arg-max across lanes with ties -> lowest class.  Rows failing the
+// objectness gate — almost all of them on a real detector — cost one 4-byte load and nothing else.
 __global__ __launch_bounds__(256) void yolo_cand_kernel(const float* __restrict__ dec, int n, int no, float conf_thr,
                                                         CoreWs w, float4* __restrict__ cand_box,
                                                         int32_t* __restrict__ cand_cls,
@@ -34,37 +36,44 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const float* __restrict_
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
   u64* keys = w.keys + (size_t)b * w.key_cap;
-  for (int i = wave; i < n; i += n_waves) {
-    const float* r = dec + ((size_t)b * n + i) * no;
-    const float obj = r[4];
-    if (!(obj > conf_thr)) continue;  // wave-uniform
-    float best = -1.0f;
-    int bc = 0;
-    for (int c = 5 + lane; c < no; c += 64) {
-      const float v = r[c];
-      if (v > best) {
-        best = v;
-        bc = c - 5;
+  const float* base = dec + (size_t)b * n * no;
+  for (int r0 = wave * 64; r0 < n; r0 += n_waves * 64) {
+    const int row = r0 + lane;
+    const float my_obj = row < n ? base[(size_t)row * no + 4] : 0.0f;
+    unsigned long long pass = __ballot(row < n && my_obj > conf_thr);
+    while (pass) {
+      const int j = __ffsll((long long)pass) - 1;
+      pass &= pass - 1;
+      const int i = r0 + j;
+      const float* r = base + (size_t)i * no;
+      const float obj = __shfl(my_obj, j, 64);
+      float best = -1.0f;
+      int bc = 0;
+      for (int c = 5 + lane; c < no; c += 64) {
+        const float v = r[c];
+        if (v > best) {
+          best = v;
+          bc = c - 5;
+        }
       }
-    }
-    // arg-max across lanes, ties -> lower class index
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oc = __shfl_xor(bc, o, 64);
-      if (ob > best || (ob == best && oc < bc)) {
-        best = ob;
-        bc = oc;
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        if (ob > best || (ob == best && oc < bc)) {
+          best = ob;
+          bc = oc;
+        }
       }
-    }
-    const float conf = obj * best;
-    if (lane == 0 && conf > conf_thr) {
-      const float cx = r[0], cy = r[1], bw = r[2], bh = r[3];
-      cand_box[(size_t)b * n + i] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
-      cand_cls[(size_t)b * n + i] = bc;
-      cand_conf[(size_t)b * n + i] = conf;
-      const int pos = atomicAdd(&w.n_keys[b], 1);
-      keys[pos] = make_key(conf, (uint32_t)i);
+      const float conf = obj * best;
+      if (lane == 0 && conf > conf_thr) {
+        const float cx = r[0], cy = r[1], bw = r[2], bh = r[3];
+        cand_box[(size_t)b * n + i] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
+        cand_cls[(size_t)b * n + i] = bc;
+        cand_conf[(size_t)b * n + i] = conf;
+        const int pos = atomicAdd(&w.n_keys[b], 1);
+        keys[pos] = make_key(conf, (uint32_t)i);
+      }
     }
   }
 }
@@ -171,8 +180,8 @@ extern "C" hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float c
   if (workspace_bytes < y.bytes + w.bytes) return HD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
-  int gx = (n + 3) / 4;  // 4 waves per block, one row per wave per iteration
-  if (gx > 1024) gx = 1024;
+  int gx = (n + 255) / 256;  // 4 waves per block, 64 rows per wave per iteration
+  if (gx > 512) gx = 512;
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(gx, B), dim3(256), 0, s, dec, n, no, conf_thr, w, y.cand_box, y.cand_cls,
                      y.cand_conf);
   HD_RETURN_IF_LAUNCH_FAILED();

@@ -46,9 +46,37 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const float* __restrict_
       const int shift = 56 - 8 * pass;
       for (int i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
       __syncthreads();
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const u64 key = make_key(lg[off + i], (uint32_t)(off + i));
-        if ((key & pmask) == prefix) atomicAdd(&s_hist[(int)((key >> shift) & 255ull)], 1);
+      // One workgroup walks a whole level (up to ~400k logits) several times, so the loop must keep
+      // many loads in flight: 8 independent 4-byte loads per lane are issued before any is used.
+      // Logit exponents cluster, so most lanes of a wave hit the same bin and a plain LDS atomic would
+      // serialise 64-fold: 8 ballots find the lanes with an equal digit and the lowest such lane adds
+      // the whole group's count with one atomic.
+      constexpr int U = 8;
+      for (int i0 = 0; i0 < n; i0 += blockDim.x * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * blockDim.x + threadIdx.x;
+          v[u] = i < n ? lg[off + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * blockDim.x + threadIdx.x;
+          bool in = i < n;
+          const u64 key = make_key(v[u], (uint32_t)(off + i));
+          in = in && ((key & pmask) == prefix);
+          const int digit = (int)((key >> shift) & 255ull);
+          u64 peers = __ballot(in);
+          if (peers == 0ull) continue;  // wave-uniform
+#pragma unroll
+          for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (digit >> bit) & 1;
+            const u64 bal = __ballot(in && one);
+            peers &= one ? bal : ~bal;
+          }
+          if (in && (__ffsll((long long)peers) - 1) == (int)(threadIdx.x & 63))
+            atomicAdd(&s_hist[digit], __popcll(peers));
+        }
       }
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -72,6 +100,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const float* __restrict_
     thr = prefix;
   }
   u64* keys = w.keys + (size_t)b * w.key_cap;
+#pragma unroll 4
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int gi = off + i;
     const float v = lg[gi];

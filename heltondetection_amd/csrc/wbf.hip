@@ -52,7 +52,8 @@ __global__ __launch_bounds__(1024) void wbf_kernel(const float4* __restrict__ bo
                                                    const int32_t* __restrict__ k_valid, int K, float weight_sum,
                                                    float iou_thr, float skip_thr, WbfWs w, float* __restrict__ out,
                                                    int32_t* __restrict__ out_count) {
-  __shared__ u64 s_tile[kSortTile];
+  constexpr int kWbfTile = 4096;  // static 32 KiB tile (the NMS engine uses a larger dynamic one)
+  __shared__ u64 s_tile[kWbfTile];
   __shared__ u64 s_red[16];
   __shared__ int s_n;
   const int b = blockIdx.x, t = threadIdx.x;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(1024) void wbf_kernel(const float4* __restrict__ bo
   while (n_pow2 < n) n_pow2 <<= 1;
   for (int i = n + t; i < n_pow2; i += blockDim.x) keys[i] = 0ull;
   __syncthreads();
-  block_sort_desc(keys, n_pow2, s_tile);
+  block_sort_desc(keys, n_pow2, s_tile, kWbfTile);
   // 2. sequential clustering
   int ncl = 0;
   for (int r = 0; r < n; ++r) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(1024) void wbf_kernel(const float4* __restrict__ bo
     keys[c] = key;
   }
   __syncthreads();
-  block_sort_desc(keys, c_pow2, s_tile);
+  block_sort_desc(keys, c_pow2, s_tile, kWbfTile);
   for (int k = t; k < K; k += blockDim.x) {
     float* o = out + ((size_t)b * K + k) * 6;
     if (k < ncl) {
