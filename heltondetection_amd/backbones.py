@@ -8,7 +8,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import C3, SPPF, ConvBNAct
+from .layers import C3, SPPF, ConvBNAct, FusedBNAct
 from .registry import BACKBONES
 
 
@@ -62,10 +62,13 @@ class _ResBottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
+        if self.downsample is None:
+            idt = x
+        else:
+            idt = FusedBNAct.apply(self.downsample[1], self.downsample[0](x), None)
+        y = FusedBNAct.apply(self.bn1, self.conv1(x), "relu")
+        y = FusedBNAct.apply(self.bn2, self.conv2(y), "relu")
+        y = FusedBNAct.apply(self.bn3, self.conv3(y), None)
         return self.relu(y + idt)
 
 
@@ -104,7 +107,7 @@ class ResNet50(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(FusedBNAct.apply(self.bn1, self.conv1(x), "relu"))
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -10,6 +10,29 @@ def autopad(k: int, p=None) -> int:
     return k // 2 if p is None else p
 
 
+class FusedBNAct:
+    """Mixin-free helper: `apply(bn, x, act)` runs BatchNorm2d + activation as the fused HIP kernels
+    (csrc/bn_act.hip) when `x` is a dense channels-last HIP tensor and `enabled` is set, otherwise the
+    plain torch modules.  One statistics slot per BatchNorm2d module is kept in `_slots`."""
+
+    enabled = True
+    _ACTS = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}
+
+    @staticmethod
+    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act):
+        if FusedBNAct.enabled and x.is_cuda:
+            from . import ops
+            if ops.bn_act_supported(x):
+                slot = getattr(bn, "_hd_slot", None)
+                if slot is None and bn.training:
+                    slot = ops.bn_act_slot(x.device, x.shape[1])
+                    bn._hd_slot = slot
+                training = bn.training or bn.running_mean is None
+                return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                  bn.momentum if bn.momentum is not None else 0.1, act, training, slot)
+        return FusedBNAct._ACTS[act](bn(x))
+
+
 class ConvBNAct(nn.Module):
     """Conv2d(bias=False) + BatchNorm2d + activation (SiLU for the YOLOv5 family, ReLU for ResNet)."""
 
@@ -25,14 +48,8 @@ class ConvBNAct(nn.Module):
 
     def forward(self, x):
         y = self.conv(x)
-        if self.fused and y.is_cuda:
-            from . import ops  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
-            if ops.bn_act_supported(y):
-                if self._slot is None and self.training:
-                    self._slot = ops.bn_act_slot(y.device, y.shape[1])
-                bn = self.bn
-                return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
-                                  self.act_name, self.training, self._slot)
+        if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
+            return FusedBNAct.apply(self.bn, y, self.act_name)
         return self.act(self.bn(y))
 
 
