@@ -49,7 +49,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
-    ap.add_argument("--no-graph", action="store_true", help="run forward+backward eagerly instead of from a hipGraph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run forward+backward eagerly instead of replaying a hipGraph (the graph has its memset "
+                         "nodes rewritten into kernel nodes, DESIGN.md section 9, and is guarded: a non-finite or "
+                         "eager-mismatching loss makes bench.py re-time eagerly)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="skip MIOpen's per-shape solver search (faster first step, ~20%% slower steady state)")
     return ap.parse_args()
@@ -204,7 +207,12 @@ def micro_kernels(device):
     add("yolo_decode_kernel", ms, 2 * 16 * n * 85 * 4, "B=16 640x640 C=80")
     dec = ops.yolo_decode(views, strides, anchors)
     ms = timeit(lambda: ops.yolo_nms(dec, 0.25, 0.45, 30000, 300))
-    add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 85 * 4, "B=16 n=25200 conf=0.25", "latency")
+    add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 85 * 4,
+        "B=16 n=25200 conf=0.25 on random logits: ~75% of rows are candidates (stress case)", "latency")
+    ms = timeit(lambda: ops.yolo_nms(dec, 0.9, 0.45, 30000, 300))
+    add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 4,
+        "B=16 n=25200 conf=0.9: ~15 candidates per image (detector-like pass rate; reads the objectness column)",
+        "latency")
     # NMS at RPN-like sizes
     for Nn in (2000, 8000):
         bx = torch.stack([syn.random_boxes(Nn, 832.0, g, 16.0, 300.0) for _ in range(16)]).to(device)
@@ -219,6 +227,17 @@ def micro_kernels(device):
     rois = torch.cat([torch.arange(16).repeat_interleave(512)[:, None].float(), rb], 1).to(device)
     ms = timeit(lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
     add("roi_align_kernel<fwd>", ms, R * 256 * 49 * 4, f"R={R} C=256 P=7 s=2 (out bytes only)")
+    # RPN proposals, config 3: 832^2, 5 levels x 3 anchors, pre 2000 / post 1000
+    strides_r = [4, 8, 16, 32, 64]
+    hw = [(math.ceil(832 / s), math.ceil(832 / s)) for s in strides_r]
+    base = torch.stack([ops.anchor_base([8.0 * s], [0.5, 1.0, 2.0]) for s in strides_r])
+    anchors_r = ops.anchor_grid(hw, strides_r, base, 0.5, device)
+    ls = [h * w * 3 for h, w in hw]
+    NA = anchors_r.shape[0]
+    lg = torch.randn((16, NA), generator=g).to(device)
+    dl = (torch.randn((16, NA, 4), generator=g) * 0.2).to(device)
+    ms = timeit(lambda: ops.rpn_proposals(lg, dl, anchors_r, ls, 2000, 1000, 0.7, 0.0, 832.0, 832.0))
+    add("rpn_proposals (topk+decode+sort+mask+scan+emit)", ms, 16 * NA * 20, f"B=16 NA={NA} pre=2000 post=1000", "latency")
     return res
 
 
@@ -243,7 +262,7 @@ def main():
     model = model.to(device).to(memory_format=torch.channels_last).train()
     trainer = Trainer(model, lr=1e-3, amp_dtype=None if args.fp32 else torch.bfloat16,
                       total_steps=args.steps + args.warmup + 1, warmup_steps=3, device=device,
-                      use_graph=not args.no_graph)
+                      use_graph=not args.no_graph, graph_sync=False)
     batches = make_batches(4, args.batch, args.size, args.classes, 1234 + rank, device)
 
     def log(msg):

@@ -101,6 +101,7 @@ SIGNATURES = {
     "hd_bn_act_infer": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _I, _P, _P]),
     "hd_bn_act_bwd_reduce": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P]),
     "hd_bn_act_bwd_dx": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "hd_graph_replace_memsets": (_I, [_P, _P, _P]),
     "hd_wbf_workspace_bytes": (_Z, [_I, _I]),
     "hd_wbf": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
 }

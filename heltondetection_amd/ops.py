@@ -674,3 +674,14 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
                               _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), code,
                               _ptr(y), _stream(x)), "hd_bn_act_infer")
     return y
+
+
+# ------------------------------------------------------------------------------- hipGraph hygiene
+def graph_replace_memsets(raw_graph) -> Tuple[int, int]:
+    """raw_graph: the hipGraph_t of a captured but not yet instantiated graph
+    (``torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()``).  Returns (nodes, memsets replaced)."""
+    lib = _lib.load()
+    n, r = C.c_int(0), C.c_int(0)
+    ptr = raw_graph if isinstance(raw_graph, int) else int(raw_graph)
+    check(lib.hd_graph_replace_memsets(C.c_void_p(ptr), C.byref(n), C.byref(r)), "hd_graph_replace_memsets")
+    return n.value, r.value

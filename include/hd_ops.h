@@ -330,6 +330,14 @@ hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, int64_t R, 
                            const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                            float* dbeta, hd_stream stream);
 
+/* ---- hipGraph hygiene ------------------------------------------------------------------------ */
+
+/* Replaces every memset node of a captured, NOT YET INSTANTIATED hipGraph_t by an equivalent
+ * fill-kernel node with the same predecessors/successors (host call; no stream).  On ROCm 7.2
+ * memset nodes were observed not to stay ordered against neighbouring kernel nodes on replay
+ * (DESIGN.md section 9).  n_nodes_out / n_replaced_out (host, may be NULL) receive the counts. */
+hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out, int* n_replaced_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,3 +385,43 @@ def test_bn_act_matches_torch(gpu, ops, dtype, act, C):
     zi = torch.nn.functional.batch_norm(x.double(), rmd.cpu().double(), rvd.cpu().double(), w.double(), b.double(), False, 0.03, 1e-3)
     yir = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}[act](zi)
     assert H.rel_err(yi.float().cpu().numpy(), yir.numpy()) < tol
+
+
+# ------------------------------------------------------------------------------- hipGraph memset rewrite
+def test_graph_memset_nodes_are_rewritten(gpu, ops):
+    """Capture a small graph containing real hipMemsetAsync calls (1-byte pattern on an odd length, 4-byte
+    aligned span) between kernels, rewrite the memset nodes, instantiate, replay: same results, no memset left."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetAsync.restype = ctypes.c_int
+    a = torch.full((1001,), 7, dtype=torch.uint8, device=gpu)
+    b = torch.ones((4096,), dtype=torch.float32, device=gpu)
+    x = torch.arange(64, dtype=torch.float32, device=gpu)
+    y = torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y.copy_(x * 2)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        st = torch.cuda.current_stream().cuda_stream
+        y.copy_(x * 2)
+        assert hip.hipMemsetAsync(a.data_ptr() + 3, 0x5A, 997, st) == 0      # unaligned, odd length
+        assert hip.hipMemsetAsync(b.data_ptr(), 0, 4096 * 4, st) == 0         # aligned words
+        y.add_(b[:64])                                                        # depends on the memset of b
+    nodes, replaced = ops.graph_replace_memsets(g.raw_cuda_graph())
+    assert replaced == 2 and nodes >= 4
+    g.instantiate()
+    for _ in range(3):
+        a.fill_(7)
+        b.fill_(1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        ar = a.cpu().numpy()
+        assert (ar[:3] == 7).all() and (ar[3:1000] == 0x5A).all() and ar[1000] == 7
+        assert float(b.abs().sum()) == 0.0
+        assert torch.equal(y.cpu(), torch.arange(64, dtype=torch.float32) * 2)   # b was already zero when added
+    nodes2, replaced2 = ops.graph_replace_memsets(g.raw_cuda_graph())
+    assert replaced2 == 0
