@@ -1,0 +1,168 @@
+"""Edge cases through the C-ABI and size-independent properties at BASELINE.json's full sizes
+(the serial oracle would need minutes there, so the checks are identities between HIP paths, or
+against plain torch fp32 ops on the GPU for the floating-point decode)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from heltondetection_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------- edge cases
+def test_empty_and_degenerate_inputs(gpu, ops):
+    z4 = torch.zeros((2, 0, 4), device=gpu)
+    b = H.boxes_batch(2, 5, 64, 1).to(gpu)
+    assert ops.pairwise_iou(z4, b).shape == (2, 0, 5)
+    assert ops.pairwise_iou(b, z4).shape == (2, 5, 0)
+    mx, am, gmx, gam = ops.iou_assign(b, z4, None)
+    assert (mx == -1).all() and (am == -1).all() and gmx.shape == (2, 0)
+    mx, am, gmx, gam = ops.iou_assign(b, b, torch.zeros(2, dtype=torch.int32, device=gpu))   # all gt padded out
+    assert (mx == -1).all() and (am == -1).all() and (gmx == -1).all() and (gam == -1).all()
+    keep, cnt = ops.nms_batched(b, torch.rand((2, 5), device=gpu), None, torch.zeros(2, dtype=torch.int32, device=gpu), 0.0, 0.5, 0, 5)
+    assert (cnt == 0).all() and (keep == -1).all()
+    keep, cnt = ops.nms_batched(b, torch.full((2, 5), float("nan"), device=gpu), None, None, 0.0, 0.5, 0, 5)
+    assert (cnt == 0).all()                                            # NaN scores never pass
+    keep, cnt = ops.nms_batched(b, torch.rand((2, 5), device=gpu), None, None, 0.0, 0.5, 0, 0)
+    assert keep.shape == (2, 0) and (cnt == 0).all()
+    # zero-area boxes never suppress each other
+    zb = torch.tensor([[[5., 5., 5., 5.], [5., 5., 5., 5.], [1., 1., 9., 9.]]], device=gpu)
+    keep, cnt = ops.nms_batched(zb, torch.tensor([[0.9, 0.8, 0.7]], device=gpu), None, None, 0.0, 0.1, 0, 3)
+    assert int(cnt[0]) == 3
+    # RoIAlign with no RoIs, WBF with nothing above the skip threshold
+    f = [torch.randn((1, 8, 16, 16), device=gpu)]
+    assert ops.roi_align(f, torch.zeros((0, 5), device=gpu), 3, [1.0], 2, True, 2, 224.0, 4).shape == (0, 8, 3, 3)
+    out, c = ops.wbf(b, torch.zeros((2, 5), device=gpu), torch.zeros((2, 5), dtype=torch.int32, device=gpu),
+                     torch.ones((2, 5), device=gpu), None, 1.0, 0.5, 0.1)
+    assert (c == 0).all() and float(out.abs().sum()) == 0.0
+
+
+def test_ragged_batches_match_oracle(gpu, ops):
+    """Every image has a different number of valid gt boxes / candidates (padding must be inert)."""
+    B, N, M = 4, 700, 48
+    a = H.boxes_batch(B, N, 512, 3)
+    b = H.boxes_batch(B, M, 512, 4)
+    mv = torch.tensor([48, 1, 0, 17], dtype=torch.int32)
+    got = ops.iou_assign(a.to(gpu), b.to(gpu), mv.to(gpu))
+    ref = co.iou_assign(a.numpy(), b.numpy(), mv.numpy())
+    for x, y in zip(got, ref):
+        assert np.array_equal(x.cpu().numpy(), y)
+    scores = H.distinct_scores(B, N, 5)
+    nv = torch.tensor([700, 3, 0, 65], dtype=torch.int32)   # 65: one past a 64-box tile boundary
+    keep, cnt = ops.nms_batched(a.to(gpu), scores.to(gpu), None, nv.to(gpu), 0.1, 0.4, 0, 128)
+    rk, rc = co.nms_batched(a.numpy(), scores.numpy(), None, nv.numpy(), 0.1, 0.4, 0, 128)
+    assert np.array_equal(cnt.cpu().numpy(), rc) and np.array_equal(keep.cpu().numpy(), rk)
+
+
+def test_status_codes_on_bad_arguments(gpu, ops):
+    import ctypes as C
+    from heltondetection_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros((1, 70000, 4), device=gpu)
+    s = torch.zeros((1, 70000), device=gpu)
+    with pytest.raises(_lib.HdError, match="out of range"):            # > 65536 candidates with no clamp
+        ops.nms_batched(t, s, None, None, -1.0, 0.5, 0, 10)
+    keep, cnt = ops.nms_batched(t, s, None, None, -1.0, 0.5, 4096, 10)  # clamped: fine
+    assert keep.shape == (1, 10)
+    with pytest.raises(_lib.HdError):                                   # dtype contract
+        ops.pairwise_iou(t.double(), t)
+    # workspace too small is reported, not written past
+    ws = torch.empty(16, dtype=torch.uint8, device=gpu)
+    k = torch.empty((1, 4), dtype=torch.int32, device=gpu)
+    c = torch.empty((1,), dtype=torch.int32, device=gpu)
+    st = lib.hd_nms_batched(C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()), None, None, 1, 100, 0.0, 0.5, 0, 4,
+                            C.c_void_p(k.data_ptr()), C.c_void_p(c.data_ptr()), C.c_void_p(ws.data_ptr()), 16, None)
+    assert st == -4
+
+
+# ------------------------------------------------------------------------------- full-size properties
+def test_fullsize_fused_assign_equals_materialised_reductions(gpu, ops):
+    """BASELINE config 5 shape: 1280^2, A=3 -> N=409200 anchors, ~500 gt.  max/argmax of the materialised
+    [B,N,M] matrix (torch reductions on the GPU) must equal the fused kernel's outputs bit for bit."""
+    from heltondetection_amd import synthetic as syn
+    g = syn.make_generator(21)
+    B, N, M = 2, 409200, 500
+    a = syn.random_boxes(N, 1280.0, g, 8.0, 512.0).to(gpu)
+    b = torch.stack([syn.random_boxes(M, 1280.0, g, 4.0, 64.0) for _ in range(B)]).to(gpu)
+    mv = torch.tensor([500, 433], dtype=torch.int32, device=gpu)
+    iou = ops.pairwise_iou(a, b, mv)                   # 1.6 GB
+    mx, am, gmx, gam = ops.iou_assign(a, b, mv)
+    assert float(iou.max()) <= 1.0 and float(iou[0].min()) >= 0.0
+    assert (iou[1, :, 433:] == -1).all()
+    rmx, _ = iou.max(dim=2)
+    assert torch.equal(rmx, mx)
+    # argmax: the fused index must point at a maximal entry, and be the FIRST such entry
+    picked = torch.gather(iou, 2, am.long().clamp(min=0)[..., None])[..., 0]
+    assert torch.equal(picked, mx)
+    first = (iou == mx[..., None]).int().argmax(dim=2)
+    assert torch.equal(first.int(), am)
+    cmx, _ = iou.max(dim=1)
+    assert torch.equal(cmx[0], gmx[0]) and torch.equal(cmx[1, :433], gmx[1, :433]) and (gmx[1, 433:] == -1).all()
+    cfirst = (iou == cmx[:, None, :]).int().argmax(dim=1)
+    assert torch.equal(cfirst[0].int(), gam[0]) and torch.equal(cfirst[1, :433].int(), gam[1, :433])
+    del iou
+
+
+def test_fullsize_decode_matches_torch_fp32(gpu, ops):
+    """bs16 640x640 C=80 through the channels-last view, against plain torch fp32 ops on the GPU (1e-4 rel)."""
+    from heltondetection_amd.heads import YOLOV5_ANCHORS
+    B, no = 16, 85
+    g = torch.Generator(device="cpu").manual_seed(31)
+    views, ref_rows = [], []
+    for l, s in enumerate((8, 16, 32)):
+        Hh = 640 // s
+        conv = (torch.randn((B, 3 * no, Hh, Hh), generator=g) * 2).to(gpu).contiguous(memory_format=torch.channels_last)
+        v = conv.view(B, 3, no, Hh, Hh).permute(0, 1, 3, 4, 2)
+        views.append(v)
+        y = v.sigmoid()
+        yy, xx = torch.meshgrid(torch.arange(Hh, device=gpu, dtype=torch.float32), torch.arange(Hh, device=gpu, dtype=torch.float32), indexing="ij")
+        grid = torch.stack((xx, yy), 2).view(1, 1, Hh, Hh, 2)
+        anc = torch.tensor(YOLOV5_ANCHORS[l], device=gpu, dtype=torch.float32).view(1, 3, 1, 1, 2)
+        ref_rows.append(torch.cat(((y[..., :2] * 2 - 0.5 + grid) * s, (y[..., 2:4] * 2) ** 2 * anc, y[..., 4:]), -1).reshape(B, -1, no))
+    ref = torch.cat(ref_rows, 1)
+    out = ops.yolo_decode(views, (8, 16, 32), YOLOV5_ANCHORS)
+    assert out.shape == (16, 25200, 85)
+    rel = ((out - ref).abs() / (ref.abs() + 1e-4)).max()
+    assert float(rel) < 1e-4
+
+
+def test_fullsize_loss_bookkeeping(gpu, ops):
+    """bs16 640x640: total == B*(lbox+lobj+lcls); the dense gradient is zero outside channel 4 except at the
+    matched cells; its per-channel sums equal the bias gradient the kernels report."""
+    from heltondetection_amd import synthetic as syn
+    from heltondetection_amd.heads import YOLOV5_ANCHORS
+    B, no = 16, 85
+    g = syn.make_generator(41)
+    gtb, gtc, mv = syn.make_targets(B, 640, g, "coco", 80, 40)
+    convs = []
+    for s in (8, 16, 32):
+        Hh = 640 // s
+        convs.append(torch.randn((B, 3 * no, Hh, Hh), generator=g).to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True))
+    views = [c.view(B, 3, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in convs]
+    shapes = [(3, v.shape[2], v.shape[3], no) for v in views]
+    slots = ops.yolo_assign(shapes, (8, 16, 32), YOLOV5_ANCHORS, gtb.to(gpu), gtc.to(gpu), mv.to(gpu))
+    biases = [torch.zeros(3 * no, device=gpu, requires_grad=True) for _ in views]
+    total, parts = ops.yolo_loss(views, (8, 16, 32), YOLOV5_ANCHORS, slots, 40, biases=biases)
+    assert abs(float(parts[0]) - B * float(parts[1] + parts[2] + parts[3])) < 1e-3 * float(parts[0])
+    assert abs(float(total) - float(parts[0])) < 1e-6
+    total.backward()
+    for l, c in enumerate(convs):
+        gview = c.grad.view(B, 3, no, c.shape[2], c.shape[3])
+        matched = torch.zeros((B * 3 * c.shape[2] * c.shape[3],), dtype=torch.bool, device=gpu)
+        cells = slots[0][l]
+        matched[cells[cells >= 0].long()] = True
+        matched = matched.view(B, 3, c.shape[2], c.shape[3])
+        others = gview[:, :, [0, 1, 2, 3] + list(range(5, no))]
+        assert float(others.abs().amax(dim=2)[~matched].max()) == 0.0     # only matched cells carry box/class gradient
+        ref_bias = gview.double().sum(dim=(0, 3, 4)).reshape(-1)
+        assert float((biases[l].grad.double() - ref_bias).abs().max() / (ref_bias.abs().max() + 1e-12)) < 1e-4
