@@ -54,6 +54,12 @@ inline hd_status check_levels(const hd_yolo_levels* lv, int B) {
   return HD_OK;
 }
 
+inline bool is_dense_nhwc_decl(const hd_yolo_levels& g, int l, int B) {
+  const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l];
+  return g.so[l] == 1 && g.sa[l] == no && g.sx[l] == na * no && g.sy[l] == W * na * no &&
+         (B == 1 || g.sb[l] == H * W * na * no);
+}
+
 // ------------------------------------------------------------------------------------ decode
 //
 // One workgroup = 64 consecutive output rows of one (level, image, anchor) group, staged through
@@ -101,19 +107,35 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const hd_yolo_levels l
   const float stride = lv.stride[l], aw = lv.anchor_w[l][a], ah = lv.anchor_h[l][a];
   const float inv_no = 1.0f / (float)no;
   const int elems = rows * no;
-  for (int i = threadIdx.x; i < elems; i += blockDim.x) {
-    int r = (int)(((float)i + 0.5f) * inv_no);
-    int c = i - r * no;
-    if (c < 0) { --r; c += no; }
-    if (c >= no) { ++r; c -= no; }
-    const float s = hd_sigmoid(pr[s_off[r] + c * so]);
-    float v;
-    if (c == 0) v = (s * 2.0f - 0.5f + (float)s_x[r]) * stride;
-    else if (c == 1) v = (s * 2.0f - 0.5f + (float)s_y[r]) * stride;
-    else if (c == 2) v = (s * 2.0f) * (s * 2.0f) * aw;
-    else if (c == 3) v = (s * 2.0f) * (s * 2.0f) * ah;
-    else v = s;
-    s_tile[i] = v;
+  // 4 elements per lane per iteration: the four (row table lookup -> global load) chains are issued
+  // before any value is used, so four 4-byte loads per lane are in flight instead of one
+  for (int i0 = threadIdx.x; i0 < elems; i0 += blockDim.x * 4) {
+    int r[4], c[4];
+    float raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      int rr = (int)(((float)i + 0.5f) * inv_no);
+      int cc = i - rr * no;
+      if (cc < 0) { --rr; cc += no; }
+      if (cc >= no) { ++rr; cc -= no; }
+      r[u] = rr;
+      c[u] = cc;
+      raw[u] = i < elems ? pr[s_off[rr] + cc * so] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i >= elems) break;
+      const float s = hd_sigmoid(raw[u]);
+      float v;
+      if (c[u] == 0) v = (s * 2.0f - 0.5f + (float)s_x[r[u]]) * stride;
+      else if (c[u] == 1) v = (s * 2.0f - 0.5f + (float)s_y[r[u]]) * stride;
+      else if (c[u] == 2) v = (s * 2.0f) * (s * 2.0f) * aw;
+      else if (c[u] == 3) v = (s * 2.0f) * (s * 2.0f) * ah;
+      else v = s;
+      s_tile[i] = v;
+    }
   }
   __syncthreads();
   const long long n_total = ix.first_row[lv.n_levels];
@@ -126,6 +148,107 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const hd_yolo_levels l
     for (int i = (words << 2) + threadIdx.x; i < elems; i += blockDim.x) o[i] = s_tile[i];
   } else {
     for (int i = threadIdx.x; i < elems; i += blockDim.x) o[i] = s_tile[i];
+  }
+}
+
+// Dense channels-last fast path.  The level's tensor is one contiguous block in memory order
+// (b, y, x, a, c); a workgroup takes kDenseCells consecutive cells = kDenseCells*na*no contiguous floats,
+// reads them with 16-byte loads (every byte of every cache line is used exactly once, unlike the
+// per-anchor gather above, whose 4*no-byte rows sit at a 4*na*no-byte stride), decodes each value
+// in registers and drops it at its OUTPUT position in an LDS tile laid out [a][cell][c]; each
+// anchor's kDenseCells*no floats are then contiguous in the output and are streamed out with
+// 16-byte stores when aligned.
+constexpr int kDenseCells = 16;
+
+__global__ __launch_bounds__(256) void yolo_decode_dense_kernel(const hd_yolo_levels lv, const LevelIndex ix,
+                                                                const DecodePlan plan, int B,
+                                                                float* __restrict__ out) {
+  extern __shared__ float s_tile[];  // [na][kDenseCells][no]
+  __shared__ float s_gx[kDenseCells], s_gy[kDenseCells];
+  __shared__ float s_aw[HD_MAX_ANCHORS], s_ah[HD_MAX_ANCHORS];  // per-lane anchor index: keep the table out of the kernarg struct
+  const int no = lv.no, na = lv.na;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < HD_MAX_LEVELS; ++k)
+    if (k < lv.n_levels && (int)blockIdx.x >= plan.first_block[k]) l = k;
+  int rem = (int)blockIdx.x - plan.first_block[l];
+  const int tile = rem % plan.tiles[l];
+  const int b = rem / plan.tiles[l];
+  const int H = lv.h[l], W = lv.w[l], HW = H * W;
+  const int cell0 = tile * kDenseCells;
+  const int cells = min(kDenseCells, HW - cell0);
+  const int row_len = na * no;               // floats per cell
+  const int elems = cells * row_len;
+  const float* __restrict__ src = lv.pred[l] + (size_t)b * lv.sb[l] + (size_t)cell0 * row_len;
+  const float stride = lv.stride[l];
+  if (threadIdx.x < cells) {
+    const int gcell = cell0 + threadIdx.x;
+    const int y = gcell / W;
+    s_gx[threadIdx.x] = (float)(gcell - y * W);
+    s_gy[threadIdx.x] = (float)y;
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + na) {
+    s_aw[threadIdx.x - 64] = lv.anchor_w[l][threadIdx.x - 64];
+    s_ah[threadIdx.x - 64] = lv.anchor_h[l][threadIdx.x - 64];
+  }
+  __syncthreads();
+  // lane-consecutive elements: 256-byte coalesced loads and conflict-free LDS writes (consecutive lanes
+  // hit consecutive words).  The (cell, anchor, channel) digits of a lane's element are computed once and
+  // then advanced by the block stride with carries — no division in the loop.
+  int c = threadIdx.x % no;
+  int t = threadIdx.x / no;
+  int a = t % na;
+  int cell = t / na;
+  const int dc = (int)blockDim.x % no;
+  const int t2 = (int)blockDim.x / no;
+  const int da = t2 % na, dcell = t2 / na;
+  for (int i0 = threadIdx.x; i0 < elems; i0 += blockDim.x * 4) {
+    float raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      raw[u] = i < elems ? src[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i < elems) {
+        const float s = hd_sigmoid(raw[u]);
+        float v = s;
+        if (c < 4) {
+          if (c == 0) v = (s * 2.0f - 0.5f + s_gx[cell]) * stride;
+          else if (c == 1) v = (s * 2.0f - 0.5f + s_gy[cell]) * stride;
+          else if (c == 2) v = (s * 2.0f) * (s * 2.0f) * s_aw[a];
+          else v = (s * 2.0f) * (s * 2.0f) * s_ah[a];
+        }
+        s_tile[(a * kDenseCells + cell) * no + c] = v;
+      }
+      // advance the digits by blockDim.x
+      c += dc;
+      int carry = c >= no;
+      c -= carry * no;
+      a += da + carry;
+      carry = a >= na;
+      a -= carry * na;
+      carry += a >= na;  // da + carry can wrap twice only if na == 1; handled by the second compare
+      a -= (a >= na) * na;
+      cell += dcell + carry;
+    }
+  }
+  __syncthreads();
+  const long long n_total = ix.first_row[lv.n_levels];
+  const int per_a = cells * no;
+  for (int a = 0; a < na; ++a) {
+    float* __restrict__ o = out + (((long long)b * n_total + ix.first_row[l] + (long long)a * HW + cell0) * no);
+    const float* __restrict__ t = s_tile + (size_t)a * kDenseCells * no;
+    if ((reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
+      const int words = per_a >> 2;
+      for (int q = threadIdx.x; q < words; q += blockDim.x)
+        reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(t)[q];
+      for (int i = (words << 2) + threadIdx.x; i < per_a; i += blockDim.x) o[i] = t[i];
+    } else {
+      for (int i = threadIdx.x; i < per_a; i += blockDim.x) o[i] = t[i];
+    }
   }
 }
 
@@ -556,6 +679,27 @@ extern "C" hd_status hd_yolo_decode(const hd_yolo_levels* lv, int B, float* out,
   if (!out) return HD_ERR_NULL;
   if (!hd_aligned16(out)) return HD_ERR_ALIGN;
   const LevelIndex ix = make_index(*lv, B);
+  bool all_dense = true;
+  for (int l = 0; l < lv->n_levels; ++l) all_dense = all_dense && is_dense_nhwc_decl(*lv, l, B);
+  if (all_dense && (size_t)lv->na * kDenseCells * lv->no * sizeof(float) <= 64 * 1024) {
+    DecodePlan dplan;
+    long long dblocks = 0;
+    for (int l = 0; l <= HD_MAX_LEVELS; ++l) {
+      dplan.first_block[l] = (int)dblocks;
+      if (l < lv->n_levels) {
+        dplan.tiles[l] = (lv->h[l] * lv->w[l] + kDenseCells - 1) / kDenseCells;
+        dblocks += (long long)dplan.tiles[l] * B;
+      } else if (l < HD_MAX_LEVELS) {
+        dplan.tiles[l] = 1;
+      }
+    }
+    if (dblocks > 0x7fffffffLL) return HD_ERR_SHAPE;
+    const size_t dlds = (size_t)lv->na * kDenseCells * lv->no * sizeof(float);
+    hipLaunchKernelGGL(yolo_decode_dense_kernel, dim3((unsigned)dblocks), dim3(256), dlds, (hipStream_t)stream, *lv,
+                       ix, dplan, B, out);
+    HD_RETURN_IF_LAUNCH_FAILED();
+    return HD_OK;
+  }
   DecodePlan plan;
   long long blocks = 0;
   for (int l = 0; l <= HD_MAX_LEVELS; ++l) {
