@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -82,6 +82,8 @@ SIGNATURES = {
     "hd_roi_level_map": (_I, [_P, _I, _I, _I, _F, _I, _P, _P]),
     "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
     "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
+    "hd_roi_pool_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
+    "hd_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_yolo_decode": (_I, [_P, _I, _P, _P]),
     "hd_yolo_assign": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "hd_yolo_loss_workspace_bytes": (_Z, [_P, _I]),

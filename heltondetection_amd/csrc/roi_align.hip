@@ -1,5 +1,7 @@
-// roi_align.hip — RoIAlign over pyramid levels, forward and backward
-// (reference README.md:65,73 "RoIAlign" default; SURVEY.md §8a "RoIAlign over FPN levels").
+// roi_align.hip — RoIAlign (default) and quantised RoI max-pooling (the "-RoIPooling" variant)
+// over pyramid levels, forward and backward
+// (reference README.md:65,73 "RoIAlign" default, README.md:73 "FasterRCNN-FPNP2-RoIPooling";
+// SURVEY.md §8a "RoIAlign over FPN levels").
 //
 // A gather: per RoI bin, sampling_ratio^2 bilinear samples x 4 taps x C channels.  The layout
 // decision that matters on MI355X: features are consumed through explicit strides and the fast
@@ -134,6 +136,84 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const hd_roi_levels lv, 
   }
 }
 
+// ---- quantised RoI max-pooling -------------------------------------------------------------------
+// Same mapping as RoIAlign: workgroup = (RoI, pooled row), lanes = channels, so the bin bounds are
+// wave-uniform scalars and a wave reads 64 consecutive channels of one cell per request.
+struct PoolGeom {
+  int start_w, start_h;
+  float bin_w, bin_h;
+};
+
+__device__ __forceinline__ PoolGeom pool_geometry(const float* roi, float scale, int P) {
+  PoolGeom g;
+  g.start_w = (int)roundf(roi[1] * scale);
+  g.start_h = (int)roundf(roi[2] * scale);
+  const int end_w = (int)roundf(roi[3] * scale), end_h = (int)roundf(roi[4] * scale);
+  const int rw = max(end_w - g.start_w + 1, 1), rh = max(end_h - g.start_h + 1, 1);
+  g.bin_w = (float)rw / (float)P;
+  g.bin_h = (float)rh / (float)P;
+  return g;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const hd_roi_levels lv, const float* __restrict__ rois,
+                                                           int C, int P, float* __restrict__ out,
+                                                           int32_t* __restrict__ argmax, long long out_sr,
+                                                           long long out_sc, long long out_sh, long long out_sw) {
+  const int r = blockIdx.x, ph = blockIdx.y;
+  const float* roi = rois + (size_t)r * 5;
+  const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
+  const int bi = (int)roi[0];
+  const int H = lv.h[l], W = lv.w[l];
+  const PoolGeom g = pool_geometry(roi, lv.spatial_scale[l], P);
+  const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
+  const float* fbase = lv.feat[l] + (long long)bi * lv.sb[l];
+  const int hs = clampi((int)floorf((float)ph * g.bin_h) + g.start_h, 0, H);
+  const int he = clampi((int)ceilf((float)(ph + 1) * g.bin_h) + g.start_h, 0, H);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* f = fbase + (long long)c * sc;
+    for (int pw = 0; pw < P; ++pw) {
+      const int ws = clampi((int)floorf((float)pw * g.bin_w) + g.start_w, 0, W);
+      const int we = clampi((int)ceilf((float)(pw + 1) * g.bin_w) + g.start_w, 0, W);
+      const bool empty = (he <= hs) || (we <= ws);
+      float best = empty ? 0.0f : -3.402823466e+38f;
+      int arg = -1;
+      for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) {
+          const float v = f[y * sh + x * sw];
+          if (v > best) {
+            best = v;
+            arg = y * W + x;
+          }
+        }
+      const long long o = r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
+      out[o] = best;
+      argmax[o] = arg;
+    }
+  }
+}
+
+// flat over [R, P, P, C-major-last]: every output element scatters one value
+__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const hd_roi_levels lv, const float* __restrict__ rois,
+                                                           int C, int P, const float* __restrict__ grad_out,
+                                                           const int32_t* __restrict__ argmax, long long out_sr,
+                                                           long long out_sc, long long out_sh, long long out_sw) {
+  const int r = blockIdx.x, ph = blockIdx.y;
+  const float* roi = rois + (size_t)r * 5;
+  const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
+  const int bi = (int)roi[0];
+  const int W = lv.w[l];
+  const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
+  float* fbase = const_cast<float*>(lv.feat[l]) + (long long)bi * lv.sb[l];
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    for (int pw = 0; pw < P; ++pw) {
+      const long long o = r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
+      const int a = argmax[o];
+      if (a >= 0) atomicAdd(fbase + (long long)c * sc + (long long)(a / W) * sh + (long long)(a % W) * sw, grad_out[o]);
+    }
+}
+
 inline hd_status check_roi_args(const hd_roi_levels* lv, const float* rois, int R, int C, int P, const float* out) {
   if (!lv) return HD_ERR_NULL;
   if (R < 0 || C <= 0 || P <= 0 || P > 65535 || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS) return HD_ERR_SHAPE;
@@ -181,6 +261,32 @@ extern "C" hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const fl
   hipLaunchKernelGGL((roi_align_kernel<true>), dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *grad_levels, rois,
                      C, P, sampling_ratio, aligned, const_cast<float*>(grad_out), (long long)out_sr,
                      (long long)out_sc, (long long)out_sh, (long long)out_sw);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_roi_pool_fwd(const hd_roi_levels* levels, const float* rois, int R, int C, int P, float* out,
+                                     int32_t* argmax, int64_t out_sr, int64_t out_sc, int64_t out_sh,
+                                     int64_t out_sw, hd_stream stream) {
+  hd_status st = check_roi_args(levels, rois, R, C, P, out);
+  if (st != HD_OK || R == 0) return st;
+  if (!argmax) return HD_ERR_NULL;
+  const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
+  hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *levels, rois, C, P, out,
+                     argmax, (long long)out_sr, (long long)out_sc, (long long)out_sh, (long long)out_sw);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_roi_pool_bwd(const hd_roi_levels* grad_levels, const float* rois, int R, int C, int P,
+                                     const float* grad_out, const int32_t* argmax, int64_t out_sr, int64_t out_sc,
+                                     int64_t out_sh, int64_t out_sw, hd_stream stream) {
+  hd_status st = check_roi_args(grad_levels, rois, R, C, P, grad_out);
+  if (st != HD_OK || R == 0) return st;
+  if (!argmax) return HD_ERR_NULL;
+  const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
+  hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *grad_levels, rois, C, P,
+                     grad_out, argmax, (long long)out_sr, (long long)out_sc, (long long)out_sh, (long long)out_sw);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

@@ -176,15 +176,19 @@ class RPNHead(nn.Module):
 
 @HEADS.register()
 class RoIHead(nn.Module):
-    """Second stage: RoIAlign over pyramid levels (HIP) + box head.  `decoupled=True` gives the
-    Decoupled-Head of README.md:65,76 (separate classification FC tower and regression conv tower)."""
+    """Second stage: RoIAlign (default) or quantised RoI max-pooling (`roi_op="pool"`, the
+    "-RoIPooling" variant of README.md:73) over pyramid levels (HIP) + box head.  `decoupled=True` gives
+    the Decoupled-Head of README.md:65,76 (separate classification FC tower and regression conv tower)."""
 
     def __init__(self, in_channels: int = 256, num_classes: int = 80, roi_size: int = 7, sampling_ratio: int = 2,
                  featmap_strides: Sequence[int] = (4, 8, 16, 32), k_min: int = 2, decoupled: bool = False,
                  fc_dim: int = 1024, batch_per_image: int = 128, pos_fraction: float = 0.25, assigner=None,
                  delta_std: Sequence[float] = (0.1, 0.1, 0.2, 0.2), score_thr: float = 0.05, nms_thr: float = 0.5,
-                 max_det: int = 100, pre_nms_candidates: int = 4096):
+                 max_det: int = 100, pre_nms_candidates: int = 4096, roi_op: str = "align"):
         super().__init__()
+        if roi_op not in ("align", "pool"):
+            raise ValueError(f"roi_op must be 'align' or 'pool', got {roi_op!r}")
+        self.roi_op = roi_op
         self.nc, self.P, self.sr = num_classes, roi_size, sampling_ratio
         self.scales = tuple(1.0 / s for s in featmap_strides)
         self.k_min = k_min
@@ -217,6 +221,9 @@ class RoIHead(nn.Module):
     # ---- RoI features ------------------------------------------------------------------------
     def extract(self, feats: List[torch.Tensor], rois5: torch.Tensor) -> torch.Tensor:
         f32 = [f.float() for f in feats[: len(self.scales)]]
+        if self.roi_op == "pool":
+            return ops.roi_pool(f32, rois5, self.P, self.scales[: len(f32)], self.k_min, 224.0, 4,
+                                channels_last_out=self.decoupled)
         return ops.roi_align(f32, rois5, self.P, self.scales[: len(f32)], self.sr, True, self.k_min, 224.0, 4,
                              channels_last_out=self.decoupled)
 

@@ -286,6 +286,53 @@ def roi_align(feats: Sequence[torch.Tensor], rois: torch.Tensor, P: int, scales:
                              float(canonical_scale), int(canonical_level), bool(channels_last_out), *feats)
 
 
+class _RoIPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, P, scales, k_min, canonical_scale, canonical_level, channels_last_out, *feats):
+        lib = _lib.load()
+        rois = _need(rois.detach(), _F32, "rois")
+        feats_d = [f.detach() for f in feats]
+        st = _roi_levels(feats_d, scales, k_min, canonical_scale, canonical_level)
+        R, Cc = rois.shape[0], feats[0].shape[1]
+        fmt = torch.channels_last if channels_last_out else torch.contiguous_format
+        out = torch.empty((R, Cc, P, P), dtype=_F32, device=rois.device, memory_format=fmt)
+        arg = torch.empty((R, Cc, P, P), dtype=_I32, device=rois.device, memory_format=fmt)
+        check(lib.hd_roi_pool_fwd(C.byref(st), _ptr(rois), R, Cc, P, _ptr(out), _ptr(arg), out.stride(0),
+                                  out.stride(1), out.stride(2), out.stride(3), _stream(rois)), "hd_roi_pool_fwd")
+        ctx.save_for_backward(rois, arg)
+        ctx.meta = (P, tuple(scales), k_min, canonical_scale, canonical_level,
+                    [(tuple(f.shape), f.is_contiguous(memory_format=torch.channels_last)) for f in feats])
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        lib = _lib.load()
+        rois, arg = ctx.saved_tensors
+        P, scales, k_min, cs, cl, shapes = ctx.meta
+        # the gradient must share argmax's strides: one index walks both
+        go = torch.empty_like(arg, dtype=_F32)
+        go.copy_(grad_out)
+        grads = [torch.empty(shape, dtype=_F32, device=rois.device,
+                             memory_format=torch.channels_last if cl_fmt else torch.contiguous_format).zero_()
+                 for shape, cl_fmt in shapes]
+        st = _roi_levels(grads, scales, k_min, cs, cl)
+        R, Cc = rois.shape[0], shapes[0][0][1]
+        check(lib.hd_roi_pool_bwd(C.byref(st), _ptr(rois), R, Cc, P, _ptr(go), _ptr(arg), go.stride(0),
+                                  go.stride(1), go.stride(2), go.stride(3), _stream(rois)), "hd_roi_pool_bwd")
+        return (None,) * 7 + tuple(grads)
+
+
+def roi_pool(feats: Sequence[torch.Tensor], rois: torch.Tensor, P: int, scales: Sequence[float], k_min: int = 2,
+             canonical_scale: float = 224.0, canonical_level: int = 4, channels_last_out: bool = False,
+             return_argmax: bool = False):
+    """Quantised RoI max-pooling over pyramid levels (README.md:73 "-RoIPooling" variant).
+    feats: list of [B,C,H,W] float32 (channels-last is the fast layout); rois [R,5] -> [R,C,P,P]."""
+    out, arg = _RoIPoolFn.apply(rois, int(P), tuple(scales), int(k_min), float(canonical_scale),
+                                int(canonical_level), bool(channels_last_out), *feats)
+    return (out, arg) if return_argmax else out
+
+
 # ------------------------------------------------------------------------------- YOLOv5
 def _yolo_levels(preds: Sequence[torch.Tensor], strides: Sequence[float], anchors) -> YoloLevels:
     """preds: list of [B, na, H, W, no] views (any strides). anchors: [L][na][2] pixels."""

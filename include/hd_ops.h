@@ -178,6 +178,25 @@ hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, 
                            int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw,
                            hd_stream stream);
 
+/* ---- RoI max-pooling over pyramid levels (README.md:73 "FasterRCNN-FPNP2-RoIPooling") ---- */
+
+/* Quantised RoI max-pooling (the public RoIPool definition): the RoI corners are rounded to
+ * cells of its level (round half away from zero, x*spatial_scale), width/height = end-start+1
+ * (>= 1), bin (ph,pw) covers rows [floor(ph*bh), ceil((ph+1)*bh)) + start, clipped to the map;
+ * out = max over the bin (first maximum in row-major order wins; an empty bin gives 0),
+ * argmax = y*W + x of the winner inside its level's map, or -1 for an empty bin.
+ * out and argmax [R,C,P,P] share the element strides (out_sr,out_sc,out_sh,out_sw).
+ * The level of a RoI is hd_roi_level_map's. */
+hd_status hd_roi_pool_fwd(const hd_roi_levels* levels, const float* rois, int R, int C, int P,
+                          float* out, int32_t* argmax, int64_t out_sr, int64_t out_sc,
+                          int64_t out_sh, int64_t out_sw, hd_stream stream);
+
+/* Backward: grad_feat[level][b, c, argmax] += grad_out (float atomics; the caller zeroes the
+ * grad buffers given in grad_levels->feat[]). */
+hd_status hd_roi_pool_bwd(const hd_roi_levels* grad_levels, const float* rois, int R, int C,
+                          int P, const float* grad_out, const int32_t* argmax, int64_t out_sr,
+                          int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream);
+
 /* ---- YOLOv5 head ops (README.md:9) ----------------------------------------- */
 
 typedef struct hd_yolo_levels {

@@ -232,6 +232,31 @@ def roi_align_bwd(feat_shapes, rois, grad_out, scales, sampling_ratio=2, aligned
     return keep  # the (contiguous NCHW) gradient arrays
 
 
+def roi_pool_fwd(feats, rois, P, scales, k_min=2, canonical_scale=224.0, canonical_level=4, layout="nchw"):
+    """-> (out [R,C,P,P] f32, argmax [R,C,P,P] i32 = y*W+x inside the RoI's level, -1 for empty bins)."""
+    feats = [_f(f) for f in feats]
+    rois = _f(rois)
+    st, keep = _roi_levels(feats, scales, k_min, canonical_scale, canonical_level, layout)
+    R, Cc = rois.shape[0], feats[0].shape[1]
+    out = np.zeros((R, Cc, P, P), np.float32)
+    arg = np.full((R, Cc, P, P), -1, np.int32)
+    lib().orc_roi_pool_fwd(C.byref(st), _p(rois), C.c_int(R), C.c_int(Cc), C.c_int(P), _p(out), _p(arg),
+                           C.c_int64(Cc * P * P), C.c_int64(P * P), C.c_int64(P), C.c_int64(1))
+    del keep
+    return out, arg
+
+
+def roi_pool_bwd(feat_shapes, rois, grad_out, argmax, scales, k_min=2, canonical_scale=224.0, canonical_level=4):
+    grads = [np.zeros(s, np.float32) for s in feat_shapes]
+    rois, grad_out = _f(rois), _f(grad_out)
+    argmax = np.ascontiguousarray(argmax, np.int32)
+    st, keep = _roi_levels(grads, scales, k_min, canonical_scale, canonical_level, "nchw")
+    R, Cc, P = grad_out.shape[0], grad_out.shape[1], grad_out.shape[2]
+    lib().orc_roi_pool_bwd(C.byref(st), _p(rois), C.c_int(R), C.c_int(Cc), C.c_int(P), _p(grad_out), _p(argmax),
+                           C.c_int64(Cc * P * P), C.c_int64(P * P), C.c_int64(P), C.c_int64(1))
+    return keep
+
+
 # ---------------------------------------------------------------------------- YOLOv5
 def _yolo_levels(preds, strides, anchors):
     """preds: list of [B,na,H,W,no] float32 arrays (contiguous); anchors: [L,na,2] pixels."""

@@ -18,6 +18,7 @@
  *
  * All pointers are host pointers.  Plain serial loops; sizes the tests use finish in seconds.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -385,6 +386,82 @@ void orc_roi_align_fwd(const orc_roi_levels* lv, const float* rois, int R, int C
             }
           }
           out[r * out_sr + c * out_sc + ph * out_sh + pw * out_sw] = acc / g.count;
+        }
+  }
+}
+
+/* Quantised RoI max-pooling (README.md:73 "-RoIPooling" variant), the public RoIPool definition:
+ * corners rounded to cells (roundf: half away from zero), size = end - start + 1 (>= 1), bin rows
+ * [floor(ph*bh), ceil((ph+1)*bh)) + start clipped to the map, first maximum in row-major order,
+ * empty bin -> 0 with argmax -1.  argmax is y*W + x inside the RoI's level. */
+typedef struct { int start_w, start_h; float bin_w, bin_h; } pool_geom;
+
+static pool_geom pool_geometry(const float* roi, float scale, int P) {
+  pool_geom g;
+  g.start_w = (int)roundf(roi[1] * scale);
+  g.start_h = (int)roundf(roi[2] * scale);
+  int end_w = (int)roundf(roi[3] * scale), end_h = (int)roundf(roi[4] * scale);
+  int rw = end_w - g.start_w + 1, rh = end_h - g.start_h + 1;
+  if (rw < 1) rw = 1;
+  if (rh < 1) rh = 1;
+  g.bin_w = (float)rw / (float)P;
+  g.bin_h = (float)rh / (float)P;
+  return g;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_roi_pool_fwd(const orc_roi_levels* lv, const float* rois, int R, int C, int P, float* out,
+                      int32_t* argmax, int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw) {
+  for (int r = 0; r < R; ++r) {
+    const float* roi = rois + (int64_t)r * 5;
+    int l = roi_level(roi, lv->k_min, lv->n_levels, lv->canonical_scale, lv->canonical_level);
+    int bi = (int)roi[0];
+    int H = lv->h[l], W = lv->w[l];
+    pool_geom g = pool_geometry(roi, lv->spatial_scale[l], P);
+    const float* f = lv->feat[l] + (int64_t)bi * lv->sb[l];
+    for (int c = 0; c < C; ++c)
+      for (int ph = 0; ph < P; ++ph) {
+        int hs = clampi((int)floorf((float)ph * g.bin_h) + g.start_h, 0, H);
+        int he = clampi((int)ceilf((float)(ph + 1) * g.bin_h) + g.start_h, 0, H);
+        for (int pw = 0; pw < P; ++pw) {
+          int ws = clampi((int)floorf((float)pw * g.bin_w) + g.start_w, 0, W);
+          int we = clampi((int)ceilf((float)(pw + 1) * g.bin_w) + g.start_w, 0, W);
+          int empty = (he <= hs) || (we <= ws);
+          float best = empty ? 0.0f : -FLT_MAX;
+          int arg = -1;
+          const float* fc = f + (int64_t)c * lv->sc[l];
+          for (int y = hs; y < he; ++y)
+            for (int x = ws; x < we; ++x) {
+              float v = fc[y * lv->sh[l] + x * lv->sw[l]];
+              if (v > best) { best = v; arg = y * W + x; }
+            }
+          int64_t o = r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
+          out[o] = best;
+          argmax[o] = arg;
+        }
+      }
+  }
+}
+
+void orc_roi_pool_bwd(const orc_roi_levels* grad_lv, const float* rois, int R, int C, int P,
+                      const float* grad_out, const int32_t* argmax, int64_t out_sr, int64_t out_sc,
+                      int64_t out_sh, int64_t out_sw) {
+  for (int r = 0; r < R; ++r) {
+    const float* roi = rois + (int64_t)r * 5;
+    int l = roi_level(roi, grad_lv->k_min, grad_lv->n_levels, grad_lv->canonical_scale,
+                      grad_lv->canonical_level);
+    int bi = (int)roi[0];
+    int W = grad_lv->w[l];
+    float* f = (float*)grad_lv->feat[l] + (int64_t)bi * grad_lv->sb[l];
+    for (int c = 0; c < C; ++c)
+      for (int ph = 0; ph < P; ++ph)
+        for (int pw = 0; pw < P; ++pw) {
+          int64_t o = r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
+          int a = argmax[o];
+          if (a < 0) continue;
+          f[(int64_t)c * grad_lv->sc[l] + (int64_t)(a / W) * grad_lv->sh[l] + (int64_t)(a % W) * grad_lv->sw[l]] +=
+              grad_out[o];
         }
   }
 }

@@ -238,6 +238,45 @@ def roi_align(feats: List[torch.Tensor], rois: torch.Tensor, P: int, scales: Seq
     return torch.stack(out, 0)
 
 
+def _round_half_away(v: float) -> int:
+    return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+
+def roi_pool(feats: List[torch.Tensor], rois: torch.Tensor, P: int, scales: Sequence[float], k_min=2,
+             canonical_scale=224.0, canonical_level=4):
+    """Quantised RoI max-pooling (README.md:73 "-RoIPooling"): slices + amax, differentiable w.r.t. feats
+    (autograd routes the gradient to the first maximum of a slice only when maxima are unique)."""
+    lvl = roi_level_map(rois.detach(), k_min, len(feats), canonical_scale, canonical_level)
+    out = []
+    f32 = torch.float32
+    for r in range(rois.shape[0]):
+        l = int(lvl[r])
+        f = feats[l][int(rois[r, 0])]
+        Hh, Ww = f.shape[1], f.shape[2]
+        s = torch.tensor(scales[l], dtype=f32)
+        x1, y1, x2, y2 = [_round_half_away(float(rois[r, k].to(f32) * s)) for k in (1, 2, 3, 4)]
+        rw, rh = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1)
+        bw = torch.tensor(rw, dtype=f32) / torch.tensor(P, dtype=f32)
+        bh = torch.tensor(rh, dtype=f32) / torch.tensor(P, dtype=f32)
+        rows = []
+        for ph in range(P):
+            hs = min(max(int(torch.floor(torch.tensor(ph, dtype=f32) * bh)) + y1, 0), Hh)
+            he = min(max(int(torch.ceil(torch.tensor(ph + 1, dtype=f32) * bh)) + y1, 0), Hh)
+            cols = []
+            for pw in range(P):
+                ws = min(max(int(torch.floor(torch.tensor(pw, dtype=f32) * bw)) + x1, 0), Ww)
+                we = min(max(int(torch.ceil(torch.tensor(pw + 1, dtype=f32) * bw)) + x1, 0), Ww)
+                if he <= hs or we <= ws:
+                    cols.append(torch.zeros((f.shape[0],), dtype=f.dtype))
+                else:
+                    cols.append(f[:, hs:he, ws:we].amax(dim=(1, 2)))
+            rows.append(torch.stack(cols, 1))
+        out.append(torch.stack(rows, 1))
+    if not out:
+        return torch.zeros((0, feats[0].shape[1], P, P))
+    return torch.stack(out, 0)
+
+
 # ------------------------------------------------------------------------------- CIoU
 def ciou_xyxy(p: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     """CIoU of matched xyxy boxes (v6.1 bbox_iou form; alpha is detached)."""

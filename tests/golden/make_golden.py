@@ -81,7 +81,11 @@ def main():
     agree(ra, ra2, 1e-5, "roi_align")
     lv = co.roi_level_map(rr, 3, 3, 56.0, 4)
     agree(lv, tr.roi_level_map(torch.from_numpy(rr), 3, 3, 56.0, 4).numpy(), 0.0, "roi levels")
-    d.update(roi_f0=feats[0], roi_f1=feats[1], roi_f2=feats[2], roi_rois=rr, roi_out=ra, roi_levels=lv)
+    rp, rarg = co.roi_pool_fwd(feats, rr, 3, scales, 3, 56.0, 4)
+    rp2 = tr.roi_pool([torch.from_numpy(f) for f in feats], torch.from_numpy(rr), 3, scales, 3, 56.0, 4).numpy()
+    agree(rp, rp2, 0.0, "roi_pool")
+    d.update(roi_f0=feats[0], roi_f1=feats[1], roi_f2=feats[2], roi_rois=rr, roi_out=ra, roi_levels=lv,
+             roi_pool_out=rp, roi_pool_arg=rarg)
     # YOLOv5
     preds = [p.numpy() for p in H.yolo_preds(2, 64, 9, 8)]
     gtb, gtc, gmv = syn.make_targets(2, 64, syn.make_generator(9), "coco", 4, 12)

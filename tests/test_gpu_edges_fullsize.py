@@ -42,6 +42,7 @@ def test_empty_and_degenerate_inputs(gpu, ops):
     # RoIAlign with no RoIs, WBF with nothing above the skip threshold
     f = [torch.randn((1, 8, 16, 16), device=gpu)]
     assert ops.roi_align(f, torch.zeros((0, 5), device=gpu), 3, [1.0], 2, True, 2, 224.0, 4).shape == (0, 8, 3, 3)
+    assert ops.roi_pool(f, torch.zeros((0, 5), device=gpu), 3, [1.0], 2, 224.0, 4).shape == (0, 8, 3, 3)
     out, c = ops.wbf(b, torch.zeros((2, 5), device=gpu), torch.zeros((2, 5), dtype=torch.int32, device=gpu),
                      torch.ones((2, 5), device=gpu), None, 1.0, 0.5, 0.1)
     assert (c == 0).all() and float(out.abs().sum()) == 0.0

@@ -220,6 +220,43 @@ def test_roi_align_fwd_bwd(gpu, ops, layout, aligned, sr):
         assert H.rel_err(f.grad.cpu().numpy(), r) < TOL
 
 
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_roi_pool_fwd_bwd(gpu, ops, layout):
+    """README.md:73 "-RoIPooling" variant: values and argmax bit-exact, backward = scatter to argmax."""
+    strides = [4, 8, 16, 32]
+    feats, rois = _roi_case(61, 2, 48, 256, 60, strides)
+    scales = [1.0 / s for s in strides]
+    fd = [dev(f, gpu) for f in feats]
+    if layout == "nhwc":
+        fd = [f.contiguous(memory_format=torch.channels_last) for f in fd]
+    fd = [f.requires_grad_(True) for f in fd]
+    out, arg = ops.roi_pool(fd, dev(rois, gpu), 7, scales, 2, 224.0 / 4, 4, channels_last_out=(layout == "nhwc"),
+                            return_argmax=True)
+    ref, rarg = co.roi_pool_fwd([f.numpy() for f in feats], rois.numpy(), 7, scales, 2, 224.0 / 4, 4)
+    assert np.array_equal(out.detach().cpu().numpy(), ref)
+    assert np.array_equal(arg.cpu().numpy(), rarg)
+    assert (rarg >= 0).mean() > 0.9
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(62))
+    out.backward(dev(go, gpu))
+    rg = co.roi_pool_bwd([tuple(f.shape) for f in feats], rois.numpy(), go.numpy(), rarg, scales, 2, 224.0 / 4, 4)
+    for f, r in zip(fd, rg):
+        assert H.rel_err(f.grad.cpu().numpy(), r) < TOL  # atomic summation order differs
+
+
+def test_roi_pool_single_level_quantisation_edges(gpu, ops):
+    """RoIs off the map, inverted, sub-cell and with .5 corners, on one stride-1 level."""
+    g = torch.Generator().manual_seed(63)
+    f = torch.randn((2, 16, 20, 24), generator=g)
+    rois = torch.tensor([[0, 2.5, 2.5, 2.5, 2.5], [1, 20.0, 14.0, 60.0, 50.0], [0, 40.0, 40.0, 50.0, 50.0],
+                         [1, 9.0, 9.0, 4.0, 4.0], [0, -6.0, -3.0, 5.5, 4.5], [1, 0.0, 0.0, 23.0, 19.0],
+                         [0, 3.49, 7.51, 3.51, 7.49]])
+    for P in (1, 3, 7):
+        out, arg = ops.roi_pool([dev(f, gpu)], dev(rois, gpu), P, [1.0], 2, 224.0, 4, return_argmax=True)
+        ref, rarg = co.roi_pool_fwd([f.numpy()], rois.numpy(), P, [1.0], 2, 224.0, 4)
+        assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(arg.cpu().numpy(), rarg)
+    assert (rarg[2] == -1).all()
+
+
 # ------------------------------------------------------------------------------- YOLOv5
 @pytest.mark.parametrize("no,size,B", [(85, 128, 2), (9, 96, 3)])
 def test_yolo_decode(gpu, ops, no, size, B):

@@ -62,6 +62,42 @@ def test_golden_roi_align(gold):
     assert np.array_equal(out, out2)
 
 
+def test_golden_roi_pool(gold):
+    feats = [gold["roi_f0"], gold["roi_f1"], gold["roi_f2"]]
+    out, arg = co.roi_pool_fwd(feats, gold["roi_rois"], 3, [1 / 8, 1 / 16, 1 / 32], 3, 56.0, 4)
+    assert np.array_equal(out, gold["roi_pool_out"]) and np.array_equal(arg, gold["roi_pool_arg"])
+    out2, arg2 = co.roi_pool_fwd(feats, gold["roi_rois"], 3, [1 / 8, 1 / 16, 1 / 32], 3, 56.0, 4, layout="nhwc")
+    assert np.array_equal(out, out2) and np.array_equal(arg, arg2)
+
+
+def test_roi_pool_known_answers():
+    # ramp feature f[y, x] = 16*y + x: the maximum of a bin is its bottom-right cell
+    f = (np.arange(16, dtype=np.float32)[:, None] * 16 + np.arange(16, dtype=np.float32)[None, :])[None, None]
+    rois = np.array([[0, 2.0, 3.0, 9.0, 8.0]], np.float32)  # cells x 2..9 (8 wide), y 3..8 (6 high)
+    out, arg = co.roi_pool_fwd([f], rois, 2, [1.0], 2, 224.0, 4)
+    # bins: x [2,6) [6,10), y [3,6) [6,9)
+    assert np.array_equal(out[0, 0], np.array([[5 * 16 + 5, 5 * 16 + 9], [8 * 16 + 5, 8 * 16 + 9]], np.float32))
+    assert np.array_equal(arg[0, 0], out[0, 0].astype(np.int32))  # value == flat index on this ramp
+    # rounding is half away from zero: 2.5 -> 3, and a RoI hanging off the map is clipped; a RoI entirely
+    # outside gives empty bins (0, argmax -1); an inverted RoI is forced to 1x1
+    rois = np.array([[0, 2.5, 2.5, 2.5, 2.5], [0, 14.0, 14.0, 40.0, 40.0], [0, 30.0, 30.0, 40.0, 40.0],
+                     [0, 9.0, 9.0, 4.0, 4.0]], np.float32)
+    out, arg = co.roi_pool_fwd([f], rois, 1, [1.0], 2, 224.0, 4)
+    assert out[0, 0, 0, 0] == 3 * 16 + 3 and arg[0, 0, 0, 0] == 3 * 16 + 3
+    assert out[1, 0, 0, 0] == 15 * 16 + 15
+    assert out[2, 0, 0, 0] == 0.0 and arg[2, 0, 0, 0] == -1
+    assert out[3, 0, 0, 0] == 9 * 16 + 9
+    # ties: the first maximum in row-major order wins
+    c = np.zeros((1, 1, 8, 8), np.float32)
+    out, arg = co.roi_pool_fwd([c], np.array([[0, 1.0, 2.0, 5.0, 6.0]], np.float32), 1, [1.0], 2, 224.0, 4)
+    assert out[0, 0, 0, 0] == 0.0 and arg[0, 0, 0, 0] == 2 * 8 + 1
+    # backward routes every output gradient to its argmax cell (and nowhere for empty bins)
+    g = np.ones((3, 1, 1, 1), np.float32)
+    a3 = np.array([3 * 16 + 3, 3 * 16 + 3, -1], np.int32).reshape(3, 1, 1, 1)
+    gf = co.roi_pool_bwd([(1, 1, 16, 16)], rois[[0, 0, 2]], g, a3, [1.0], 2, 224.0, 4)[0]
+    assert gf[0, 0, 3, 3] == 2.0 and gf.sum() == 2.0
+
+
 def test_golden_yolo(gold):
     preds = [gold["y_p0"], gold["y_p1"], gold["y_p2"]]
     assert np.array_equal(co.yolo_decode(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS), gold["y_dec"])
