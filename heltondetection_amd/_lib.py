@@ -58,6 +58,9 @@ class YoloLossCfg(C.Structure):
         ("obj_gain", C.c_float),
         ("cls_gain", C.c_float),
         ("balance", C.c_float * MAX_LEVELS),
+        ("focal_gamma", C.c_float),
+        ("focal_alpha", C.c_float),
+        ("focal_terms", C.c_int),
     ]
 
 

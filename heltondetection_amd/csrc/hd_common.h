@@ -51,6 +51,21 @@ __device__ __forceinline__ float hd_bce_logits(float x, float z) {
   return fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
 }
 
+// Focal-modulated BCE-with-logits and its derivative w.r.t. the logit (z may be a soft target):
+//   L = af * m * bce,  m = q^gamma, q = 1 - p_t, p_t = z p + (1-z)(1-p), af = z a + (1-z)(1-a) (1 if a <= 0)
+//   dL/dx = af * (m (p - z) + bce * dm/dx),  dm/dx = -gamma q^(gamma-1) (2z - 1) p (1 - p)
+// q^(gamma-1) is formed as m / q and dropped at q == 0, where bce * q^(gamma-1) -> 0 for every gamma > 0.
+__device__ __forceinline__ float hd_focal_bce(float x, float z, float gamma, float alpha, float* dldx) {
+  const float p = hd_sigmoid(x);
+  const float bce = hd_bce_logits(x, z);
+  const float q = 1.0f - (z * p + (1.0f - z) * (1.0f - p));
+  const float af = alpha > 0.0f ? z * alpha + (1.0f - z) * (1.0f - alpha) : 1.0f;
+  const float m = powf(q, gamma);
+  const float dm = q > 0.0f ? -gamma * (m / q) * ((2.0f * z - 1.0f) * (p * (1.0f - p))) : 0.0f;
+  *dldx = af * (m * (p - z) + bce * dm);
+  return af * (m * bce);
+}
+
 // order-preserving float -> uint32 (larger float -> larger key)
 __device__ __forceinline__ uint32_t hd_f2key(float f) {
   uint32_t u = __float_as_uint(f);

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
   const int wave = threadIdx.x >> 6;
   const int no = lv.no, nc = lv.no - 5, na = lv.na;
   const bool do_bias = BWD && grad_bias != nullptr;
+  const bool focal_cls = cfg.focal_gamma > 0.0f && (cfg.focal_terms & 1);
   if (do_bias) {
     for (int i = threadIdx.x; i < na * no; i += blockDim.x) s_gb[i] = 0.0f;
     __syncthreads();
@@ -444,8 +445,15 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
     if (!BWD) {
       const float ci = hd_ciou<false>(pb, tx, nullptr);
       float csum = 0.0f;
-      if (nc > 1)
-        for (int c = lane; c < nc; c += 64) csum += hd_bce_logits(p[(5 + c) * so], c == tc ? 1.0f : 0.0f);
+      if (nc > 1) {
+        if (focal_cls) {
+          float unused;
+          for (int c = lane; c < nc; c += 64)
+            csum += hd_focal_bce(p[(5 + c) * so], c == tc ? 1.0f : 0.0f, cfg.focal_gamma, cfg.focal_alpha, &unused);
+        } else {
+          for (int c = lane; c < nc; c += 64) csum += hd_bce_logits(p[(5 + c) * so], c == tc ? 1.0f : 0.0f);
+        }
+      }
       csum = hd_wave_sum(csum);
       sum_box += 1.0f - ci;
       sum_cls += csum;
@@ -473,7 +481,10 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
       }
       if (nc > 1)
         for (int c = lane; c < nc; c += 64) {
-          const float v = gcls * (hd_sigmoid(p[(5 + c) * so]) - (c == tc ? 1.0f : 0.0f));
+          float d;
+          if (focal_cls) hd_focal_bce(p[(5 + c) * so], c == tc ? 1.0f : 0.0f, cfg.focal_gamma, cfg.focal_alpha, &d);
+          else d = hd_sigmoid(p[(5 + c) * so]) - (c == tc ? 1.0f : 0.0f);
+          const float v = gcls * d;
           atomicAdd(g + (5 + c) * gso, v);
           if (do_bias) atomicAdd(&s_gb[cp.a * no + 5 + c], v);
         }
@@ -503,31 +514,38 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
 }
 
 // objectness BCE over every cell of one level; grid (blocks, n_levels)
-// It also overwrites tobj[m] with the objectness residual sigmoid(x) - tobj[m]: backward then needs
+// It also overwrites tobj[m] with d(term)/d(logit) (sigmoid(x) - tobj[m] for plain BCE): backward then needs
 // only that linear array (4 B per cell) instead of re-gathering the logits at a 4*no-byte stride
 // (PMC: the gather fetched 28 MB raw / 56 MB corrected per launch for 3.2 MB of useful bytes).
 __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels lv, const LevelIndex ix,
-                                                           const LevelFlags fl, int B, float* __restrict__ tobj,
-                                                           float* __restrict__ acc) {
+                                                           const LevelFlags fl, int B, const hd_yolo_loss_cfg cfg,
+                                                           float* __restrict__ tobj, float* __restrict__ acc) {
   __shared__ float s_part[4];
   const int l = blockIdx.y;
   const int cells = (int)(ix.first_cell[l + 1] - ix.first_cell[l]);
   float* to = tobj + ix.first_cell[l];
   const float* pr = lv.pred[l];
   float sum = 0.0f;
+  const bool focal_obj = cfg.focal_gamma > 0.0f && (cfg.focal_terms & 2);
+  // d(loss term)/d(logit) replaces the target in place: sigmoid(x) - t, or the focal derivative
+  auto term = [&](float x, float t, float* d) -> float {
+    if (focal_obj) return hd_focal_bce(x, t, cfg.focal_gamma, cfg.focal_alpha, d);
+    *d = hd_sigmoid(x) - t;
+    return hd_bce_logits(x, t);
+  };
   if (fl.pred_dense[l]) {
     const int no = lv.no;
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < cells; m += gridDim.x * blockDim.x) {
-      const float x = pr[(long long)m * no + 4], t = to[m];
-      sum += hd_bce_logits(x, t);
-      to[m] = hd_sigmoid(x) - t;
+      float d;
+      sum += term(pr[(long long)m * no + 4], to[m], &d);
+      to[m] = d;
     }
   } else {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += gridDim.x * blockDim.x) {
       const CellPos cp = cell_decompose(lv, l, c);
-      const float x = pr[cell_offset(lv, l, cp) + 4 * lv.so[l]], t = to[c];
-      sum += hd_bce_logits(x, t);
-      to[c] = hd_sigmoid(x) - t;
+      float d;
+      sum += term(pr[cell_offset(lv, l, cp) + 4 * lv.so[l]], to[c], &d);
+      to[c] = d;
     }
   }
   sum = hd_wave_sum(sum);
@@ -789,7 +807,7 @@ extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, co
   long long max_cells = 0;
   for (int l = 0; l < lv->n_levels; ++l) max_cells = std::max(max_cells, ix.first_cell[l + 1] - ix.first_cell[l]);
   dim3 ogrid(cap_grid(max_cells, 256 * 2), (unsigned)lv->n_levels);
-  hipLaunchKernelGGL(yolo_obj_fwd_kernel, ogrid, dim3(256), 0, s, *lv, ix, fl, B, tobj, acc);
+  hipLaunchKernelGGL(yolo_obj_fwd_kernel, ogrid, dim3(256), 0, s, *lv, ix, fl, B, *cfg, tobj, acc);
   HD_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, s, *lv, ix, B, *cfg, acc, loss_out);
   HD_RETURN_IF_LAUNCH_FAILED();

@@ -27,8 +27,12 @@ class YOLOv5Head(nn.Module):
 
     def __init__(self, in_channels: Sequence[int], num_classes: int = 80, anchors=YOLOV5_ANCHORS,
                  strides: Sequence[int] = (8, 16, 32), assigner=None, box_gain: float = 0.05, obj_gain: float = 1.0,
-                 cls_gain: float = 0.5, balance: Sequence[float] = (4.0, 1.0, 0.4), img_size: int = 640):
+                 cls_gain: float = 0.5, balance: Sequence[float] = (4.0, 1.0, 0.4), img_size: int = 640,
+                 focal: Optional[dict] = None):
         super().__init__()
+        # focal: dict(gamma=1.5, alpha=0.25, terms=("cls", "obj")) — the "YOLOv5s-focalloss(...)" rows of
+        # README.md:118-154; which BCE terms it wraps is the `terms` subset (e.g. ("cls",) only)
+        self.focal = dict(focal) if focal else None
         self.nc, self.no = int(num_classes), int(num_classes) + 5
         self.anchors = tuple(tuple(tuple(float(v) for v in a) for a in lv) for lv in anchors)
         self.na, self.nl = len(self.anchors[0]), len(self.anchors)
@@ -68,7 +72,7 @@ class YOLOv5Head(nn.Module):
         slots = self.assigner(shapes, self.strides, self.anchors, gt_boxes, gt_cls, m_valid)
         biases = [c.bias for c in self.m] if (self.training and self.bias_grad_in_loss) else None
         return ops.yolo_loss(preds, self.strides, self.anchors, slots, gt_cls.shape[1], self.box_gain, self.obj_gain,
-                             self.cls_gain, self.balance, biases=biases)
+                             self.cls_gain, self.balance, biases=biases, focal=self.focal)
 
     @torch.no_grad()
     def predict(self, preds, conf_thr=0.25, iou_thr=0.45, max_nms=30000, max_det=300):

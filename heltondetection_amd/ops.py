@@ -388,11 +388,29 @@ def yolo_assign(shapes: Sequence[Tuple[int, int, int, int]], strides, anchors, g
     return cell, tbox, cls
 
 
-def _loss_cfg(box_gain, obj_gain, cls_gain, balance) -> YoloLossCfg:
+_FOCAL_TERM_BITS = {"cls": 1, "obj": 2}
+
+
+def _focal_tuple(focal):
+    """None | dict(gamma=, alpha=, terms=) | (gamma, alpha, terms) -> hashable (gamma, alpha, bits) or None."""
+    if focal is None:
+        return None
+    if isinstance(focal, dict):
+        focal = (focal.get("gamma", 1.5), focal.get("alpha", 0.25), focal.get("terms", ("cls", "obj")))
+    gamma, alpha, terms = focal
+    bits = terms if isinstance(terms, int) else sum(_FOCAL_TERM_BITS[t] for t in terms)
+    if float(gamma) <= 0.0 or bits == 0:
+        return None
+    return (float(gamma), float(alpha), int(bits))
+
+
+def _loss_cfg(box_gain, obj_gain, cls_gain, balance, focal=None) -> YoloLossCfg:
     cfg = YoloLossCfg()
     cfg.box_gain, cfg.obj_gain, cfg.cls_gain = float(box_gain), float(obj_gain), float(cls_gain)
     for l, v in enumerate(balance):
         cfg.balance[l] = float(v)
+    if focal is not None:
+        cfg.focal_gamma, cfg.focal_alpha, cfg.focal_terms = focal
     return cfg
 
 
@@ -409,7 +427,7 @@ class _YoloLossFn(torch.autograd.Function):
         st = _yolo_levels(preds_d, strides, anchors)
         B = preds[0].shape[0]
         slot_cell, slot_tbox, slot_cls = slots
-        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
+        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance, gains[3] if len(gains) > 3 else None)
         dev = preds[0].device
         out = torch.empty((4,), dtype=_F32, device=dev)
         ws, wsb = _ws(lib.hd_yolo_loss_workspace_bytes(C.byref(st), B), dev)
@@ -432,7 +450,7 @@ class _YoloLossFn(torch.autograd.Function):
         grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=p.device) for p in preds]
         gst = _yolo_levels(grads, strides, anchors)
         B = preds[0].shape[0]
-        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
+        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance, gains[3] if len(gains) > 3 else None)
         gs = grad_total.detach().to(_F32).reshape(1).contiguous()
         gbias = None
         if bias_meta:
@@ -449,15 +467,19 @@ class _YoloLossFn(torch.autograd.Function):
 
 def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, box_gain: float = 0.05,
               obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4),
-              biases: Optional[Sequence[torch.Tensor]] = None):
+              biases: Optional[Sequence[torch.Tensor]] = None, focal=None):
     """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached).
+
+    ``focal``: None, or dict(gamma=1.5, alpha=0.25, terms=("cls", "obj")) / the same as a tuple — the
+    "focalloss" variants of README.md:118-154 (alpha <= 0 drops the class-balance factor).
 
     ``biases``: optionally the per-level Detect-conv bias parameters ([na*no] each) whose values are
     already folded into ``preds`` (the conv ran with ``bias.detach()``); their gradients are then
     produced by the loss kernels."""
     biases = tuple(biases) if biases is not None else ()
     return _YoloLossFn.apply(tuple(strides), tuple(tuple(tuple(a) for a in lv) for lv in anchors), slots, int(M),
-                             (box_gain, obj_gain, cls_gain), tuple(balance), len(preds), *preds, *biases)
+                             (box_gain, obj_gain, cls_gain, _focal_tuple(focal)), tuple(balance), len(preds), *preds,
+                             *biases)
 
 
 def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,

@@ -233,6 +233,12 @@ hd_status hd_yolo_assign(const hd_yolo_levels* lv, const float* gt_boxes, const 
 typedef struct hd_yolo_loss_cfg {
   float box_gain, obj_gain, cls_gain; /* hyp.box, hyp.obj, hyp.cls (already rescaled)        */
   float balance[HD_MAX_LEVELS];       /* objectness weight per level                         */
+  /* Focal variant of the BCE terms ("YOLOv5s-focalloss" rows, README.md:118-154), the public
+   * FocalLoss-over-BCEWithLogits form:  bce * (1 - p_t)^gamma * (z*alpha + (1-z)*(1-alpha)),
+   * p_t = z*p + (1-z)*(1-p), p = sigmoid(x), z the (possibly soft) target. */
+  float focal_gamma;                  /* <= 0: plain BCE everywhere                          */
+  float focal_alpha;                  /* <= 0: no class-balance factor                       */
+  int focal_terms;                    /* bit 0: classification term, bit 1: objectness term  */
 } hd_yolo_loss_cfg;
 
 /* Loss forward.  tobj [sum_l B*na*H_l*W_l] scratch (objectness targets, level-major),

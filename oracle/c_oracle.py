@@ -77,6 +77,9 @@ class YoloLossCfg(C.Structure):
         ("obj_gain", C.c_float),
         ("cls_gain", C.c_float),
         ("balance", C.c_float * MAX_LEVELS),
+        ("focal_gamma", C.c_float),
+        ("focal_alpha", C.c_float),
+        ("focal_terms", C.c_int),
     ]
 
 
@@ -304,24 +307,31 @@ def yolo_assign(shapes, strides, anchors, gt_boxes, gt_cls, m_valid, anchor_t=4.
     return cell, tbox, cls
 
 
-def _loss_cfg(box_gain, obj_gain, cls_gain, balance):
+FOCAL_TERM_BITS = {"cls": 1, "obj": 2}
+
+
+def _loss_cfg(box_gain, obj_gain, cls_gain, balance, focal=None):
+    """focal: None or (gamma, alpha, terms) with terms a subset of ("cls", "obj")."""
     cfg = YoloLossCfg()
     cfg.box_gain, cfg.obj_gain, cfg.cls_gain = box_gain, obj_gain, cls_gain
     for l, b in enumerate(balance):
         cfg.balance[l] = b
+    if focal is not None:
+        cfg.focal_gamma, cfg.focal_alpha = float(focal[0]), float(focal[1])
+        cfg.focal_terms = sum(FOCAL_TERM_BITS[t] for t in focal[2])
     return cfg
 
 
 def yolo_loss(preds, strides, anchors, slot_cell, slot_tbox, slot_cls, M, box_gain=0.05, obj_gain=1.0,
-              cls_gain=0.5, balance=(4.0, 1.0, 0.4), grad_scale=1.0, want_grad=True):
-    """Returns loss[4], grads (list of [B,na,H,W,no]) or None."""
+              cls_gain=0.5, balance=(4.0, 1.0, 0.4), grad_scale=1.0, want_grad=True, focal=None):
+    """Returns loss[4], grads (list of [B,na,H,W,no]) or None.  focal = (gamma, alpha, terms) or None."""
     st, keep = _yolo_levels(preds, strides, anchors)
     B = keep[0].shape[0]
     cells = sum(p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3] for p in keep)
     tobj = np.zeros((cells,), np.float32)
     acc = np.zeros((len(keep) * 4,), np.float32)
     loss = np.zeros((4,), np.float32)
-    cfg = _loss_cfg(box_gain, obj_gain, cls_gain, balance)
+    cfg = _loss_cfg(box_gain, obj_gain, cls_gain, balance, focal)
     sc, tb, scl = _i(slot_cell), _f(slot_tbox), _i(slot_cls)
     lib().orc_yolo_loss_fwd(C.byref(st), C.c_int(B), C.c_int(M), _p(sc), _p(tb), _p(scl), C.byref(cfg), _p(loss), _p(tobj), _p(acc))
     grads = None

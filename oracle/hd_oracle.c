@@ -517,7 +517,25 @@ typedef struct orc_yolo_levels {
 typedef struct orc_yolo_loss_cfg {
   float box_gain, obj_gain, cls_gain;
   float balance[ORC_MAX_LEVELS];
+  float focal_gamma;  /* <= 0: plain BCE */
+  float focal_alpha;  /* <= 0: no class-balance factor */
+  int focal_terms;    /* bit 0: classification, bit 1: objectness */
 } orc_yolo_loss_cfg;
+
+/* Focal-modulated BCE-with-logits ("focalloss" rows, README.md:118-154; the public
+ * FocalLoss-over-BCEWithLogits form) and its derivative w.r.t. the logit:
+ *   L = af * q^gamma * bce, q = 1 - p_t, p_t = z p + (1-z)(1-p), af = z a + (1-z)(1-a)
+ *   dL/dx = af * (q^gamma (p - z) + bce * dq^gamma/dx), dq^gamma/dx = -gamma q^(gamma-1) (2z-1) p (1-p) */
+static float focal_bce(float x, float z, float gamma, float alpha, float* dldx) {
+  float p = sigmoidf_(x);
+  float bce = bce_logits(x, z);
+  float q = 1.0f - (z * p + (1.0f - z) * (1.0f - p));
+  float af = alpha > 0.0f ? z * alpha + (1.0f - z) * (1.0f - alpha) : 1.0f;
+  float m = powf(q, gamma);
+  float dm = q > 0.0f ? -gamma * (m / q) * ((2.0f * z - 1.0f) * (p * (1.0f - p))) : 0.0f;
+  if (dldx) *dldx = af * (m * (p - z) + bce * dm);
+  return af * (m * bce);
+}
 
 /* v6.1 decode; rows ordered level, anchor, y, x */
 void orc_yolo_decode(const orc_yolo_levels* lv, int B, float* out) {
@@ -685,6 +703,8 @@ void orc_yolo_loss_fwd(const orc_yolo_levels* lv, int B, int M, const int32_t* s
                        const float* slot_tbox, const int32_t* slot_cls,
                        const orc_yolo_loss_cfg* cfg, float* loss_out, float* tobj, float* acc) {
   const int nc = lv->no - 5;
+  const int focal_cls = cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1);
+  const int focal_obj = cfg->focal_gamma > 0.0f && (cfg->focal_terms & 2);
   const int64_t S = (int64_t)5 * lv->na * B * M;
   int64_t toff = 0;
   double lbox = 0.0, lobj = 0.0, lcls = 0.0;
@@ -709,13 +729,17 @@ void orc_yolo_loss_fwd(const orc_yolo_levels* lv, int B, int M, const int32_t* s
       if (cl > to[cell]) to[cell] = cl;
       int32_t tc = slot_cls[(int64_t)l * S + s];
       if (nc > 1)
-        for (int c = 0; c < nc; ++c) sc += (double)bce_logits(p[(5 + c) * lv->so[l]], c == tc ? 1.0f : 0.0f);
+        for (int c = 0; c < nc; ++c) {
+          float x = p[(5 + c) * lv->so[l]], z = c == tc ? 1.0f : 0.0f;
+          sc += (double)(focal_cls ? focal_bce(x, z, cfg->focal_gamma, cfg->focal_alpha, NULL) : bce_logits(x, z));
+        }
     }
     /* objectness over all cells */
     int H = lv->h[l], W = lv->w[l];
     for (int64_t cell = 0; cell < cells; ++cell) {
       int a; const float* p = yolo_cell_ptr(lv, l, (int32_t)cell, &a);
-      so_ += (double)bce_logits(p[4 * lv->so[l]], to[cell]);
+      so_ += (double)(focal_obj ? focal_bce(p[4 * lv->so[l]], to[cell], cfg->focal_gamma, cfg->focal_alpha, NULL)
+                                : bce_logits(p[4 * lv->so[l]], to[cell]));
     }
     (void)H; (void)W;
     acc[l * 4 + 0] = (float)sb; acc[l * 4 + 1] = (float)n; acc[l * 4 + 2] = (float)sc; acc[l * 4 + 3] = (float)so_;
@@ -737,6 +761,8 @@ void orc_yolo_loss_bwd(const orc_yolo_levels* lv, const orc_yolo_levels* glv, in
                        const orc_yolo_loss_cfg* cfg, float grad_scale, const float* tobj,
                        const float* acc) {
   const int nc = lv->no - 5;
+  const int focal_cls = cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1);
+  const int focal_obj = cfg->focal_gamma > 0.0f && (cfg->focal_terms & 2);
   const int64_t S = (int64_t)5 * lv->na * B * M;
   int64_t toff = 0;
   for (int l = 0; l < lv->n_levels; ++l) {
@@ -750,7 +776,10 @@ void orc_yolo_loss_bwd(const orc_yolo_levels* lv, const orc_yolo_levels* glv, in
       int a; const float* p = yolo_cell_ptr(lv, l, (int32_t)cell, &a);
       float* g = (float*)yolo_cell_ptr(glv, l, (int32_t)cell, &a);
       for (int c = 0; c < lv->no; ++c) g[c * glv->so[l]] = 0.0f;
-      g[4 * glv->so[l]] = gobj * (sigmoidf_(p[4 * lv->so[l]]) - to[cell]);
+      float d;
+      if (focal_obj) focal_bce(p[4 * lv->so[l]], to[cell], cfg->focal_gamma, cfg->focal_alpha, &d);
+      else d = sigmoidf_(p[4 * lv->so[l]]) - to[cell];
+      g[4 * glv->so[l]] = gobj * d;
     }
     if (n > 0.0f) {
       float gbox = grad_scale * (float)B * cfg->box_gain / n;
@@ -775,8 +804,12 @@ void orc_yolo_loss_bwd(const orc_yolo_levels* lv, const orc_yolo_levels* glv, in
         g[3 * glv->so[l]] += gbox * gph * 8.0f * sg[3] * sg[3] * (1.0f - sg[3]) * ah;
         int32_t tc = slot_cls[(int64_t)l * S + s];
         if (nc > 1)
-          for (int c = 0; c < nc; ++c)
-            g[(5 + c) * glv->so[l]] += gcls * (sigmoidf_(p[(5 + c) * lv->so[l]]) - (c == tc ? 1.0f : 0.0f));
+          for (int c = 0; c < nc; ++c) {
+            float x = p[(5 + c) * lv->so[l]], z = c == tc ? 1.0f : 0.0f, d;
+            if (focal_cls) focal_bce(x, z, cfg->focal_gamma, cfg->focal_alpha, &d);
+            else d = sigmoidf_(x) - z;
+            g[(5 + c) * glv->so[l]] += gcls * d;
+          }
       }
     }
     toff += cells;

@@ -346,9 +346,30 @@ def yolo_build_targets(shapes, strides, anchors, gt_boxes, gt_cls, m_valid, anch
     return res
 
 
+def focal_bce_mean(logits, target, gamma, alpha):
+    """FocalLoss over BCEWithLogits (the public ultralytics form), mean reduction."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, target, reduction="none")
+    p = torch.sigmoid(logits)
+    p_t = target * p + (1 - target) * (1 - p)
+    mod = (1.0 - p_t) ** gamma
+    af = target * alpha + (1 - target) * (1 - alpha) if alpha > 0 else 1.0
+    return (bce * af * mod).mean()
+
+
 def yolo_loss(preds, strides, anchors, gt_boxes, gt_cls, m_valid, anchor_t=4.0, box_gain=0.05, obj_gain=1.0,
-              cls_gain=0.5, balance=(4.0, 1.0, 0.4)):
-    """v6.1 ComputeLoss form (gr=1, no label smoothing, duplicates -> max). Returns (total, lbox, lobj, lcls)."""
+              cls_gain=0.5, balance=(4.0, 1.0, 0.4), focal=None):
+    """v6.1 ComputeLoss form (gr=1, no label smoothing, duplicates -> max). Returns (total, lbox, lobj, lcls).
+    focal = (gamma, alpha, terms) wraps the BCE terms named in `terms` ("cls", "obj")."""
+    def bce_cls(x, t):
+        if focal is not None and "cls" in focal[2]:
+            return focal_bce_mean(x, t, focal[0], focal[1])
+        return torch.nn.functional.binary_cross_entropy_with_logits(x, t)
+
+    def bce_obj(x, t):
+        if focal is not None and "obj" in focal[2]:
+            return focal_bce_mean(x, t, focal[0], focal[1])
+        return torch.nn.functional.binary_cross_entropy_with_logits(x, t)
+
     shapes = [tuple(p.shape[1:]) for p in preds]
     B = preds[0].shape[0]
     tg = yolo_build_targets(shapes, strides, anchors, gt_boxes, gt_cls, m_valid, anchor_t)
@@ -374,8 +395,8 @@ def yolo_loss(preds, strides, anchors, gt_boxes, gt_cls, m_valid, anchor_t=4.0, 
             if nc > 1:
                 t = torch.zeros_like(ps[:, 5:])
                 t[torch.arange(n), tcls] = 1.0
-                lcls = lcls + torch.nn.functional.binary_cross_entropy_with_logits(ps[:, 5:], t)
-        lobj = lobj + torch.nn.functional.binary_cross_entropy_with_logits(p[..., 4], tobj) * balance[l]
+                lcls = lcls + bce_cls(ps[:, 5:], t)
+        lobj = lobj + bce_obj(p[..., 4], tobj) * balance[l]
     lbox, lobj, lcls = lbox * box_gain, lobj * obj_gain, lcls * cls_gain
     return (lbox + lobj + lcls) * B, lbox.detach(), lobj.detach(), lcls.detach()
 

@@ -101,6 +101,15 @@ def main():
     agree(loss, np.array([float(x) for x in lt], np.float32), 1e-5, "yolo loss")
     for gg, p in zip(grads, pt):
         agree(gg, p.grad.numpy(), 1e-4, "yolo grad")
+    fl_loss, fl_grads, _, _ = co.yolo_loss(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, scls, 12,
+                                           focal=(1.5, 0.25, ("cls", "obj")))
+    pf = [torch.from_numpy(p).requires_grad_(True) for p in preds]
+    lf = tr.yolo_loss(pf, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb, gtc, gmv, focal=(1.5, 0.25, ("cls", "obj")))
+    lf[0].backward()
+    agree(fl_loss, np.array([float(x.detach()) for x in lf], np.float32), 1e-5, "focal yolo loss")
+    for gg, p in zip(fl_grads, pf):
+        agree(gg, p.grad.numpy(), 1e-4, "focal yolo grad")
+    d.update(y_focal_loss=fl_loss, y_focal_g0=fl_grads[0], y_focal_g2=fl_grads[2])
     det, dcnt = co.yolo_nms(dec, 0.3, 0.45, 500, 20)
     d2, c2 = tr.yolo_nms(torch.from_numpy(dec), 0.3, 0.45, 500, 20)
     agree(det, d2.numpy(), 0.0, "yolo nms"); agree(dcnt, c2.numpy(), 0.0, "yolo nms count")

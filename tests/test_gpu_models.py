@@ -14,11 +14,18 @@ def _batch(B, size, nc, seed, gpu, m_pad=24):
     return img, gtb.to(gpu), gtc.to(gpu), mv.to(gpu)
 
 
-def test_yolov5s_overfits_one_batch_and_detects(gpu):
+@pytest.mark.parametrize("focal", [None, dict(gamma=1.5, alpha=0.25, terms=("cls", "obj")),
+                                   dict(gamma=0.5, alpha=-1.0, terms=("cls",))])
+def test_yolov5s_overfits_one_batch_and_detects(gpu, focal):
+    """focal: the "YOLOv5s-focalloss(root / root_cls)"-style heads of README.md:118-154."""
     from heltondetection_amd.detectors import build_detector
     from heltondetection_amd.train import Trainer
     torch.manual_seed(0)
-    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160)).to(gpu)
+    cfg = dict(type="YOLOv5", variant="s", num_classes=8, img_size=160)
+    if focal is not None:
+        cfg["head"] = dict(type="YOLOv5Head", num_classes=8, img_size=160, focal=focal)
+    model = build_detector(cfg).to(gpu)
+    assert model.head.focal == focal
     model = model.to(memory_format=torch.channels_last).train()
     tr = Trainer(model, lr=2e-3, total_steps=60, warmup_steps=3, device=gpu)
     batch = _batch(4, 160, 8, 3, gpu, m_pad=8)

@@ -300,8 +300,15 @@ def test_yolo_assign_bit_exact(gpu, ops, size, B, style, m_pad):
     assert np.array_equal(cls.cpu().numpy(), rl)
 
 
-@pytest.mark.parametrize("no,layout", [(85, "dense"), (85, "channels_last"), (6, "dense")])
-def test_yolo_loss_fwd_bwd(gpu, ops, no, layout):
+FOCAL_CASES = [None, (1.5, 0.25, ("cls", "obj")), (0.5, -1.0, ("cls",)), (0.5, 0.25, ("obj",))]
+
+
+@pytest.mark.parametrize("no,layout,focal", [(85, "dense", None), (85, "channels_last", None), (6, "dense", None),
+                                             (85, "channels_last", FOCAL_CASES[1]), (85, "dense", FOCAL_CASES[2]),
+                                             (6, "channels_last", FOCAL_CASES[3])])
+def test_yolo_loss_fwd_bwd(gpu, ops, no, layout, focal):
+    """focal != None: the "YOLOv5s-focalloss(...)" variants (README.md:118-154); gamma 0.5 is a
+    "root"-style modulation, terms=("cls",) wraps the classification BCE only."""
     B, size = 2, 128
     nc = no - 5
     preds = H.yolo_preds(B, size, no, 81)
@@ -309,7 +316,7 @@ def test_yolo_loss_fwd_bwd(gpu, ops, no, layout):
     shapes = H.yolo_shapes(size, no)
     rc, rt, rl = co.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb.numpy(), gtc.numpy(), mv.numpy(), 4.0)
     r_loss, r_grads, _, _ = co.yolo_loss([p.numpy() for p in preds], H.YOLO_STRIDES, H.YOLO_ANCHORS, rc, rt, rl, 24,
-                                         grad_scale=0.5)
+                                         grad_scale=0.5, focal=focal)
     slots = ops.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, dev(gtb, gpu), dev(gtc, gpu), dev(mv, gpu), 4.0)
     pd = []
     for p in preds:
@@ -322,7 +329,7 @@ def test_yolo_loss_fwd_bwd(gpu, ops, no, layout):
             pd.append(conv)
     views = pd if layout == "dense" else [c.view(B, 3, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in pd]
     biases = [torch.zeros(3 * no, device=gpu, requires_grad=True) for _ in preds]  # values already in preds
-    total, parts = ops.yolo_loss(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, 24, biases=biases)
+    total, parts = ops.yolo_loss(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, 24, biases=biases, focal=focal)
     (total * 0.5).backward()
     assert H.max_rel_elem(parts.cpu().numpy(), r_loss, 1e-6) < TOL
     for l, p in enumerate(pd):

@@ -108,6 +108,9 @@ def test_golden_yolo(gold):
     assert np.allclose(loss, gold["y_loss"], rtol=1e-6, atol=0)
     for g, k in zip(grads, ("y_g0", "y_g1", "y_g2")):
         assert np.allclose(g, gold[k], rtol=1e-6, atol=1e-9)
+    fl, fg, _, _ = co.yolo_loss(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, cls, 12, focal=(1.5, 0.25, ("cls", "obj")))
+    assert np.allclose(fl, gold["y_focal_loss"], rtol=1e-6, atol=0)
+    assert np.allclose(fg[0], gold["y_focal_g0"], rtol=1e-6, atol=1e-9) and np.allclose(fg[2], gold["y_focal_g2"], rtol=1e-6, atol=1e-9)
     det, cnt = co.yolo_nms(gold["y_dec"], 0.3, 0.45, 500, 20)
     assert np.array_equal(det, gold["y_det"]) and np.array_equal(cnt, gold["y_dcnt"])
 
@@ -147,6 +150,34 @@ def test_yolo_loss_grad_vs_autograd():
     assert abs(float(lt[0].detach()) - loss[0]) / abs(loss[0]) < 1e-5
     for g, p in zip(grads, pt):
         assert H.rel_err(g, p.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("focal", [(1.5, 0.25, ("cls", "obj")), (0.5, -1.0, ("cls",)), (0.5, 0.25, ("obj",)),
+                                   (2.0, 0.5, ("cls", "obj"))])
+def test_focal_yolo_loss_matches_autograd_restatement(focal):
+    """The C oracle's hand-derived focal gradient vs float64 autograd through the public FocalLoss form
+    ("YOLOv5s-focalloss" variants, README.md:118-154).  gamma < 1 exercises the q^(gamma-1) factor."""
+    from heltondetection_amd import synthetic as syn
+    preds = [p.numpy() for p in H.yolo_preds(2, 64, 9, 8, scale=2.0)]
+    gtb, gtc, gmv = syn.make_targets(2, 64, syn.make_generator(9), "coco", 4, 12)
+    gmv = torch.clamp(gmv, max=12)
+    cell, tbox, scls = co.yolo_assign(H.yolo_shapes(64, 9), H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb.numpy(), gtc.numpy(),
+                                      gmv.numpy(), 4.0)
+    loss, grads, _, _ = co.yolo_loss(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, scls, 12, focal=focal)
+    base, _, _, _ = co.yolo_loss(preds, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, scls, 12, want_grad=False)
+    pt = [torch.from_numpy(p).double().requires_grad_(True) for p in preds]
+    lt = tr.yolo_loss(pt, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb, gtc, gmv, focal=focal)
+    lt[0].backward()
+    for a, b in zip(loss, lt):
+        assert abs(float(a) - float(b.detach())) <= 1e-5 * abs(float(b.detach()))
+    for g, p in zip(grads, pt):
+        assert H.rel_err(g, p.grad.numpy()) < 1e-5
+    assert loss[1] == base[1]                      # the box term is untouched
+    assert ("cls" in focal[2]) == (loss[3] != base[3]) and ("obj" in focal[2]) == (loss[2] != base[2])
+    # saturated logits: q underflows to 0 and the q^(gamma-1) factor must not produce NaN/inf
+    sat = [np.where(np.random.default_rng(3).random(p.shape) < 0.5, 60.0, -60.0).astype(np.float32) for p in preds]
+    l2, g2, _, _ = co.yolo_loss(sat, H.YOLO_STRIDES, H.YOLO_ANCHORS, cell, tbox, scls, 12, focal=focal)
+    assert np.isfinite(l2).all() and all(np.isfinite(g).all() for g in g2)
 
 
 def test_roi_align_backward_is_adjoint_of_forward():

@@ -47,9 +47,11 @@ def test_yolov5s_640_bs2_cpu_plumbing(monkeypatch):
         captured["targets"] = (gt_boxes, gt_cls, m_valid, anchor_t)
         return None
 
-    def fake_loss(preds, strides, anchors, slots, M, box_gain, obj_gain, cls_gain, balance, biases=None):
+    def fake_loss(preds, strides, anchors, slots, M, box_gain, obj_gain, cls_gain, balance, biases=None, focal=None):
         gtb, gtc, mv, at = captured["targets"]
-        total, lb, lo, lc = tr.yolo_loss(list(preds), strides, anchors, gtb, gtc, mv, at, box_gain, obj_gain, cls_gain, balance)
+        ft = None if focal is None else (focal.get("gamma", 1.5), focal.get("alpha", 0.25), focal.get("terms", ("cls", "obj")))
+        total, lb, lo, lc = tr.yolo_loss(list(preds), strides, anchors, gtb, gtc, mv, at, box_gain, obj_gain, cls_gain, balance,
+                                         focal=ft)
         return total, torch.stack([total.detach(), lb, lo, lc])
 
     monkeypatch.setattr(ops, "yolo_assign", fake_assign)
