@@ -347,7 +347,7 @@ def main():
         nbytes = loss_bwd_bytes(args.batch, args.size, args.classes + 5)
         achieved = nbytes / k_ms / 1e6 if k_ms > 0 else 0.0
         out = {
-            "metric": "images/sec train step, YOLOv5s 640² bs=16/GPU",
+            "metric": f"images/sec train step, YOLOv5{args.variant} {args.size}² bs={args.batch}/GPU",
             "value": round(world * args.batch * args.steps / elapsed, 2),
             "unit": "images/s",
             "n_gpus": world,

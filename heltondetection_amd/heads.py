@@ -220,6 +220,9 @@ class RoIHead(nn.Module):
         self.assigner = ASSIGNERS.build(assigner or dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.5,
                                                          match_low_quality=False))
         self.register_buffer("delta_std", torch.tensor(delta_std, dtype=torch.float32), persistent=False)
+        # placeholder box of padded samples; a buffer, not a literal: a host->device copy inside
+        # sample()/predict() would be illegal while the step is being captured into a hipGraph
+        self.register_buffer("unit_box", torch.tensor([0.0, 0.0, 1.0, 1.0], dtype=torch.float32), persistent=False)
         self.score_thr, self.nms_thr, self.max_det, self.pre_nms_candidates = score_thr, nms_thr, max_det, pre_nms_candidates
 
     # ---- RoI features ------------------------------------------------------------------------
@@ -269,7 +272,7 @@ class RoIHead(nn.Module):
         tgt = torch.where(is_fg[..., None], tgt / self.delta_std, torch.zeros_like(tgt))
         bi = torch.arange(B, device=rois.device, dtype=torch.float32)[:, None, None].expand(B, S, 1)
         # invalid samples keep a harmless 1x1 box so RoIAlign stays in range; their loss weight is 0
-        boxes = torch.where(ok[..., None], boxes, torch.tensor([0.0, 0.0, 1.0, 1.0], device=rois.device).expand_as(boxes))
+        boxes = torch.where(ok[..., None], boxes, self.unit_box.expand_as(boxes))
         rois5 = torch.cat([bi, boxes], 2).reshape(B * S, 5).contiguous()
         return rois5, cls.reshape(-1), tgt.reshape(-1, 4), ok.reshape(-1), is_fg.reshape(-1)
 
@@ -290,7 +293,7 @@ class RoIHead(nn.Module):
         bi = torch.arange(B, device=rois.device, dtype=torch.float32)[:, None, None].expand(B, K, 1)
         ar = torch.arange(K, device=rois.device)[None, :]
         valid = ar < count[:, None]
-        safe = torch.where(valid[..., None], rois, torch.tensor([0.0, 0.0, 1.0, 1.0], device=rois.device).expand_as(rois))
+        safe = torch.where(valid[..., None], rois, self.unit_box.expand_as(rois))
         cls_logits, deltas = self.forward(feats, torch.cat([bi, safe], 2).reshape(B * K, 5).contiguous())
         prob = F.softmax(cls_logits.float(), 1)[:, : self.nc].reshape(B, K, self.nc)
         prob = torch.where(valid[..., None], prob, torch.zeros_like(prob))

@@ -96,3 +96,24 @@ def test_faster_rcnn_trains_and_detects(gpu, cfg):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         det, cnt = model.forward_test(batch[0])
     assert det.shape[0] == 2 and det.shape[2] == 6 and (cnt >= 0).all()
+
+
+def test_faster_rcnn_step_captures_into_a_hipgraph(gpu):
+    """The two-stage step has no host sync or host->device copy, so Trainer(use_graph=True) can capture it
+    (fixed-size proposal / sample tensors + device-side counts)."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    model = build_detector(dict(type="FasterRCNN", num_classes=6, neck=dict(type="FPN"),
+                                roi_head=dict(type="RoIHead", num_classes=6, decoupled=False)))
+    model = model.to(gpu).to(memory_format=torch.channels_last).train()
+    model.rpn_head.pre, model.rpn_head.post = 300, 100
+    model.roi_head.batch_per_image = 32
+    tr = Trainer(model, lr=2e-4, total_steps=30, warmup_steps=2, device=gpu, use_graph=True)
+    batch = _batch(2, 192, 6, 5, gpu, m_pad=8)
+    losses = []
+    for _ in range(12):
+        loss, parts = tr.step(*batch)
+        losses.append(float(loss))
+    assert tr._graph is not None, tr.graph_error
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 1.5
