@@ -8,7 +8,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import C3, SPPF, ConvBNAct, FusedBNAct
+from .layers import C3, SPPF, ConvBNAct, FusedBNAct, ShadowConv2d
 from .registry import BACKBONES
 
 
@@ -52,11 +52,11 @@ class _ResBottleneck(nn.Module):
 
     def __init__(self, c_in, width, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(c_in, width, 1, bias=False)
+        self.conv1 = ShadowConv2d(c_in, width, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.conv2 = ShadowConv2d(width, width, 3, stride, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(width)
-        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.conv3 = ShadowConv2d(width, width * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(width * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -78,7 +78,7 @@ class ResNet50(nn.Module):
 
     def __init__(self, in_ch: int = 3, frozen_stages: int = 0):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_ch, 64, 7, 2, 3, bias=False)
+        self.conv1 = ShadowConv2d(in_ch, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
@@ -100,7 +100,7 @@ class ResNet50(nn.Module):
     def _make(self, width, n, stride):
         ds = None
         if stride != 1 or self._c != width * 4:
-            ds = nn.Sequential(nn.Conv2d(self._c, width * 4, 1, stride, bias=False), nn.BatchNorm2d(width * 4))
+            ds = nn.Sequential(ShadowConv2d(self._c, width * 4, 1, stride, bias=False), nn.BatchNorm2d(width * 4))
         layers = [_ResBottleneck(self._c, width, stride, ds)]
         self._c = width * 4
         layers += [_ResBottleneck(self._c, width) for _ in range(n - 1)]

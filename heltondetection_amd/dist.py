@@ -15,7 +15,7 @@ Works unchanged on the gloo backend (CPU tests, world_size 2).
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -60,8 +60,12 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, first_bucket_bytes: int = 4 << 20,
-                 process_group=None, broadcast_params: bool = True, defer_collectives: bool = False):
+                 process_group=None, broadcast_params: bool = True, defer_collectives: bool = False,
+                 grad_sources: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None):
         self.module = module
+        # grad_sources: parameter -> the leaf tensor that receives its gradient instead of the parameter
+        # (a bf16 weight shadow, train.LowpShadows); the bucket copy converts to fp32 while packing
+        self._src = dict(grad_sources or {})
         # defer_collectives: hooks only pack gradients; finish() launches the all-reduces.  Used when
         # forward+backward are replayed from a hipGraph (collectives stay outside the captured region).
         self.defer = defer_collectives
@@ -87,7 +91,13 @@ class GradReducer:
             for p in b.params:
                 self._bucket_of[p] = b
         self._avg_native = self.world > 1 and dist.get_backend(process_group) == "nccl"
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._hooks = []
+        for p in params:
+            src = self._src.get(p)
+            if src is None:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            else:
+                self._hooks.append(src.register_post_accumulate_grad_hook(lambda _t, p=p: self._on_grad(p)))
 
     # autograd calls this once per parameter per backward, right after .grad is final
     def _on_grad(self, p: torch.nn.Parameter):
@@ -96,11 +106,26 @@ class GradReducer:
         if b.pending == 0:
             self._launch(b)
 
+    def _grad_of(self, p):
+        src = self._src.get(p)
+        return p.grad if src is None else src.grad
+
     def _launch(self, b: _Bucket):
-        grads = [p.grad for p in b.params]
-        torch._foreach_copy_(b.views, grads)
+        # one multi-tensor copy per gradient dtype (fp32 from parameters, bf16 from weight shadows):
+        # _foreach_copy_ keeps its single-launch path only for dtype-homogeneous lists
+        groups: Dict[torch.dtype, Tuple[list, list]] = {}
+        for p, v in zip(b.params, b.views):
+            g = self._grad_of(p)
+            vs, gs = groups.setdefault(g.dtype, ([], []))
+            vs.append(v)
+            gs.append(g)
+        for vs, gs in groups.values():
+            torch._foreach_copy_(vs, gs)
         for p, v in zip(b.params, b.views):
             p.grad = v
+            src = self._src.get(p)
+            if src is not None:
+                src.grad = None
         if self.world > 1 and not self.defer:
             if self._avg_native:
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -114,6 +139,9 @@ class GradReducer:
             b.work = None
             for p in b.params:
                 p.grad = None
+                src = self._src.get(p)
+                if src is not None:
+                    src.grad = None
 
     def finish(self):
         """Call after backward: wait for every bucket (the current stream then depends on RCCL's)."""
@@ -121,12 +149,15 @@ class GradReducer:
             if b.pending != 0:
                 # parameters that received no gradient this step (unused branch): reduce zeros
                 for p, v in zip(b.params, b.views):
-                    if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                        if p.grad is None:
+                    g = self._grad_of(p)
+                    if g is None or g.data_ptr() != v.data_ptr():
+                        if g is None:
                             v.zero_()
                         else:
-                            v.copy_(p.grad)
+                            v.copy_(g)
                         p.grad = v
+                        if p in self._src:
+                            self._src[p].grad = None
                 b.pending = 0
                 if self.world > 1:
                     op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import ConvBNAct
+from .layers import ConvBNAct, ShadowConv2d
 from .registry import ASSIGNERS, HEADS
 
 YOLOV5_ANCHORS = (((10, 13), (16, 30), (33, 23)), ((30, 61), (62, 45), (59, 119)), ((116, 90), (156, 198), (373, 326)))
@@ -37,7 +37,7 @@ class YOLOv5Head(nn.Module):
         self.anchors = tuple(tuple(tuple(float(v) for v in a) for a in lv) for lv in anchors)
         self.na, self.nl = len(self.anchors[0]), len(self.anchors)
         self.strides = tuple(float(s) for s in strides)
-        self.m = nn.ModuleList(nn.Conv2d(c, self.na * self.no, 1) for c in in_channels)
+        self.m = nn.ModuleList(ShadowConv2d(c, self.na * self.no, 1) for c in in_channels)
         self.assigner = ASSIGNERS.build(assigner or dict(type="YOLOv5Assigner", anchor_t=4.0))
         # gain scaling as in the public v6.1 training script
         self.box_gain = box_gain * 3.0 / self.nl
@@ -60,7 +60,7 @@ class YOLOv5Head(nn.Module):
             # bias.detach(): the bias gradient comes from the loss kernels (ops.yolo_loss(biases=...)),
             # not from a framework reduction over the dense [B, na*no, H, W] gradient
             bias = conv.bias.detach() if (self.training and self.bias_grad_in_loss) else conv.bias
-            y = F.conv2d(f, conv.weight, bias).float()
+            y = F.conv2d(f, conv.lp_weight(), bias).float()
             if not y.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous(memory_format=torch.channels_last)
             B, _, H, W = y.shape
@@ -114,9 +114,9 @@ class RPNHead(nn.Module):
         self.sizes = [list(map(float, z)) for z in sizes] if sizes is not None else \
             [[anchor_scale * s * 2 ** (i / scales_per_octave) for i in range(scales_per_octave)] for s in self.strides]
         self.A = len(self.ratios) * len(self.sizes[0])
-        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
-        self.obj = nn.Conv2d(in_channels, self.A, 1)
-        self.reg = nn.Conv2d(in_channels, self.A * 4, 1)
+        self.conv = ShadowConv2d(in_channels, in_channels, 3, padding=1)
+        self.obj = ShadowConv2d(in_channels, self.A, 1)
+        self.reg = ShadowConv2d(in_channels, self.A * 4, 1)
         for m in (self.conv, self.obj, self.reg):
             nn.init.normal_(m.weight, std=0.01)
             nn.init.zeros_(m.bias)

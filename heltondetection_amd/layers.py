@@ -10,6 +10,30 @@ def autopad(k: int, p=None) -> int:
     return k // 2 if p is None else p
 
 
+class LowpWeights:
+    """Switch + bookkeeping for low-precision weight shadows (train.Trainer turns `on` around its own
+    forward/backward only, so an evaluation or a hand-rolled forward never sees a stale shadow)."""
+
+    on = False
+
+
+class ShadowConv2d(nn.Conv2d):
+    """nn.Conv2d whose fp32 master weight can be shadowed by a bf16 copy (`weight_lp`, a plain leaf
+    tensor owned by train.LowpShadows).  Under autocast a plain Conv2d casts its weight fp32->bf16 on
+    every call and autograd casts the bf16 weight gradient back: ~140 launches of ~6 us per YOLOv5s
+    step, 0.8 ms of a 9.7 ms step once the step replays from a hipGraph.  With a shadow the cast is
+    one multi-tensor launch per step for all convolutions and the weight gradients stay bf16 until
+    dist.GradReducer packs them into its fp32 buckets (again multi-tensor)."""
+
+    weight_lp = None
+
+    def lp_weight(self) -> torch.Tensor:
+        return self.weight_lp if (LowpWeights.on and self.weight_lp is not None) else self.weight
+
+    def forward(self, x):
+        return self._conv_forward(x, self.lp_weight(), self.bias)
+
+
 class FusedBNAct:
     """Mixin-free helper: `apply(bn, x, act)` runs BatchNorm2d + activation as the fused HIP kernels
     (csrc/bn_act.hip) when `x` is a dense channels-last HIP tensor and `enabled` is set, otherwise the
@@ -40,7 +64,7 @@ class ConvBNAct(nn.Module):
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
-        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.conv = ShadowConv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act

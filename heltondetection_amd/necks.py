@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import C2f, C3, ConvBNAct
+from .layers import C2f, C3, ConvBNAct, ShadowConv2d
 from .registry import NECKS
 
 
@@ -48,8 +48,8 @@ class FPN(nn.Module):
     def __init__(self, in_channels: Sequence[int], out_channels: int = 256, extra_level: bool = True,
                  p2_only: bool = False):
         super().__init__()
-        self.lateral = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels)
-        self.output = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+        self.lateral = nn.ModuleList(ShadowConv2d(c, out_channels, 1) for c in in_channels)
+        self.output = nn.ModuleList(ShadowConv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
         self.extra_level = extra_level
         self.p2_only = p2_only  # "P2" variants: only level P2 reaches the heads (README.md:65)
         self.out_channels = out_channels

@@ -9,6 +9,35 @@ from typing import Optional
 import torch
 
 from .dist import GradReducer
+from .layers import LowpWeights, ShadowConv2d
+
+
+class LowpShadows:
+    """bf16 shadows of the convolution weights (layers.ShadowConv2d): `refresh()` re-casts every master
+    weight with one multi-tensor launch; the shadows are the autograd leaves of the step, so weight
+    gradients arrive in bf16 and are converted once, while dist.GradReducer packs its buckets."""
+
+    def __init__(self, model: torch.nn.Module, dtype: torch.dtype):
+        self.masters, self.shadows = [], []
+        for m in model.modules():
+            if isinstance(m, ShadowConv2d) and m.weight.requires_grad and m.weight.is_cuda:
+                lp = torch.empty_like(m.weight, dtype=dtype).requires_grad_(True)  # keeps channels-last strides
+                m.weight_lp = lp
+                self.masters.append(m.weight)
+                self.shadows.append(lp)
+
+    def grad_sources(self):
+        return dict(zip(self.masters, self.shadows))
+
+    @torch.no_grad()
+    def refresh(self):
+        if self.shadows:
+            torch._foreach_copy_(self.shadows, self.masters)
+
+    def release(self, model: torch.nn.Module):
+        for m in model.modules():
+            if isinstance(m, ShadowConv2d):
+                m.weight_lp = None
 
 
 def warmup_cosine(step: int, total: int, warmup: int, min_ratio: float = 0.01) -> float:
@@ -26,13 +55,19 @@ class Trainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
-                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = False):
+                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = False,
+                 lowp_weights: bool = True):
         self.model = model
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self.graph_sync = bool(graph_sync)
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph)
+        # bf16 weight shadows only make sense where autocast would otherwise cast per call
+        self.shadows = None
+        if lowp_weights and amp_dtype is not None and self.device.type == "cuda":
+            self.shadows = LowpShadows(model, amp_dtype)
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph,
+                                   grad_sources=self.shadows.grad_sources() if self.shadows else None)
         decay, no_decay = [], []
         for n, p in model.named_parameters():
             if not p.requires_grad:
@@ -57,9 +92,15 @@ class Trainer:
             from . import ops
             ops.bn_arena_reset(self.device)  # one kernel clears every fused-BN statistics slot
         use_amp = self.amp_dtype is not None and self.device.type == "cuda"
-        with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
-            loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
-        loss.backward()
+        if self.shadows is not None:
+            self.shadows.refresh()
+        LowpWeights.on = self.shadows is not None
+        try:
+            with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
+                loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
+            loss.backward()
+        finally:
+            LowpWeights.on = False
         return loss.detach(), parts
 
     def _capture(self, batch):

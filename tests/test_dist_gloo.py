@@ -92,3 +92,53 @@ def test_shard_batch_partitions():
         s = shard_batch(64, r, 4)
         seen += list(range(64))[s]
     assert seen == list(range(64))
+
+
+def _shadow_worker(rank, world, port, tmp):
+    """Same collective, with the convolution weight gradients arriving on bf16 shadow leaves
+    (train.LowpShadows' arrangement, emulated on CPU): the reducer must convert them while packing."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from heltondetection_amd.dist import GradReducer, init_distributed
+    from heltondetection_amd.layers import LowpWeights, ShadowConv2d
+    init_distributed("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(ShadowConv2d(3, 8, 3, padding=1), torch.nn.Tanh(), ShadowConv2d(8, 4, 1, bias=False))
+    convs = [m for m in model if isinstance(m, ShadowConv2d)]
+    sources = {}
+    for m in convs:
+        m.weight_lp = m.weight.detach().to(torch.bfloat16).requires_grad_(True)
+        sources[m.weight] = m.weight_lp
+    red = GradReducer(model, bucket_bytes=1 << 20, first_bucket_bytes=64, grad_sources=sources)
+    x = torch.rand((2, 3, 16, 16), generator=torch.Generator().manual_seed(100 + rank))
+    for step in range(2):  # twice: prepare() must drop the shadows' gradients too
+        red.prepare()
+        LowpWeights.on = True
+        try:
+            y = model[2](model[1](torch.nn.functional.conv2d(x.to(torch.bfloat16), convs[0].lp_weight(),
+                                                             convs[0].bias.to(torch.bfloat16), padding=1)))
+            loss = (y.float() ** 2).mean()
+            # this rank's own bf16 gradients, taken before the reducer's hooks consume them in backward()
+            local = [g.float().clone() for g in torch.autograd.grad(loss, [m.weight_lp for m in convs], retain_graph=True)]
+            loss.backward()
+        finally:
+            LowpWeights.on = False
+        red.finish()
+    assert all(m.weight_lp.grad is None for m in convs)
+    assert all(m.weight.grad.dtype == torch.float32 for m in convs)
+    torch.save({"reduced": [m.weight.grad.clone() for m in convs] + [convs[0].bias.grad.clone()], "local": local},
+               os.path.join(tmp, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_reducer_with_bf16_grad_sources_two_ranks_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_shadow_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    for a, b in zip(s0["reduced"], s1["reduced"]):
+        assert torch.equal(a, b)
+    for red, l0, l1 in zip(s0["reduced"][:2], s0["local"], s1["local"]):
+        assert torch.allclose(red, (l0 + l1) / 2, rtol=1e-6, atol=1e-9)  # fp32 mean of the bf16 shard gradients

@@ -117,3 +117,51 @@ def test_faster_rcnn_step_captures_into_a_hipgraph(gpu):
         losses.append(float(loss))
     assert tr._graph is not None, tr.graph_error
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 1.5
+
+
+def test_lowp_weight_shadows_match_autocast_casts(gpu):
+    """Trainer(lowp_weights=True) feeds the convolutions bf16 shadows of the fp32 masters.  On a small
+    BatchNorm-free stack (a full detector at random init amplifies MIOpen's run-to-run noise far beyond
+    bf16 rounding, with or without shadows) the result must be what autocast's per-call casts give: same
+    loss, same fp32 gradients on the masters up to bf16 rounding, and the optimizer moves the masters."""
+    from heltondetection_amd.layers import ShadowConv2d
+    from heltondetection_amd.train import Trainer
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = ShadowConv2d(3, 16, 3, 2, 1, bias=False)
+            self.c2 = ShadowConv2d(16, 32, 3, 2, 1, bias=True)
+            self.c3 = ShadowConv2d(32, 8, 1, bias=False)
+
+        def forward_train(self, images, gt_boxes, gt_cls, m_valid):
+            y = self.c3(torch.tanh(self.c2(torch.tanh(self.c1(images)))))
+            loss = (y.float() ** 2).mean() + 0.1 * y.float().mean()
+            return loss, torch.stack([loss.detach()] * 4)
+
+    batch = _batch(2, 64, 8, 3, gpu, m_pad=8)
+    out = {}
+    for lowp in (False, True):
+        torch.manual_seed(0)
+        model = Tiny().to(gpu).to(memory_format=torch.channels_last).train()
+        tr = Trainer(model, lr=1e-2, total_steps=20, warmup_steps=1, device=gpu, lowp_weights=lowp)
+        convs = [model.c1, model.c2, model.c3]
+        assert all((m.weight_lp is not None) == lowp for m in convs)
+        loss0, _ = tr._fwd_bwd(*batch)
+        tr.reducer.finish()
+        assert all(m.weight.grad.dtype == torch.float32 and m.weight.grad.shape == m.weight.shape for m in convs)
+        out[lowp] = (float(loss0), [m.weight.grad.clone() for m in convs], model.c2.bias.grad.clone())
+        if lowp:
+            before = model.c2.weight.detach().clone()
+            losses = [float(tr.step(*batch)[0]) for _ in range(6)]
+            assert np.isfinite(losses).all() and losses[-1] < losses[0]
+            assert not torch.equal(before, model.c2.weight)               # the master moved
+            assert not torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))  # stale until ...
+            tr.shadows.refresh()                                          # ... the next step's refresh
+            assert torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))
+            # outside the Trainer's step the module uses its master weight (no stale shadow in eval)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                assert model.c2.lp_weight() is model.c2.weight
+    assert abs(out[True][0] - out[False][0]) <= 1e-4 * abs(out[False][0])
+    for a, b in zip(out[True][1] + [out[True][2]], out[False][1] + [out[False][2]]):
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-9
