@@ -333,6 +333,17 @@ inline bool is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
          (B == 1 || g.sb[l] == H * W * na * no) && hd_aligned16(g.pred[l]);
 }
 
+// Loss accumulators (sum(1-ciou), n_pos, sum bce_cls, sum bce_obj per level).  The totals sit in the
+// first 32 floats of the workspace; workgroups add into one of kAccRep replicas a cache line apart
+// (replica = blockIdx.x % kAccRep) and yolo_loss_finalize_kernel folds them.  With a single copy all
+// n_levels*4 floats share one 128-byte line and every wave of the launch serialises on that L2 line:
+// measured 71.7 us for the matched-cell pass with one atomic triple per wave, against 24 us of work.
+constexpr int kAccRep = 32;
+constexpr int kAccStride = 32;  // floats = 128 bytes >= HD_MAX_LEVELS*4 floats
+__device__ __forceinline__ float* acc_replica(float* acc, unsigned block) {
+  return acc + 64 + (block % kAccRep) * kAccStride;
+}
+
 struct CellPos {
   int b, a, gj, gi;
 };
@@ -373,14 +384,14 @@ __device__ __forceinline__ float4 tbox_xyxy(const float4 tb) {
   return make_float4(tb.x - tb.z * 0.5f, tb.y - tb.w * 0.5f, tb.x + tb.z * 0.5f, tb.y + tb.w * 0.5f);
 }
 
-// Matched-cell terms.  grid: (ceil(S / (4 waves * 8 slots)), n_levels).  A wave owns 8 consecutive
+// Matched-cell terms.  grid: (ceil(S / (4 waves * 4 slots)), n_levels).  A wave owns 4 consecutive
 // slots (short serial chain: the per-slot work is a dependent gather + CIoU), finds the matched
 // ones with one ballot and spends all 64 lanes on the `no` channels of each matched cell.
 // Backward accumulates the bias gradient (sum over cells, per channel) in LDS first and issues
 // one global atomic per touched channel per workgroup.
-constexpr int kSlotsPerWave = 8;
+constexpr int kSlotsPerWave = 4;
 
-template <bool BWD>
+template <bool BWD, bool FOCAL>
 __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
                                                        const LevelIndex ix, const LevelFlags fl, int B, long long S,
                                                        const int32_t* __restrict__ slot_cell,
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
   const int wave = threadIdx.x >> 6;
   const int no = lv.no, nc = lv.no - 5, na = lv.na;
   const bool do_bias = BWD && grad_bias != nullptr;
-  const bool focal_cls = cfg.focal_gamma > 0.0f && (cfg.focal_terms & 1);
+  constexpr bool focal_cls = FOCAL;  // focal modulation of the classification BCE (template: see yolo_obj_fwd_kernel)
   if (do_bias) {
     for (int i = threadIdx.x; i < na * no; i += blockDim.x) s_gb[i] = 0.0f;
     __syncthreads();
@@ -490,10 +501,18 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
         }
     }
   }
-  if (!BWD && lane == 0 && cnt > 0.0f) {
-    atomicAdd(acc + l * 4 + 0, sum_box);
-    atomicAdd(acc + l * 4 + 1, cnt);
-    atomicAdd(acc + l * 4 + 2, sum_cls);
+  if (!BWD) {
+    // workgroup-level fold in LDS, then one atomic triple per workgroup into its replica
+    __shared__ float s_red[3];
+    if (threadIdx.x < 3) s_red[threadIdx.x] = 0.0f;
+    __syncthreads();
+    if (lane == 0 && cnt > 0.0f) {
+      atomicAdd(&s_red[0], sum_box);
+      atomicAdd(&s_red[1], cnt);
+      atomicAdd(&s_red[2], sum_cls);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_red[1] > 0.0f) atomicAdd(acc_replica(acc, blockIdx.x) + l * 4 + threadIdx.x, s_red[threadIdx.x]);
   }
   if (do_bias) {
     // workgroup 0 of each level folds in the dense kernel's per-workgroup objectness partials
@@ -517,6 +536,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
 // It also overwrites tobj[m] with d(term)/d(logit) (sigmoid(x) - tobj[m] for plain BCE): backward then needs
 // only that linear array (4 B per cell) instead of re-gathering the logits at a 4*no-byte stride
 // (PMC: the gather fetched 28 MB raw / 56 MB corrected per launch for 3.2 MB of useful bytes).
+template <bool FOCAL>  // a template, not a branch: the powf path costs registers the plain-BCE gather cannot afford
 __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels lv, const LevelIndex ix,
                                                            const LevelFlags fl, int B, const hd_yolo_loss_cfg cfg,
                                                            float* __restrict__ tobj, float* __restrict__ acc) {
@@ -526,16 +546,32 @@ __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels 
   float* to = tobj + ix.first_cell[l];
   const float* pr = lv.pred[l];
   float sum = 0.0f;
-  const bool focal_obj = cfg.focal_gamma > 0.0f && (cfg.focal_terms & 2);
   // d(loss term)/d(logit) replaces the target in place: sigmoid(x) - t, or the focal derivative
   auto term = [&](float x, float t, float* d) -> float {
-    if (focal_obj) return hd_focal_bce(x, t, cfg.focal_gamma, cfg.focal_alpha, d);
+    if (FOCAL) return hd_focal_bce(x, t, cfg.focal_gamma, cfg.focal_alpha, d);
     *d = hd_sigmoid(x) - t;
     return hd_bce_logits(x, t);
   };
   if (fl.pred_dense[l]) {
+    // the objectness logit is 4 bytes of every 4*no: a pure-latency gather, so each lane keeps 4
+    // independent (logit, target) pairs in flight
     const int no = lv.no;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < cells; m += gridDim.x * blockDim.x) {
+    const int step = gridDim.x * blockDim.x;
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; m + 3 * step < cells; m += 4 * step) {
+      float x[4], t[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = pr[(long long)(m + u * step) * no + 4];
+        t[u] = to[m + u * step];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sum += term(x[u], t[u], &d[u]);
+        to[m + u * step] = d[u];
+      }
+    }
+    for (; m < cells; m += step) {
       float d;
       sum += term(pr[(long long)m * no + 4], to[m], &d);
       to[m] = d;
@@ -551,13 +587,22 @@ __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels 
   sum = hd_wave_sum(sum);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc + l * 4 + 3, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  if (threadIdx.x == 0)
+    atomicAdd(acc_replica(acc, blockIdx.x) + l * 4 + 3, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// one 64-lane workgroup: lanes 0..31 fold the replicas into the totals (which backward reads), lane 0 finishes
 __global__ void yolo_loss_finalize_kernel(const hd_yolo_levels lv, const LevelIndex ix, int B,
-                                          const hd_yolo_loss_cfg cfg, const float* __restrict__ acc,
+                                          const hd_yolo_loss_cfg cfg, float* __restrict__ acc,
                                           float* __restrict__ loss_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < kAccStride) {
+    float v = 0.0f;
+    for (int r = 0; r < kAccRep; ++r) v += acc[64 + r * kAccStride + threadIdx.x];
+    acc[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const int nc = lv.no - 5;
   float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
   for (int l = 0; l < lv.n_levels; ++l) {
@@ -760,7 +805,7 @@ extern "C" hd_status hd_yolo_assign(const hd_yolo_levels* lv, const float* gt_bo
 
 // workspace = [acc: 256 B][bias-gradient partials: n_levels * kDenseMaxBlocks * na floats]
 //             [tobj: total cells * 4 B]
-static constexpr size_t kAccBytes = 256;
+static constexpr size_t kAccBytes = 256 + (size_t)kAccRep * kAccStride * sizeof(float);  // totals + replicas
 
 static size_t part_bytes(const hd_yolo_levels* lv) {
   return hd_align_up((size_t)lv->n_levels * kDenseMaxBlocks * lv->na * sizeof(float), 256);
@@ -799,15 +844,23 @@ extern "C" hd_status hd_yolo_loss_fwd(const hd_yolo_levels* lv, int B, int M, co
   if (hd_fill32(tobj, 0u, (size_t)ix.first_cell[lv->n_levels], s) != HD_OK) return HD_ERR_LAUNCH;
   const long long S = (long long)5 * lv->na * B * M;
   if (S > 0) {
-    hipLaunchKernelGGL((yolo_pos_kernel<false>), pos_grid(S, lv->n_levels), dim3(256), 0, s, *lv, *lv, ix, fl, B, S,
-                       slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, (const float*)nullptr,
-                       acc, tobj, (float*)nullptr, (const float*)nullptr, 0);
+    if (cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1))
+      hipLaunchKernelGGL((yolo_pos_kernel<false, true>), pos_grid(S, lv->n_levels), dim3(256), 0, s, *lv, *lv, ix, fl,
+                         B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg,
+                         (const float*)nullptr, acc, tobj, (float*)nullptr, (const float*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((yolo_pos_kernel<false, false>), pos_grid(S, lv->n_levels), dim3(256), 0, s, *lv, *lv, ix, fl,
+                         B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg,
+                         (const float*)nullptr, acc, tobj, (float*)nullptr, (const float*)nullptr, 0);
     HD_RETURN_IF_LAUNCH_FAILED();
   }
   long long max_cells = 0;
   for (int l = 0; l < lv->n_levels; ++l) max_cells = std::max(max_cells, ix.first_cell[l + 1] - ix.first_cell[l]);
-  dim3 ogrid(cap_grid(max_cells, 256 * 2), (unsigned)lv->n_levels);
-  hipLaunchKernelGGL(yolo_obj_fwd_kernel, ogrid, dim3(256), 0, s, *lv, ix, fl, B, *cfg, tobj, acc);
+  dim3 ogrid(cap_grid(max_cells, 256 * 4), (unsigned)lv->n_levels);
+  if (cfg->focal_gamma > 0.0f && (cfg->focal_terms & 2))
+    hipLaunchKernelGGL(yolo_obj_fwd_kernel<true>, ogrid, dim3(256), 0, s, *lv, ix, fl, B, *cfg, tobj, acc);
+  else
+    hipLaunchKernelGGL(yolo_obj_fwd_kernel<false>, ogrid, dim3(256), 0, s, *lv, ix, fl, B, *cfg, tobj, acc);
   HD_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, s, *lv, ix, B, *cfg, acc, loss_out);
   HD_RETURN_IF_LAUNCH_FAILED();
@@ -867,9 +920,14 @@ extern "C" hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yol
   const long long S = (long long)5 * lv->na * B * M;
   const size_t lds = grad_bias ? (size_t)lv->na * lv->no * sizeof(float) : 0;
   dim3 grid = S > 0 ? pos_grid(S, lv->n_levels) : dim3(1, (unsigned)lv->n_levels);  // M == 0: partial reduce only
-  hipLaunchKernelGGL((yolo_pos_kernel<true>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl, B, S,
-                     slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj,
-                     grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
+  if (cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1))
+    hipLaunchKernelGGL((yolo_pos_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
+                       B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
+                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
+  else
+    hipLaunchKernelGGL((yolo_pos_kernel<true, false>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
+                       B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
+                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
