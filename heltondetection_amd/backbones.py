@@ -26,8 +26,10 @@ class CSPDarknet(nn.Module):
 
     PRESETS = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 
-    def __init__(self, variant: str = "s", depth: float | None = None, width: float | None = None, in_ch: int = 3):
+    def __init__(self, variant: str = "s", depth: float | None = None, width: float | None = None, in_ch: int = 3,
+                 frozen: bool = False):
         super().__init__()
+        self.frozen = bool(frozen)  # "..._frozeBackbone" (README.md:133): no gradients, BatchNorm on running stats
         d0, w0 = self.PRESETS[variant]
         depth, width = depth or d0, width or w0
         c = [_w(v, width) for v in (64, 128, 256, 512, 1024)]
@@ -38,6 +40,14 @@ class CSPDarknet(nn.Module):
         self.stage3 = nn.Sequential(ConvBNAct(c[2], c[3], 3, 2), C3(c[3], c[3], _d(9, depth)))
         self.stage4 = nn.Sequential(ConvBNAct(c[3], c[4], 3, 2), C3(c[4], c[4], _d(3, depth)), SPPF(c[4], c[4], 5))
         self.depth, self.width = depth, width
+        if self.frozen:
+            for p in self.parameters():
+                p.requires_grad_(False)
+            self.train(False)
+
+    def train(self, mode: bool = True):
+        super().train(mode and not self.frozen)
+        return self
 
     def forward(self, x) -> List[torch.Tensor]:
         x = self.stage1(self.stem(x))

@@ -139,3 +139,39 @@ class SPPF(nn.Module):
         y1 = pool(x)
         y2 = pool(y1)
         return self.cv2(torch.cat((x, y1, y2, pool(y2)), 1))
+
+
+class DropBlock2d(nn.Module):
+    """DropBlock regularisation (the "*_dropBlock0.5" rows of README.md:90,132-133): contiguous
+    `block_size` x `block_size` squares of a feature map are zeroed with overall drop probability `p`,
+    and the survivors rescaled.  Identity in eval mode.  Device-side only (no host sync), so a step that
+    contains it still captures into a hipGraph."""
+
+    def __init__(self, p: float = 0.1, block_size: int = 5):
+        super().__init__()
+        if not 0.0 <= p < 1.0 or block_size < 1 or block_size % 2 == 0:
+            raise ValueError("DropBlock2d: need 0 <= p < 1 and an odd block_size")
+        self.p, self.block_size = float(p), int(block_size)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        B, C, H, W = x.shape
+        bs = min(self.block_size, H if H % 2 else H - 1, W if W % 2 else W - 1)
+        bs = max(bs, 1)
+        # seed rate so that the expected dropped fraction is p (the public DropBlock formula)
+        gamma = self.p / (bs * bs) * (H * W) / max((H - bs + 1) * (W - bs + 1), 1)
+        seeds = (torch.rand((B, C, H, W), device=x.device) < gamma).to(x.dtype)
+        drop = torch.nn.functional.max_pool2d(seeds, bs, 1, bs // 2)
+        keep = 1.0 - drop
+        scale = keep.numel() / keep.float().sum().clamp(min=1.0)
+        return x * keep * scale.to(x.dtype)
+
+
+def make_drop_block(cfg):
+    """None | float p | dict(p=, block_size=) -> module (Identity when disabled)."""
+    if not cfg:
+        return nn.Identity()
+    if isinstance(cfg, (int, float)):
+        return DropBlock2d(float(cfg))
+    return DropBlock2d(**cfg)

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import C2f, C3, ConvBNAct, ShadowConv2d
+from .layers import C2f, C3, ConvBNAct, ShadowConv2d, make_drop_block
 from .registry import NECKS
 
 
@@ -16,8 +16,9 @@ from .registry import NECKS
 class YOLOv5PAFPN(nn.Module):
     """v6.1 head layers 10-23: top-down + bottom-up over (P3, P4, P5)."""
 
-    def __init__(self, in_channels: Sequence[int], depth: float = 0.33):
+    def __init__(self, in_channels: Sequence[int], depth: float = 0.33, drop_block=None):
         super().__init__()
+        self.drop = make_drop_block(drop_block)  # "YOLOv5s_dropBlock0.5" (README.md:132): on the neck outputs
         c3, c4, c5 = in_channels
         n = max(round(3 * depth), 1)
         self.lat5 = ConvBNAct(c5, c4, 1, 1)
@@ -38,7 +39,7 @@ class YOLOv5PAFPN(nn.Module):
         o3 = self.td3(torch.cat((F.interpolate(l4, scale_factor=2.0, mode="nearest"), p3), 1))
         o4 = self.bu4(torch.cat((self.down3(o3), l4), 1))
         o5 = self.bu5(torch.cat((self.down4(o4), l5), 1))
-        return [o3, o4, o5]
+        return [self.drop(o3), self.drop(o4), self.drop(o5)]
 
 
 @NECKS.register()
@@ -46,8 +47,9 @@ class FPN(nn.Module):
     """Feature Pyramid Network over (C2..C5) -> (P2..P5) [+P6 by stride-2 subsampling for the RPN]."""
 
     def __init__(self, in_channels: Sequence[int], out_channels: int = 256, extra_level: bool = True,
-                 p2_only: bool = False):
+                 p2_only: bool = False, drop_block=None):
         super().__init__()
+        self.drop = make_drop_block(drop_block)
         self.lateral = nn.ModuleList(ShadowConv2d(c, out_channels, 1) for c in in_channels)
         self.output = nn.ModuleList(ShadowConv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
         self.extra_level = extra_level
@@ -58,7 +60,7 @@ class FPN(nn.Module):
         lat = [l(f) for l, f in zip(self.lateral, feats)]
         for i in range(len(lat) - 1, 0, -1):
             lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[-2:], mode="nearest")
-        outs = [o(x) for o, x in zip(self.output, lat)]
+        outs = [self.drop(o(x)) for o, x in zip(self.output, lat)]
         if self.p2_only:
             return outs[:1]
         if self.extra_level:
@@ -72,8 +74,9 @@ class PAFPN(nn.Module):
     C2f top-down fusion, strided-conv + C2f bottom-up fusion."""
 
     def __init__(self, in_channels: Sequence[int], out_channels: int = 256, n: int = 1, extra_level: bool = True,
-                 p2_only: bool = False, act: str = "silu"):
+                 p2_only: bool = False, act: str = "silu", drop_block=None):
         super().__init__()
+        self.drop = make_drop_block(drop_block)  # "..._dropBlock0.5" (README.md:90)
         L = len(in_channels)
         self.lateral = nn.ModuleList(ConvBNAct(c, out_channels, 1, 1, act=act) for c in in_channels)
         self.td = nn.ModuleList(C2f(2 * out_channels, out_channels, n, act=act) for _ in range(L - 1))
@@ -94,6 +97,7 @@ class PAFPN(nn.Module):
         outs = [td[0]]
         for i in range(1, L):
             outs.append(self.bu[i - 1](torch.cat((self.down[i - 1](outs[-1]), td[i]), 1)))
+        outs = [self.drop(o) for o in outs]
         if self.p2_only:
             return outs[:1]
         if self.extra_level:

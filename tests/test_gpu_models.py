@@ -165,3 +165,25 @@ def test_lowp_weight_shadows_match_autocast_casts(gpu):
     assert abs(out[True][0] - out[False][0]) <= 1e-4 * abs(out[False][0])
     for a, b in zip(out[True][1] + [out[True][2]], out[False][1] + [out[False][2]]):
         assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-9
+
+
+def test_yolov5_frozen_backbone_dropblock_trains_under_graph(gpu):
+    """ "YOLOv5s_dropBlock0.5_frozeBackbone" (README.md:133) as a hipGraph-replayed step: the frozen
+    backbone runs its BatchNorms on running statistics (fused inference kernel), DropBlock draws its
+    mask on the device, and only neck + head parameters move."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160,
+                                backbone=dict(type="CSPDarknet", variant="s", frozen=True),
+                                neck=dict(type="YOLOv5PAFPN", depth=0.33, drop_block=dict(p=0.2, block_size=3))))
+    model = model.to(gpu).to(memory_format=torch.channels_last).train()
+    bb0 = [p.detach().clone() for p in model.backbone.parameters()]
+    nk0 = [p.detach().clone() for p in model.neck.parameters()]
+    tr = Trainer(model, lr=2e-3, total_steps=40, warmup_steps=2, device=gpu, use_graph=True)
+    batch = _batch(4, 160, 8, 3, gpu, m_pad=8)
+    losses = [float(tr.step(*batch)[0]) for _ in range(14)]
+    assert tr._graph is not None, tr.graph_error
+    assert np.isfinite(losses).all()
+    assert all(torch.equal(a, b) for a, b in zip(bb0, model.backbone.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(nk0, model.neck.parameters()))

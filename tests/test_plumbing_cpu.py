@@ -71,3 +71,52 @@ def test_yolov5s_640_bs2_cpu_plumbing(monkeypatch):
     preds = model.head(model.extract(img))
     assert [tuple(p.shape) for p in preds] == [(2, 3, 80, 80, 85), (2, 3, 40, 40, 85), (2, 3, 20, 20, 85)]
     assert all(p.stride(4) == 1 for p in preds)  # channels-last view, no copy
+
+
+def test_drop_block_statistics_and_eval_identity():
+    from heltondetection_amd.layers import DropBlock2d
+    torch.manual_seed(0)
+    db = DropBlock2d(p=0.3, block_size=5).train()
+    x = torch.ones((4, 16, 40, 40))
+    y = db(x)
+    dropped = float((y == 0).float().mean())
+    assert 0.2 < dropped < 0.4                       # expected dropped fraction ~ p
+    assert abs(float(y.mean()) - 1.0) < 1e-3         # survivors rescaled: the mean is preserved
+    # zeros come in block_size squares: the dropped set is a union of (border-clipped) 5x5 windows, i.e. it is
+    # unchanged by a morphological opening with that window
+    d = (y == 0).float()
+    eroded = 1.0 - torch.nn.functional.max_pool2d(1.0 - d, 5, 1, 2)
+    assert torch.equal(torch.nn.functional.max_pool2d(eroded, 5, 1, 2), d)
+    assert torch.equal(db.eval()(x), x)
+    with pytest.raises(ValueError):
+        DropBlock2d(p=0.1, block_size=4)
+
+
+def test_frozen_backbone_and_drop_block_configs():
+    """ "YOLOv5s_dropBlock0.5_frozeBackbone" (README.md:133): no gradient and no statistics update in the backbone."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.profiling import count_flops, count_params, model_summary
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant="n", num_classes=4, img_size=64,
+                                backbone=dict(type="CSPDarknet", variant="n", frozen=True),
+                                neck=dict(type="YOLOv5PAFPN", depth=0.33, drop_block=dict(p=0.5, block_size=3))))
+    model.train()
+    assert not any(p.requires_grad for p in model.backbone.parameters())
+    assert all(not m.training for m in model.backbone.modules())
+    assert model.neck.training and model.neck.drop.training
+    rm0 = [m.running_mean.clone() for m in model.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    x = torch.rand((2, 3, 64, 64))
+    feats = model.extract(x)
+    sum(f.float().mean() for f in feats).backward()
+    assert all(p.grad is None for p in model.backbone.parameters())
+    assert any(p.grad is not None for p in model.neck.parameters())
+    rm1 = [m.running_mean for m in model.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert all(torch.equal(a, b) for a, b in zip(rm0, rm1))
+    assert any(bool((f == 0).any()) for f in feats)                 # DropBlock acted on the neck outputs
+    # FLOPs / Params (README.md:24): a 3x3 conv 8->16 on 10x10 = 2*16*10*10*8*9 FLOPs
+    conv = torch.nn.Conv2d(8, 16, 3, padding=1, bias=False)
+    flops, _ = count_flops(conv, lambda: conv(torch.zeros(1, 8, 10, 10)))
+    assert flops == 2 * 16 * 10 * 10 * 8 * 9 and count_params(conv) == 16 * 8 * 9
+    s = model_summary(model, lambda: model.extract(x))
+    assert s["params_M"] > 1.0 and s["gflops"] > 0.01
+    assert count_params(model, trainable_only=True) < count_params(model)
