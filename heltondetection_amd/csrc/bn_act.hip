@@ -28,9 +28,11 @@ struct RowVec;
 template <>
 struct RowVec<float> {
   static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4 r, float* v) {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+  }
   static __device__ __forceinline__ void load(const float* p, float* v) {
-    const float4 r = *reinterpret_cast<const float4*>(p);
-    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    unpack(*reinterpret_cast<const uint4*>(p), v);
   }
   static __device__ __forceinline__ void store(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -39,8 +41,7 @@ struct RowVec<float> {
 template <>
 struct RowVec<__hip_bfloat16> {
   static constexpr int N = 8;
-  static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
-    const uint4 r = *reinterpret_cast<const uint4*>(p);
+  static __device__ __forceinline__ void unpack(const uint4 r, float* v) {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -48,13 +49,18 @@ struct RowVec<__hip_bfloat16> {
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
+  static __device__ __forceinline__ void load(const __hip_bfloat16* p, float* v) {
+    unpack(*reinterpret_cast<const uint4*>(p), v);
+  }
   static __device__ __forceinline__ void store(__hip_bfloat16* p, const float* v) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
-      w[i] = (uint32_t)(*reinterpret_cast<const uint16_t*>(&lo)) |
-             ((uint32_t)(*reinterpret_cast<const uint16_t*>(&hi)) << 16);
+    for (int i = 0; i < 4; ++i) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even) per pair
+      const f32x2 f = {v[2 * i], v[2 * i + 1]};
+      const bf16x2 r = __builtin_convertvector(f, bf16x2);
+      w[i] = *reinterpret_cast<const uint32_t*>(&r);
     }
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
@@ -62,9 +68,15 @@ struct RowVec<__hip_bfloat16> {
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 
+// sigmoid via v_exp_f32 + v_rcp_f32 (1 ulp).  An IEEE division costs ~14 instruction slots here (the
+// library is built with -ffp-contract=off and no fast-math for the box kernels' sake), which made the
+// SiLU layers VALU-bound: ~100 cycles per element-wave against ~40 with the reciprocal.  The results are
+// rounded to bf16 / compared with PyTorch at 1e-2..1e-3, far above 1 ulp of fp32.
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z) {
-  if (ACT == ACT_SILU) return z / (1.0f + __expf(-z));
+  if (ACT == ACT_SILU) return z * fast_sigmoid(z);
   if (ACT == ACT_RELU) return z > 0.0f ? z : 0.0f;
   return z;
 }
@@ -72,8 +84,8 @@ __device__ __forceinline__ float act_fwd(float z) {
 template <int ACT>
 __device__ __forceinline__ float act_grad(float z) {
   if (ACT == ACT_SILU) {
-    const float s = 1.0f / (1.0f + __expf(-z));
-    return s * (1.0f + z * (1.0f - s));
+    const float s = fast_sigmoid(z);
+    return fmaf(z * s, 1.0f - s, s);  // s + z s (1 - s)
   }
   if (ACT == ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
@@ -86,15 +98,69 @@ constexpr int kMaxC = 4096;
 // below the spread-out rate, MI355X_MICROARCH 'Global float atomics'): a 22-25 us floor per launch.
 constexpr int kRep = 16;
 
+// Workgroup fold of per-lane channel partials a[V], b[V] (lane's channel group g, cg groups) into
+// global rows dst[0..C) and dst[C..2C).  Lanes of a wave that own the same group (cg < 64: lane % cg)
+// are first combined with a shuffle butterfly, each wave then parks its cg x V results in its own LDS
+// slot with plain stores, and the slots are summed while publishing: no LDS atomics.  (With
+// ds_add_f32 straight from every lane, C = 32 means 4 groups -> 16 lanes of a wave on one LDS address
+// for each of 2V instructions, a 16-way serialisation per workgroup that set the reduce kernels' floor.)
+// Requires blockDim.x == 256 and cg a power of two <= 256; other shapes use fold_atomic().
+template <int V>
+__device__ __forceinline__ void fold_slots(float* s_part /* [4][2C] */, float* a, float* b, int g, int cg, int C,
+                                           float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  for (int off = cg; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      a[k] += __shfl_xor(a[k], off, 64);
+      b[k] += __shfl_xor(b[k], off, 64);
+    }
+  }
+  const int span = cg < 64 ? 64 : cg;        // threads per full sweep of the groups
+  const int nslots = 256 / span;             // 4, 2 or 1
+  const int slot = threadIdx.x / span;
+  if (cg >= 64 || lane < cg) {
+    float* row = s_part + (size_t)slot * 2 * C;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      row[g * V + k] = a[k];
+      row[C + g * V + k] = b[k];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float v = s_part[i];
+    for (int sl = 1; sl < nslots; ++sl) v += s_part[(size_t)sl * 2 * C + i];
+    atomicAdd(&dst[i], v);
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void fold_atomic(float* s_acc /* [2C], zeroed */, const float* a, const float* b, int g,
+                                            int C, float* __restrict__ dst) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    atomicAdd(&s_acc[g * V + k], a[k]);
+    atomicAdd(&s_acc[C + g * V + k], b[k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&dst[i], s_acc[i]);
+}
+
+__device__ __forceinline__ bool fold_by_slots(int cg) { return blockDim.x == 256 && (cg & (cg - 1)) == 0; }
+
 // ---- forward statistics -------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long long nvec, int C,
                                                        float* __restrict__ sums /* [kRep, 2, C] */) {
   constexpr int V = RowVec<T>::N;
-  extern __shared__ float s_acc[];  // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.0f;
-  __syncthreads();
+  extern __shared__ float s_acc[];  // [4][2*C] wave slots (fold_slots) or [2*C] accumulators (fold_atomic)
   const int cg = C / V;
+  const bool slots = fold_by_slots(cg);
+  if (!slots) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.0f;
+    __syncthreads();
+  }
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = (int)(i0 % cg);
@@ -103,15 +169,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   for (int k = 0; k < V; ++k) s[k] = ss[k] = 0.0f;
   long long i = i0;
   for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
-    float v0[V], v1[V], v2[V], v3[V];
-    RowVec<T>::load(x + i * V, v0);
-    RowVec<T>::load(x + (i + stride) * V, v1);
-    RowVec<T>::load(x + (i + 2 * stride) * V, v2);
-    RowVec<T>::load(x + (i + 3 * stride) * V, v3);
+    uint4 raw[4];
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      s[k] += (v0[k] + v1[k]) + (v2[k] + v3[k]);
-      ss[k] += (v0[k] * v0[k] + v1[k] * v1[k]) + (v2[k] * v2[k] + v3[k] * v3[k]);
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[V];
+      RowVec<T>::unpack(raw[u], v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        s[k] += v[k];
+        ss[k] = fmaf(v[k], v[k], ss[k]);
+      }
     }
   }
   for (; i < nvec; i += stride) {
@@ -120,17 +189,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       s[k] += v[k];
-      ss[k] += v[k] * v[k];
+      ss[k] = fmaf(v[k], v[k], ss[k]);
     }
   }
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    atomicAdd(&s_acc[g * V + k], s[k]);
-    atomicAdd(&s_acc[C + g * V + k], ss[k]);
-  }
-  __syncthreads();
   float* dst = sums + (size_t)(blockIdx.x % kRep) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&dst[i], s_acc[i]);
+  if (slots) fold_slots<V>(s_acc, s, ss, g, cg, C, dst);
+  else fold_atomic<V>(s_acc, s, ss, g, C, dst);
 }
 
 __device__ __forceinline__ float rep_sum(const float* __restrict__ p, int idx, int C) {
@@ -178,11 +242,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     a[k] = s_coef[g * V + k];
     b[k] = s_coef[C + g * V + k];
   }
-  for (long long i = i0; i < nvec; i += stride) {
+  long long i = i0;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
+    float v[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) RowVec<T>::load(x + (i + u * stride) * V, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
+      RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+    }
+  }
+  for (; i < nvec; i += stride) {
     float v[V];
     RowVec<T>::load(x + i * V, v);
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(a[k] * v[k] + b[k]);
+    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(fmaf(a[k], v[k], b[k]));
     RowVec<T>::store(y + i * V, v);
   }
 }
@@ -211,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
     float v[V];
     RowVec<T>::load(x + i * V, v);
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(a[k] * v[k] + b[k]);
+    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(fmaf(a[k], v[k], b[k]));
     RowVec<T>::store(y + i * V, v);
   }
 }
@@ -227,37 +303,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             float* __restrict__ dsums /* [kRep,2,C]: dbeta, dgamma */) {
   constexpr int V = RowVec<T>::N;
   extern __shared__ float s_acc[];
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.0f;
-  __syncthreads();
   const int cg = C / V;
+  const bool slots = fold_by_slots(cg);
+  if (!slots) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.0f;
+    __syncthreads();
+  }
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = (int)(i0 % cg);
-  float mu[V], is[V], ga[V], be[V], s1[V], s2[V];
+  // per-channel constants folded so an element costs two FMAs besides act': xhat = is*x + c0, z = ga*xhat + be
+  float is[V], c0[V], ga[V], be[V], s1[V], s2[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int c = g * V + k;
-    mu[k] = save_mean[c];
     is[k] = save_invstd[c];
+    c0[k] = -save_mean[c] * is[k];
     ga[k] = gamma[c];
     be[k] = beta[c];
     s1[k] = s2[k] = 0.0f;
   }
   long long i = i0;
   for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
-    float xv[V], gv[V], xw[V], gw[V];
-    RowVec<T>::load(x + i * V, xv);
-    RowVec<T>::load(dy + i * V, gv);
-    RowVec<T>::load(x + (i + stride) * V, xw);
-    RowVec<T>::load(dy + (i + stride) * V, gw);
+    uint4 rx[2], rg[2];
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const float xh = (xv[k] - mu[k]) * is[k];
-      const float dz = gv[k] * act_grad<ACT>(ga[k] * xh + be[k]);
-      const float xh2 = (xw[k] - mu[k]) * is[k];
-      const float dz2 = gw[k] * act_grad<ACT>(ga[k] * xh2 + be[k]);
-      s1[k] += dz + dz2;
-      s2[k] += dz * xh + dz2 * xh2;
+    for (int u = 0; u < 2; ++u) {
+      rx[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
+      rg[u] = *reinterpret_cast<const uint4*>(dy + (i + u * stride) * V);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float xv[V], gv[V];
+      RowVec<T>::unpack(rx[u], xv);
+      RowVec<T>::unpack(rg[u], gv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = fmaf(is[k], xv[k], c0[k]);
+        const float dz = gv[k] * act_grad<ACT>(fmaf(ga[k], xh, be[k]));
+        s1[k] += dz;
+        s2[k] = fmaf(dz, xh, s2[k]);
+      }
     }
   }
   for (; i < nvec; i += stride) {
@@ -266,20 +351,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     RowVec<T>::load(dy + i * V, gv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const float xh = (xv[k] - mu[k]) * is[k];
-      const float dz = gv[k] * act_grad<ACT>(ga[k] * xh + be[k]);
+      const float xh = fmaf(is[k], xv[k], c0[k]);
+      const float dz = gv[k] * act_grad<ACT>(fmaf(ga[k], xh, be[k]));
       s1[k] += dz;
-      s2[k] += dz * xh;
+      s2[k] = fmaf(dz, xh, s2[k]);
     }
   }
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    atomicAdd(&s_acc[g * V + k], s1[k]);
-    atomicAdd(&s_acc[C + g * V + k], s2[k]);
-  }
-  __syncthreads();
   float* dst = dsums + (size_t)(blockIdx.x % kRep) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&dst[i], s_acc[i]);
+  if (slots) fold_slots<V>(s_acc, s1, s2, g, cg, C, dst);
+  else fold_atomic<V>(s_acc, s1, s2, g, C, dst);
 }
 
 template <typename T, int ACT>
@@ -307,26 +387,45 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
     }
   }
   __syncthreads();
-  float mu[V], is[V], ga[V], be[V], k1[V], k2[V];
+  // dx = ga*is*(dz - k1 - xhat*k2) with xhat = is*x + c0 and z = ga*xhat + be, folded per channel into
+  //   z = az*x + bz,   dx = A*dz + (P*x + Q):   three FMAs per element besides act'
+  float az[V], bz[V], A[V], P[V], Q[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int c = g * V + k;
-    mu[k] = save_mean[c];
-    is[k] = save_invstd[c];
-    ga[k] = gamma[c];
-    be[k] = beta[c];
-    k1[k] = s_coef[c];
-    k2[k] = s_coef[C + c];
+    const float is = save_invstd[c], c0 = -save_mean[c] * is, ga = gamma[c];
+    az[k] = ga * is;
+    bz[k] = fmaf(ga, c0, beta[c]);
+    A[k] = ga * is;
+    P[k] = -A[k] * s_coef[C + c] * is;
+    Q[k] = -A[k] * (s_coef[c] + s_coef[C + c] * c0);
   }
-  for (long long i = i0; i < nvec; i += stride) {
+  long long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
+    float xv[2][V], gv[2][V];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      RowVec<T>::load(x + (i + u * stride) * V, xv[u]);
+      RowVec<T>::load(dy + (i + u * stride) * V, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float dz = gv[u][k] * act_grad<ACT>(fmaf(az[k], xv[u][k], bz[k]));
+        xv[u][k] = fmaf(A[k], dz, fmaf(P[k], xv[u][k], Q[k]));
+      }
+      RowVec<T>::store(dx + (i + u * stride) * V, xv[u]);
+    }
+  }
+  for (; i < nvec; i += stride) {
     float xv[V], gv[V];
     RowVec<T>::load(x + i * V, xv);
     RowVec<T>::load(dy + i * V, gv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const float xh = (xv[k] - mu[k]) * is[k];
-      const float dz = gv[k] * act_grad<ACT>(ga[k] * xh + be[k]);
-      xv[k] = ga[k] * is[k] * (dz - k1[k] - xh * k2[k]);
+      const float dz = gv[k] * act_grad<ACT>(fmaf(az[k], xv[k], bz[k]));
+      xv[k] = fmaf(A[k], dz, fmaf(P[k], xv[k], Q[k]));
     }
     RowVec<T>::store(dx + i * V, xv);
   }
@@ -345,6 +444,13 @@ inline Launch plan(long long nvec, int cg, int max_blocks) {
   if (g < 1) g = 1;
   l.grid = (unsigned)g;
   return l;
+}
+
+// dynamic LDS of the reduce kernels: wave slots [256/max(cg,64)][2C] (fold_slots) or [2C] (fold_atomic)
+inline size_t reduce_lds_bytes(const Launch& l, int cg, int C) {
+  const bool slots = l.block == 256 && (cg & (cg - 1)) == 0;
+  const int nslots = slots ? 256 / (cg < 64 ? 64 : cg) : 1;
+  return (size_t)nslots * 2 * (size_t)C * sizeof(float);
 }
 
 inline hd_status common_checks(int dtype, long long R, int C) {
@@ -370,8 +476,8 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
   if (!hd_aligned16(x)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane: few workgroups -> few atomics
-  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
+  const size_t lds = reduce_lds_bytes(l, C / V, C);
   if (dtype == 0)
     hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,
                        reinterpret_cast<const float*>(x), nvec, C, sums);
@@ -438,8 +544,8 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dty
   if (!hd_aligned16(x) || !hd_aligned16(dy)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane: few workgroups -> few atomics
-  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
+  const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
 #define HD_RED(T, A, XT)                                                                                          \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<XT, A>), dim3(l.grid), dim3(l.block), lds, s,                         \
