@@ -241,6 +241,58 @@ def micro_kernels(device):
     return res
 
 
+def inference_leg(model, batches, args, device):
+    """Serving-side number for the same model: eval-mode forward (bf16 autocast, fused BN on running
+    statistics) + HIP decode + HIP per-class NMS, replayed from a hipGraph (static shapes: padded
+    detections + device-side counts), K images per replay.  Not the headline metric; reported beside it."""
+    was_training = model.training
+    model.eval()
+    img = batches[0][0]
+    try:
+        def run():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+                return model.forward_test(img, conf_thr=0.25, iou_thr=0.45, max_nms=30000, max_det=300)
+        for _ in range(3):
+            det, cnt = run()
+        torch.cuda.synchronize()
+        n = 30
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            det, cnt = run()
+        b.record()
+        torch.cuda.synchronize()
+        eager_ms = a.elapsed_time(b) / n
+        graph_ms = None
+        try:
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                run()
+            torch.cuda.current_stream(device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                det, cnt = run()
+            g.replay()
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(n):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            graph_ms = a.elapsed_time(b) / n
+        except Exception as e:  # eager number stands
+            print(f"[bench infer] graph capture failed: {e!r}"[:300], file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+        best = min(eager_ms, graph_ms) if graph_ms is not None else eager_ms
+        return {"images_per_s": round(args.batch / best * 1e3, 1), "ms_per_batch_eager": round(eager_ms, 3),
+                "ms_per_batch_hipgraph": None if graph_ms is None else round(graph_ms, 3), "batch": args.batch,
+                "pipeline": "eval forward (bf16) + hd_yolo_decode + hd_yolo_nms(conf 0.25, iou 0.45, max_det 300)",
+                "mean_detections": round(float(cnt.float().mean()), 1)}
+    finally:
+        model.train(was_training)
+
+
 def main():
     args = parse()
     from heltondetection_amd import ops
@@ -382,6 +434,11 @@ def main():
                 out["kernels"] = micro_kernels(device)
             except Exception as e:  # the headline number must survive a micro-leg problem
                 out["kernels_error"] = repr(e)
+        if world == 1 and not args.no_micro:
+            try:
+                out["inference"] = inference_leg(model, batches, args, device)
+            except Exception as e:
+                out["inference_error"] = repr(e)[:200]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
