@@ -323,11 +323,15 @@ def main():
 
     log(f"model+data ready on {torch.cuda.get_device_name(device)}; warm-up {args.warmup} steps "
         "(first steps include MIOpen kernel selection/compilation)")
+    eager_ms = []  # steady eager steps seen before the graph takes over (step 0 is MIOpen's search)
     for i in range(args.warmup):
         tw = time.perf_counter()
         trainer.step(*batches[i % len(batches)])
         torch.cuda.synchronize()
-        log(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
+        dt = (time.perf_counter() - tw) * 1e3
+        if i >= 1 and trainer._graph is None:
+            eager_ms.append(dt)
+        log(f"warm-up step {i}: {dt:.1f} ms")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -358,17 +362,22 @@ def main():
         if not (abs(l_graph - l_eager) <= 0.05 * abs(l_eager) + 1e-3):
             log(f"graph replay loss {l_graph} != eager loss {l_eager}")
             ok.zero_()
+    if graph_on and eager_ms and elapsed / args.steps * 1e3 > 2.5 * min(eager_ms):
+        # third guard: replays must not be slower than the eager steps they replace (a stall between the replay
+        # and the collectives would show up exactly like this, DESIGN.md §9 "second hazard")
+        log(f"graph-mode step {elapsed / args.steps * 1e3:.1f} ms vs eager {min(eager_ms):.1f} ms: falling back")
+        ok.zero_()
     if world > 1:  # every rank must take the same branch
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if graph_on and not bool(ok.item()):
         # safety net for the hipGraph path: never report a number from a corrupted run
-        log("non-finite loss after graph replays: rebuilding the trainer and re-timing eagerly")
+        log("hipGraph guard tripped (non-finite / mismatching loss or slow replays): rebuilding the trainer and re-timing eagerly")
         ops.disable_timing()
         model = build_detector(dict(type="YOLOv5", variant=args.variant, num_classes=args.classes,
                                     img_size=args.size)).to(device).to(memory_format=torch.channels_last).train()
         trainer = Trainer(model, lr=1e-3, amp_dtype=None if args.fp32 else torch.bfloat16,
                           total_steps=args.steps + args.warmup + 1, warmup_steps=3, device=device, use_graph=False)
-        trainer.graph_error = "non-finite loss under hipGraph replay; re-timed eagerly"
+        trainer.graph_error = "hipGraph guard tripped (loss check or replay slower than eager); re-timed eagerly"
         for i in range(args.warmup):
             trainer.step(*batches[i % len(batches)])
         elapsed, loss, graph_on = timed_region()

@@ -68,6 +68,10 @@ class Trainer:
             self.shadows = LowpShadows(model, amp_dtype)
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph,
                                    grad_sources=self.shadows.grad_sources() if self.shadows else None)
+        # With more than one rank the stream is drained after each replay, before the collectives are
+        # launched: an event recorded right after hipGraphLaunch is what the collective's stream waits on,
+        # and on this stack that event is observed seconds late on alternate replays.
+        self.graph_sync = self.graph_sync or self.reducer.world > 1
         decay, no_decay = [], []
         for n, p in model.named_parameters():
             if not p.requires_grad:
@@ -138,8 +142,8 @@ class Trainer:
                 dst.copy_(src, non_blocking=True)
             self._graph.replay()
             if self.graph_sync:
-                # optional belt-and-braces: drain the stream after every replay.  Not needed once the memset
-                # nodes are rewritten (1500-step soak clean without it); kept as a switch for debugging.
+                # single rank: off (not needed once the memset nodes are rewritten; 1500-step soak clean).
+                # multi rank: on, see __init__.
                 torch.cuda.current_stream(self.device).synchronize()
             loss, parts = self._static_out
         else:
