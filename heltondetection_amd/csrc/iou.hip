@@ -23,6 +23,8 @@
 //
 // Bit-exactness: hd_iou_full() evaluates the oracle's expression order with IEEE division
 // (hipcc's default) and no contraction, so values and argmax indices equal the CPU checker's.
+#include <algorithm>
+
 #include "hd_common.h"
 
 namespace {
@@ -213,13 +215,17 @@ __device__ __forceinline__ unsigned long long pack_key(float iou, int n) {
 template <bool WITH_GT>
 __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
     const float4* __restrict__ a, int64_t a_bstride4, const float4* __restrict__ b,
-    const int32_t* __restrict__ m_valid, int N, int M, int m_chunk0, float* __restrict__ max_iou,
+    const int32_t* __restrict__ m_valid, int N, int M, int m_chunk0, int lds_cap, float* __restrict__ max_iou,
     int32_t* __restrict__ argmax, unsigned long long* __restrict__ gt_key) {
   // One pass handles b boxes [m_chunk0, m_chunk0 + kAssignLdsMaxM); the host loops chunks for
   // M > kAssignLdsMaxM and the kernel then continues the running max held in max_iou/argmax.
-  __shared__ float4 s_box[kAssignLdsMaxM];
-  __shared__ float s_area[kAssignLdsMaxM];
-  __shared__ unsigned long long s_key[WITH_GT ? kAssignLdsMaxM : 1];
+  // Dynamic LDS sized by the host to the b boxes one pass really stages (lds_cap = min(M, kAssignLdsMaxM)
+  // rounded up to 4): with the static 56 KiB of the largest case only two workgroups fit a CU, which halved
+  // the throughput of this LDS-latency-bound loop for the common M = 20..500.
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  float4* s_box = reinterpret_cast<float4*>(s_raw);
+  float* s_area = reinterpret_cast<float*>(s_box + lds_cap);
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_area + lds_cap);  // WITH_GT only
   const int img = blockIdx.y;
   const int mv = m_valid ? min(m_valid[img], M) : M;
   const int m_end = min(mv, m_chunk0 + kAssignLdsMaxM);
@@ -293,8 +299,11 @@ __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
     __syncthreads();
     unsigned long long* gk = gt_key + (int64_t)img * M + m_chunk0;
     for (int m = threadIdx.x; m < mc; m += kAssignThreads) {
+      // Keys only grow, so a relaxed (possibly stale) read can only let a redundant atomic through, never
+      // hide an improving one.  Without the guard every workgroup sends M atomics onto the same few cache
+      // lines of its image (2048 workgroups x 500 b boxes: ~0.3 ms of serialised atomics at config 5).
       unsigned long long k = s_key[m];
-      if (k != 0ull) atomicMax(&gk[m], k);
+      if (k != 0ull && k > __hip_atomic_load(&gk[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gk[m], k);
     }
   }
 }
@@ -420,13 +429,15 @@ extern "C" hd_status hd_iou_assign(const float* a, int64_t a_bstride, const floa
     const float4* a4 = reinterpret_cast<const float4*>(a);
     const float4* b4 = reinterpret_cast<const float4*>(b);
     int chunk = 0;
+    const int lds_cap = std::max(4, (std::min(M, kAssignLdsMaxM) + 3) & ~3);
+    const size_t lds = (size_t)lds_cap * (sizeof(float4) + sizeof(float) + (with_gt ? sizeof(unsigned long long) : 0));
     do {
       if (with_gt)
-        hipLaunchKernelGGL((iou_assign_kernel<true>), grid, dim3(kAssignThreads), 0, s, a4, a_bstride / 4, b4,
-                           m_valid, N, M, chunk, max_iou, argmax, keys);
+        hipLaunchKernelGGL((iou_assign_kernel<true>), grid, dim3(kAssignThreads), lds, s, a4, a_bstride / 4, b4,
+                           m_valid, N, M, chunk, lds_cap, max_iou, argmax, keys);
       else
-        hipLaunchKernelGGL((iou_assign_kernel<false>), grid, dim3(kAssignThreads), 0, s, a4, a_bstride / 4, b4,
-                           m_valid, N, M, chunk, max_iou, argmax, keys);
+        hipLaunchKernelGGL((iou_assign_kernel<false>), grid, dim3(kAssignThreads), lds, s, a4, a_bstride / 4, b4,
+                           m_valid, N, M, chunk, lds_cap, max_iou, argmax, keys);
       HD_RETURN_IF_LAUNCH_FAILED();
       chunk += kAssignLdsMaxM;
     } while (chunk < M);
