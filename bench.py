@@ -200,6 +200,9 @@ def micro_kernels(device):
     b2 = torch.stack([syn.random_boxes(M2, 640.0, g) for _ in range(B2)]).to(device)
     ms = timeit(lambda: ops.iou_assign(a2, b2))
     add("iou_assign_kernel(+finalize)", ms, B2 * (16 * (N2 + M2) + 8 * N2), f"B={B2} N={N2} M={M2}", "valu")
+    ms = timeit(lambda: out_holder.__setitem__("o", ops.pairwise_iou(a2, b2)))
+    add("pairwise_iou_kernel (flat, M < 48)", ms, B2 * (16 * (N2 + M2) + 4 * N2 * M2), f"B={B2} N={N2} M={M2}")
+    out_holder.clear()
     # YOLOv5 decode bs16 640^2 C=80
     views, strides, anchors = _yolo_views(16, 640, 85, device)
     ms = timeit(lambda: ops.yolo_decode(views, strides, anchors))

@@ -31,7 +31,8 @@ namespace {
 
 constexpr int kIouThreads = 256;
 constexpr int kIouIters = 8;          // 256 lanes * 4 outputs * 8 = 8192 outputs per workgroup
-constexpr int kIouLdsMaxM = 3072;     // 3072 * (16 + 4) B = 60 KiB of LDS
+constexpr int kIouLdsMaxM = 48;       // the flat kernel only runs for M < 48 (hd_pairwise_iou): < 1 KiB of LDS,
+                                      // not the 60 KiB that limited a CU to two workgroups
 
 template <bool USE_LDS, bool VEC4>
 __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
