@@ -29,7 +29,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const float* __restrict_
                                                         const float4* __restrict__ anchors, int NA, RpnLevels lv,
                                                         int pre_nms_topk, float min_size, float img_h, float img_w,
                                                         CoreWs w, float4* __restrict__ cand_box,
-                                                        int32_t* __restrict__ cand_cls) {
+                                                        int32_t* __restrict__ cand_cls, int stage_cap) {
   __shared__ int s_hist[256];
   __shared__ u64 s_prefix;
   __shared__ int s_need;
@@ -100,20 +100,57 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const float* __restrict_
     thr = prefix;
   }
   u64* keys = w.keys + (size_t)b * w.key_cap;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  // Selected keys are staged in LDS (positions from an LDS counter, one ds_add per wave via a ballot) and the
+  // image's global counter is bumped ONCE per workgroup: n_keys[] of all images share a cache line, and one
+  // returning atomic per selected anchor (up to pre_nms_topk x levels x images of them) serialised there.
+  // stage_cap == 0 (pre_nms_topk too large for LDS): the old per-anchor reservation.
+  extern __shared__ u64 s_stage[];
+  __shared__ int s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int n_round = (n + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;  // whole waves reach the ballot
+#pragma unroll 2
+  for (int i = threadIdx.x; i < n_round; i += blockDim.x) {
     const int gi = off + i;
-    const float v = lg[gi];
-    const u64 key = make_key(v, (uint32_t)gi);
-    if (key >= thr) {
-      const float4 bx = hd_delta_decode(anchors[gi], deltas[(size_t)b * NA + gi], img_h, img_w);
-      if ((bx.z - bx.x >= min_size) && (bx.w - bx.y >= min_size)) {
-        cand_box[(size_t)b * NA + gi] = bx;
-        cand_cls[(size_t)b * NA + gi] = l;
-        const int pos = atomicAdd(&w.n_keys[b], 1);
-        if (pos < w.key_cap) keys[pos] = key;
+    bool take = false;
+    u64 key = 0ull;
+    if (i < n) {
+      const float v = lg[gi];
+      key = make_key(v, (uint32_t)gi);
+      if (key >= thr) {
+        const float4 bx = hd_delta_decode(anchors[gi], deltas[(size_t)b * NA + gi], img_h, img_w);
+        if ((bx.z - bx.x >= min_size) && (bx.w - bx.y >= min_size)) {
+          cand_box[(size_t)b * NA + gi] = bx;
+          cand_cls[(size_t)b * NA + gi] = l;
+          take = true;
+        }
       }
     }
+    if (stage_cap > 0) {
+      const u64 m = __ballot(take);
+      if (m != 0ull) {
+        int base = 0;
+        if (lane == (int)(__ffsll((long long)m) - 1)) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (take) {
+          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < stage_cap) s_stage[pos] = key;
+        }
+      }
+    } else if (take) {
+      const int pos = atomicAdd(&w.n_keys[b], 1);
+      if (pos < w.key_cap) keys[pos] = key;
+    }
+  }
+  if (stage_cap > 0) {
+    __syncthreads();
+    const int cnt = min(s_cnt, stage_cap);
+    if (threadIdx.x == 0) s_base = atomicAdd(&w.n_keys[b], cnt);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+      if (base + i < w.key_cap) keys[base + i] = s_stage[i];
   }
 }
 
@@ -205,9 +242,11 @@ extern "C" hd_status hd_rpn_proposals(const float* logits, const float* deltas, 
   if (workspace_bytes < r.bytes + w.bytes) return HD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
-  hipLaunchKernelGGL(rpn_topk_kernel, dim3(n_levels, B), dim3(1024), 0, s, logits,
+  // LDS staging of the selected keys: at most pre_nms_topk per (level, image); 6144 keys = 48 KiB
+  const int stage_cap = pre_nms_topk <= 6144 ? pre_nms_topk : 0;
+  hipLaunchKernelGGL(rpn_topk_kernel, dim3(n_levels, B), dim3(1024), (size_t)stage_cap * sizeof(u64), s, logits,
                      reinterpret_cast<const float4*>(deltas), reinterpret_cast<const float4*>(anchors), NA, lv,
-                     pre_nms_topk, min_size, img_h, img_w, w, r.cand_box, r.cand_cls);
+                     pre_nms_topk, min_size, img_h, img_w, w, r.cand_box, r.cand_cls, stage_cap);
   HD_RETURN_IF_LAUNCH_FAILED();
   hd_status st = run_core(w, B, r.cand_box, r.cand_cls, (long long)NA, iou_thr, post_nms_topk, r.keep, count, s);
   if (st != HD_OK) return st;
