@@ -292,10 +292,22 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
   }
 }
 
+// Address of vector i of dy.  dy may be a channel slice of a wider channels-last tensor (the gradient of
+// a torch.cat input: rows of C channels, row stride ld > C), which saves the .contiguous() copy autograd
+// would otherwise need in front of every such BatchNorm; ld == C is the dense case (no division).
+template <typename T>
+__device__ __forceinline__ const T* dy_at(const T* dy, long long i, int cg, int C, long long ld) {
+  constexpr int V = RowVec<T>::N;
+  if (ld == C) return dy + i * V;
+  const uint32_t r = (uint32_t)i / (uint32_t)cg;
+  const uint32_t g = (uint32_t)i - r * (uint32_t)cg;
+  return dy + (long long)r * ld + (long long)g * V;
+}
+
 // ---- backward reductions ------------------------------------------------------------------------
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            long long nvec, int C,
+                                                            long long ld_dy, long long nvec, int C,
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_invstd,
                                                             const float* __restrict__ gamma,
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       rx[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
-      rg[u] = *reinterpret_cast<const uint4*>(dy + (i + u * stride) * V);
+      rg[u] = *reinterpret_cast<const uint4*>(dy_at(dy, i + u * stride, cg, C, ld_dy));
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (; i < nvec; i += stride) {
     float xv[V], gv[V];
     RowVec<T>::load(x + i * V, xv);
-    RowVec<T>::load(dy + i * V, gv);
+    RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float xh = fmaf(is[k], xv[k], c0[k]);
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                        long long nvec, int C, float inv_R,
+                                                        long long ld_dy, long long nvec, int C, float inv_R,
                                                         const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd,
                                                         const float* __restrict__ gamma,
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       RowVec<T>::load(x + (i + u * stride) * V, xv[u]);
-      RowVec<T>::load(dy + (i + u * stride) * V, gv[u]);
+      RowVec<T>::load(dy_at(dy, i + u * stride, cg, C, ld_dy), gv[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
   for (; i < nvec; i += stride) {
     float xv[V], gv[V];
     RowVec<T>::load(x + i * V, xv);
-    RowVec<T>::load(dy + i * V, gv);
+    RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float dz = gv[k] * act_grad<ACT>(fmaf(az[k], xv[k], bz[k]));
@@ -535,8 +547,16 @@ extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C,
   return HD_OK;
 }
 
-extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dtype, int64_t R, int C,
-                                          const float* save_mean, const float* save_invstd, const float* gamma,
+// dy_row_stride: elements between consecutive rows of dy (0 or C = dense; > C = channel slice of a wider tensor)
+static hd_status check_dy_stride(int64_t dy_row_stride, int C, int V, long long nvec, int64_t* ld) {
+  *ld = dy_row_stride == 0 ? C : dy_row_stride;
+  if (*ld < C || *ld % V != 0) return HD_ERR_SHAPE;
+  if (*ld != C && nvec >= (1ll << 31)) return HD_ERR_SHAPE;  // the strided path indexes with 32-bit row numbers
+  return HD_OK;
+}
+
+extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
+                                          int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                           const float* beta, int act, float* dsums, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
@@ -544,13 +564,16 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dty
   if (!hd_aligned16(x) || !hd_aligned16(dy)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
+  int64_t ld = 0;
+  st = check_dy_stride(dy_row_stride, C, V, nvec, &ld);
+  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
 #define HD_RED(T, A, XT)                                                                                          \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<XT, A>), dim3(l.grid), dim3(l.block), lds, s,                         \
-                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), nvec, C, save_mean,        \
-                     save_invstd, gamma, beta, dsums)
+                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), (long long)ld, nvec, C,    \
+                     save_mean, save_invstd, gamma, beta, dsums)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_RED, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_RED, __hip_bfloat16);
 #undef HD_RED
@@ -558,8 +581,8 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dty
   return HD_OK;
 }
 
-extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, int64_t R, int C,
-                                      const float* save_mean, const float* save_invstd, const float* gamma,
+extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
+                                      int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                       const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                                       float* dbeta, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
@@ -569,12 +592,15 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, 
   if (!hd_aligned16(x) || !hd_aligned16(dy) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
+  int64_t ld = 0;
+  st = check_dy_stride(dy_row_stride, C, V, nvec, &ld);
+  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   const float inv_R = 1.0f / (float)R;
   hipStream_t s = (hipStream_t)stream;
 #define HD_DX(T, A, XT)                                                                                           \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<XT, A>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, reinterpret_cast<const XT*>(x), \
-                     reinterpret_cast<const XT*>(dy), nvec, C, inv_R, save_mean, save_invstd, gamma, beta, dsums,  \
+                     reinterpret_cast<const XT*>(dy), (long long)ld, nvec, C, inv_R, save_mean, save_invstd, gamma, beta, dsums,  \
                      reinterpret_cast<XT*>(dx), dgamma, dbeta)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_DX, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_DX, __hip_bfloat16);

@@ -675,6 +675,24 @@ def bn_act_supported(x: torch.Tensor) -> bool:
     return C % v == 0 and C // v <= 256 and x.is_contiguous(memory_format=torch.channels_last)
 
 
+def _cl_row_stride(t: torch.Tensor, vec: int):
+    """Row stride (elements) of a [B,C,H,W] tensor whose memory is channels-last rows of >= C channels —
+    dense channels-last, or a channel slice of a wider channels-last tensor (a torch.cat input's gradient).
+    None when the layout is anything else or the 16-byte vector accesses would be misaligned."""
+    B, Cc, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if Cc > 1 and sc != 1:
+        return None
+    ld = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else Cc))
+    if ld < Cc or ld % vec != 0:
+        return None
+    if (W > 1 and sw != ld) or (H > 1 and sh != W * ld) or (B > 1 and sb != H * W * ld):
+        return None
+    if (t.data_ptr() % 16) != 0:
+        return None
+    return ld
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot):
@@ -705,7 +723,12 @@ class _BNActFn(torch.autograd.Function):
         lib = _lib.load()
         x, w, b, save = ctx.saved_tensors
         dt, R, Cc, act, slot = ctx.meta
-        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        ld = _cl_row_stride(dy, 4 if dt == 0 else 8)
+        if ld is None:  # not (a channel slice of) a channels-last tensor: one copy
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            ld = Cc
         rep = lib.hd_bn_act_replicas()
         dsums = slot.buf[rep * 2 * Cc: rep * 4 * Cc]
         if slot.bwd_gen == slot.arena.gen:
@@ -714,9 +737,9 @@ class _BNActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
-        check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
+        check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
                                        act, _ptr(dsums), st), "hd_bn_act_bwd_reduce")
-        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), act,
+        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), act,
                                    _ptr(dsums), _ptr(dx), _ptr(dg[0]), _ptr(dg[1]), st), "hd_bn_act_bwd_dx")
         return dx, dg[0], dg[1], None, None, None, None, None, None
 

@@ -347,10 +347,12 @@ hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C, const floa
 hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var,
                           float eps, int act, void* y, hd_stream stream);
-hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int dtype, int64_t R, int C,
+/* dy_row_stride: elements between consecutive rows of dy; 0 (or C) = dense rows, > C = dy is a channel slice
+ * of a wider channels-last tensor (the gradient of a concatenation input), multiple of the vector width. */
+hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
                                const float* save_mean, const float* save_invstd, const float* gamma,
                                const float* beta, int act, float* dsums, hd_stream stream);
-hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int dtype, int64_t R, int C,
+hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
                            const float* save_mean, const float* save_invstd, const float* gamma,
                            const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                            float* dbeta, hd_stream stream);

@@ -431,6 +431,44 @@ def test_bn_act_matches_torch(gpu, ops, dtype, act, C):
     assert H.rel_err(yi.float().cpu().numpy(), yir.numpy()) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_backward_reads_cat_gradient_slices_in_place(gpu, ops, dtype):
+    """Two fused BN+SiLU outputs go through torch.cat (as in every C3 block): their backward passes receive
+    channel slices of the concatenation's gradient (row stride 2C) and must read them in place — same
+    gradients as the float64 reference, and no copy of the slice (ops._cl_row_stride recognises it)."""
+    g = torch.Generator().manual_seed(131)
+    B, C, Hh, Ww = 3, 32, 7, 10
+    xs = [(torch.randn((B, C, Hh, Ww), generator=g) * 1.2).to(dtype) for _ in range(2)]
+    ws = [torch.rand(C, generator=g) + 0.5 for _ in range(2)]
+    bs = [torch.randn(C, generator=g) * 0.2 for _ in range(2)]
+    go = torch.randn((B, 2 * C, Hh, Ww), generator=g).to(dtype)
+    # reference
+    xr = [x.double().requires_grad_(True) for x in xs]
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    yr = torch.cat([torch.nn.functional.silu(torch.nn.functional.batch_norm(x, None, None, w, b, True, 0.03, 1e-3))
+                    for x, w, b in zip(xr, wr, br)], 1)
+    yr.backward(go.double())
+    # HIP
+    xd = [x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in xs]
+    wd = [w.to(gpu).requires_grad_(True) for w in ws]
+    bd = [b.to(gpu).requires_grad_(True) for b in bs]
+    ops.bn_arena_reset(gpu)
+    y = torch.cat([ops.bn_act(x, w, b, None, None, 1e-3, 0.03, "silu", True) for x, w, b in zip(xd, wd, bd)], 1)
+    god = go.to(gpu).contiguous(memory_format=torch.channels_last)
+    sl = god[:, C:]
+    vec = 4 if dtype == torch.float32 else 8
+    assert ops._cl_row_stride(sl, vec) == 2 * C and ops._cl_row_stride(god, vec) == 2 * C
+    assert ops._cl_row_stride(god[:, 4:4 + C], 8) is None or dtype == torch.float32  # misaligned for 16-byte bf16 vectors
+    y.backward(god)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    for k in range(2):
+        assert H.rel_err(xd[k].grad.float().cpu().numpy(), xr[k].grad.numpy()) < tol
+        assert H.rel_err(wd[k].grad.cpu().numpy(), wr[k].grad.numpy()) < tol
+        assert H.rel_err(bd[k].grad.cpu().numpy(), br[k].grad.numpy()) < tol
+
+
 # ------------------------------------------------------------------------------- hipGraph memset rewrite
 def test_graph_memset_nodes_are_rewritten(gpu, ops):
     """Capture a small graph containing real hipMemsetAsync calls (1-byte pattern on an odd length, 4-byte
