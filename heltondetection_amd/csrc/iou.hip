@@ -34,23 +34,21 @@ constexpr int kIouIters = 8;          // 256 lanes * 4 outputs * 8 = 8192 output
 constexpr int kIouLdsMaxM = 48;       // the flat kernel only runs for M < 48 (hd_pairwise_iou): < 1 KiB of LDS,
                                       // not the 60 KiB that limited a CU to two workgroups
 
-template <bool USE_LDS, bool VEC4>
+template <bool VEC4>
 __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
     const float4* __restrict__ a, int64_t a_bstride4, const float4* __restrict__ b,
     const int32_t* __restrict__ m_valid, int N, int M, float* __restrict__ out) {
-  __shared__ float4 s_box[USE_LDS ? kIouLdsMaxM : 1];
-  __shared__ float s_area[USE_LDS ? kIouLdsMaxM : 1];
+  __shared__ float4 s_box[kIouLdsMaxM];
+  __shared__ float s_area[kIouLdsMaxM];
   const int img = blockIdx.y;
   const int mv = m_valid ? min(m_valid[img], M) : M;
   const float4* bb = b + (int64_t)img * M;
-  if (USE_LDS) {
-    for (int m = threadIdx.x; m < M; m += kIouThreads) {
-      float4 v = bb[m];
-      s_box[m] = v;
-      s_area[m] = hd_box_area(v);
-    }
-    __syncthreads();
+  for (int m = threadIdx.x; m < M; m += kIouThreads) {
+    float4 v = bb[m];
+    s_box[m] = v;
+    s_area[m] = hd_box_area(v);
   }
+  __syncthreads();
   const int64_t T = (int64_t)N * M;
   const float4* aa = a + (int64_t)img * a_bstride4;
   float* o = out + (int64_t)img * T;
@@ -68,8 +66,8 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
     for (int k = 0; k < 4; ++k) {
       if (e0 + k < T) {
         if (m < mv) {
-          float4 gb = USE_LDS ? s_box[m] : bb[m];
-          float garea = USE_LDS ? s_area[m] : hd_box_area(gb);
+          float4 gb = s_box[m];
+          float garea = s_area[m];
           r[k] = hd_iou_full(ab, aarea, gb, garea);
         } else {
           r[k] = -1.0f;
@@ -381,15 +379,13 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
   if (gx > 0x7fffffff) return HD_ERR_SHAPE;
   dim3 grid((unsigned)gx, (unsigned)B);
   const bool vec = (T % 4 == 0) && hd_aligned16(out);
-  const bool lds = M <= kIouLdsMaxM;
   const float4* a4 = reinterpret_cast<const float4*>(a);
   const float4* b4 = reinterpret_cast<const float4*>(b);
-#define HD_LAUNCH_PIOU(L, V) \
-  hipLaunchKernelGGL((pairwise_iou_kernel<L, V>), grid, dim3(kIouThreads), 0, s, a4, a_bstride / 4, b4, m_valid, N, M, out)
-  if (lds && vec) HD_LAUNCH_PIOU(true, true);
-  else if (lds) HD_LAUNCH_PIOU(true, false);
-  else if (vec) HD_LAUNCH_PIOU(false, true);
-  else HD_LAUNCH_PIOU(false, false);
+  static_assert(kIouLdsMaxM >= 48, "the flat kernel stages all M < 48 b boxes in LDS");
+#define HD_LAUNCH_PIOU(V) \
+  hipLaunchKernelGGL((pairwise_iou_kernel<V>), grid, dim3(kIouThreads), 0, s, a4, a_bstride / 4, b4, m_valid, N, M, out)
+  if (vec) HD_LAUNCH_PIOU(true);
+  else HD_LAUNCH_PIOU(false);
 #undef HD_LAUNCH_PIOU
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;

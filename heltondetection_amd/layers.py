@@ -68,7 +68,6 @@ class ConvBNAct(nn.Module):
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act
-        self._slot = None
 
     def forward(self, x):
         y = self.conv(x)
