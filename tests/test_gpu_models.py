@@ -187,3 +187,31 @@ def test_yolov5_frozen_backbone_dropblock_trains_under_graph(gpu):
     assert np.isfinite(losses).all()
     assert all(torch.equal(a, b) for a, b in zip(bb0, model.backbone.parameters()))
     assert any(not torch.equal(a, b) for a, b in zip(nk0, model.neck.parameters()))
+
+
+def test_graphed_detector_replays_match_eager(gpu):
+    """serve.GraphedDetector: eval forward + HIP decode + HIP NMS replayed from a hipGraph give the eager
+    path's detections on new inputs of the captured shape, and other shapes fall back to eager."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.serve import GraphedDetector
+    from heltondetection_amd import synthetic as syn
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160)).to(gpu)
+    model = model.to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():  # lift the objectness prior so random weights produce detections to compare
+        for conv in model.head.m:
+            conv.bias.view(model.head.na, -1)[:, 4] += 6.0
+    g = syn.make_generator(5)
+    imgs = [syn.make_images(4, 160, g).to(gpu).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    gd = GraphedDetector(model, imgs[0], conf_thr=0.05, iou_thr=0.45, max_nms=2000, max_det=50)
+    assert gd.graph_nodes > 50
+    for im in imgs:
+        det, cnt = gd(im)
+        det, cnt = det.clone(), cnt.clone()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            d2, c2 = model.forward_test(im, conf_thr=0.05, iou_thr=0.45, max_nms=2000, max_det=50)
+        assert int(cnt.sum()) > 0
+        assert torch.equal(cnt, c2) and torch.equal(det, d2)
+    other = syn.make_images(2, 160, g).to(gpu).contiguous(memory_format=torch.channels_last)
+    det, cnt = gd(other)                      # different batch size: eager fallback
+    assert det.shape[0] == 2
