@@ -216,6 +216,14 @@ def micro_kernels(device):
     add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 4,
         "B=16 n=25200 conf=0.9: ~15 candidates per image (detector-like pass rate; reads the objectness column)",
         "latency")
+    # Mosaic-4 on the batch resident in HBM (the step before the hot path)
+    from heltondetection_amd.augment import Mosaic
+    mimg = syn.make_images(16, 640, g).to(device).contiguous(memory_format=torch.channels_last)
+    mgb, mgc, mmv = [t.to(device) for t in syn.make_targets(16, 640, g, "coco", 80, 40)]
+    msrc, mctr, mapl = Mosaic(p=1.0, generator=torch.Generator(device=device).manual_seed(0)).draw(16, 640, device)
+    ms = timeit(lambda: ops.mosaic4(mimg, mgb, mgc, mmv, msrc, mctr, mapl))
+    add("mosaic4 (image + boxes)", ms, 5 * 16 * 3 * 640 * 640 * 4, "B=16 640x640 p=1 (4 reads + 1 write per element)")
+    del mimg
     # NMS at RPN-like sizes
     for Nn in (2000, 8000):
         bx = torch.stack([syn.random_boxes(Nn, 832.0, g, 16.0, 300.0) for _ in range(16)]).to(device)

@@ -768,6 +768,34 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
     return y
 
 
+# ------------------------------------------------------------------------------- Mosaic-4
+def mosaic4(images: torch.Tensor, gt_boxes: torch.Tensor, gt_cls: torch.Tensor, m_valid: torch.Tensor,
+            src: torch.Tensor, center: torch.Tensor, apply: torch.Tensor, fill: float = 114.0 / 255.0,
+            min_wh: float = 2.0, min_area_ratio: float = 0.1):
+    """Mosaic-4 on device (csrc/mosaic.hip; convention in DESIGN.md section 2).  images [B,3,S,S] float32 (any
+    strides; the output keeps the input's memory format), gt_boxes [B,M,4], gt_cls [B,M] int32, m_valid [B] int32,
+    src [B,4] / center [B,2] / apply [B] int32.  -> (images', boxes [B,4M,4], cls [B,4M], count [B])."""
+    lib = _lib.load()
+    if not images.is_cuda or images.dtype != _F32 or images.dim() != 4 or images.shape[1] != 3 or \
+            images.shape[2] != images.shape[3]:
+        raise _lib.HdError("mosaic4: images must be a float32 [B,3,S,S] tensor on a HIP device")
+    gt_boxes, gt_cls, m_valid = _need(gt_boxes, _F32, "gt_boxes"), _need(gt_cls, _I32, "gt_cls"), _need(m_valid, _I32, "m_valid")
+    src, center, apply = _need(src, _I32, "src"), _need(center, _I32, "center"), _need(apply, _I32, "apply")
+    B, _, S, _ = images.shape
+    M = gt_boxes.shape[1]
+    out = torch.empty_like(images)  # preserves channels-last / planar strides
+    st = _stream(images)
+    check(lib.hd_mosaic4(_ptr(images), *images.stride(), B, S, _ptr(src), _ptr(center), _ptr(apply), float(fill),
+                         _ptr(out), *out.stride(), st), "hd_mosaic4")
+    ob = torch.empty((B, 4 * M, 4), dtype=_F32, device=images.device)
+    oc = torch.empty((B, 4 * M), dtype=_I32, device=images.device)
+    cnt = torch.empty((B,), dtype=_I32, device=images.device)
+    check(lib.hd_mosaic4_boxes(_ptr(gt_boxes), _ptr(gt_cls), _ptr(m_valid), B, M, S, _ptr(src), _ptr(center),
+                               _ptr(apply), float(min_wh), float(min_area_ratio), _ptr(ob), _ptr(oc), _ptr(cnt), st),
+          "hd_mosaic4_boxes")
+    return out, ob, oc, cnt
+
+
 # ------------------------------------------------------------------------------- hipGraph hygiene
 def graph_replace_memsets(raw_graph) -> Tuple[int, int]:
     """raw_graph: the hipGraph_t of a captured but not yet instantiated graph

@@ -357,6 +357,24 @@ hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride,
                            const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                            float* dbeta, hd_stream stream);
 
+/* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
+
+/* images/out: float32 [B,3,S,S] with element strides (b,c,y,x); S even; out must not alias images.
+ * src [B,4] int32 = source image of tile TL, TR, BL, BR (indices into the batch); center [B,2] int32 =
+ * (xc, yc) on the 2S x 2S canvas, in [S/2, 3S/2]; apply [B] int32 (0: out[b] = images[src[b][0]]).
+ * out(x,y) = mean of the 2x2 canvas pixels at (2x, 2y); uncovered canvas = fill. */
+hd_status hd_mosaic4(const float* images, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int S,
+                     const int32_t* src, const int32_t* center, const int32_t* apply, float fill,
+                     float* out, int64_t ob, int64_t oc, int64_t oy, int64_t ox, hd_stream stream);
+
+/* Boxes of the same mosaic: shift, clip to the tile's visible rectangle, halve; keep iff w > min_wh and
+ * h > min_wh and clipped area / original area > min_area_ratio.  gt_boxes [B,M,4] xyxy, gt_cls [B,M],
+ * m_valid [B] -> out_boxes [B,4M,4], out_cls [B,4M] (zero padded), out_count [B]; order: tile, then source. */
+hd_status hd_mosaic4_boxes(const float* gt_boxes, const int32_t* gt_cls, const int32_t* m_valid, int B, int M,
+                           int S, const int32_t* src, const int32_t* center, const int32_t* apply,
+                           float min_wh, float min_area_ratio, float* out_boxes, int32_t* out_cls,
+                           int32_t* out_count, hd_stream stream);
+
 /* ---- hipGraph hygiene ------------------------------------------------------------------------ */
 
 /* Replaces every memset node of a captured, NOT YET INSTANTIATED hipGraph_t by an equivalent

@@ -378,3 +378,24 @@ def wbf(boxes, scores, labels, model_weight, k_valid, weight_sum, iou_thr=0.55, 
     lib().orc_wbf(_p(boxes), _p(scores), _p(labels), _p(mw), _p(kv), C.c_int(B), C.c_int(K), C.c_float(weight_sum),
                   C.c_float(iou_thr), C.c_float(skip_thr), _p(out), _p(cnt))
     return out, cnt
+
+
+# ---------------------------------------------------------------------------- Mosaic-4
+def mosaic4(images, gt_boxes, gt_cls, m_valid, src, center, apply, fill=114.0 / 255.0, min_wh=2.0, min_area_ratio=0.1):
+    """images [B,3,S,S] f32 (logical NCHW); src [B,4], center [B,2], apply [B] int32.
+    -> (out images [B,3,S,S], boxes [B,4M,4], cls [B,4M], count [B])."""
+    images = _f(images)
+    gt_boxes, gt_cls, m_valid = _f(gt_boxes), _i(gt_cls), _i(m_valid)
+    src, center, apply = _i(src), _i(center), _i(apply)
+    B, _, S, _ = images.shape
+    M = gt_boxes.shape[1]
+    out = np.empty_like(images)
+    lib().orc_mosaic4(_p(images), C.c_int64(3 * S * S), C.c_int64(S * S), C.c_int64(S), C.c_int64(1), C.c_int(B), C.c_int(S),
+                      _p(src), _p(center), _p(apply), C.c_float(fill), _p(out), C.c_int64(3 * S * S), C.c_int64(S * S),
+                      C.c_int64(S), C.c_int64(1))
+    ob = np.empty((B, 4 * M, 4), np.float32)
+    oc = np.empty((B, 4 * M), np.int32)
+    cnt = np.empty((B,), np.int32)
+    lib().orc_mosaic4_boxes(_p(gt_boxes), _p(gt_cls), _p(m_valid), C.c_int(B), C.c_int(M), C.c_int(S), _p(src), _p(center),
+                            _p(apply), C.c_float(min_wh), C.c_float(min_area_ratio), _p(ob), _p(oc), _p(cnt))
+    return out, ob, oc, cnt

@@ -921,4 +921,97 @@ void orc_wbf(const float* boxes, const float* scores, const int32_t* labels,
   free(srt); free(cl); free(rec);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Mosaic-4 on device (README.md:76-77,129-130 list Mosaic p=0.5/1.0 as the main augmentation; the
+ * reference's augmentation code is not in the snapshot, so this is this repo's frozen convention,
+ * DESIGN.md section 2 item 12).
+ *   canvas 2S x 2S, centre (xc, yc) integer in [S/2, 3S/2]; tile k = (u >= xc) + 2 (v >= yc) shows source
+ *   image src[k] translated by (ox, oy) = (xc - S | xc, yc - S | yc); uncovered canvas = fill;
+ *   out(x, y) = ((c(2x,2y) + c(2x+1,2y)) + (c(2x,2y+1) + c(2x+1,2y+1))) * 0.25
+ *   boxes: shift by (ox, oy), clip to the tile's visible rectangle, halve; keep iff w > min_wh, h > min_wh and
+ *   clipped area / original area > min_area_ratio; output order tile-major then source order.
+ *   apply[b] == 0: image src[b][0] and its boxes pass through unchanged.
+ * images / out: float32, element strides (b, c, y, x) given.
+ * ---------------------------------------------------------------------------------------- */
+static void mosaic_tile(int k, int xc, int yc, int S, int* ox, int* oy, int* lx, int* ly, int* hx, int* hy) {
+  *ox = (k & 1) ? xc : xc - S;
+  *oy = (k & 2) ? yc : yc - S;
+  *lx = (k & 1) ? xc : (*ox > 0 ? *ox : 0);
+  *hx = (k & 1) ? ((*ox + S) < 2 * S ? (*ox + S) : 2 * S) : xc;
+  *ly = (k & 2) ? yc : (*oy > 0 ? *oy : 0);
+  *hy = (k & 2) ? ((*oy + S) < 2 * S ? (*oy + S) : 2 * S) : yc;
+}
+
+void orc_mosaic4(const float* images, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int S,
+                 const int32_t* src, const int32_t* center, const int32_t* apply, float fill, float* out,
+                 int64_t ob, int64_t oc, int64_t oy_, int64_t ox_) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < 3; ++c)
+      for (int y = 0; y < S; ++y)
+        for (int x = 0; x < S; ++x) {
+          float* o = out + b * ob + c * oc + y * oy_ + x * ox_;
+          if (!apply[b]) {
+            *o = images[(int64_t)src[b * 4] * sb + c * sc + y * sy + x * sx];
+            continue;
+          }
+          int xc = center[b * 2], yc = center[b * 2 + 1];
+          float p[4];
+          for (int q = 0; q < 4; ++q) {
+            int u = 2 * x + (q & 1), v = 2 * y + (q >> 1);
+            int k = (u >= xc) + 2 * (v >= yc);
+            int ox = (k & 1) ? xc : xc - S, oy = (k & 2) ? yc : yc - S;
+            int su = u - ox, sv = v - oy;
+            p[q] = (su >= 0 && su < S && sv >= 0 && sv < S)
+                       ? images[(int64_t)src[b * 4 + k] * sb + c * sc + sv * sy + su * sx] : fill;
+          }
+          *o = ((p[0] + p[1]) + (p[2] + p[3])) * 0.25f;
+        }
+}
+
+void orc_mosaic4_boxes(const float* gt_boxes, const int32_t* gt_cls, const int32_t* m_valid, int B, int M, int S,
+                       const int32_t* src, const int32_t* center, const int32_t* apply, float min_wh,
+                       float min_area_ratio, float* out_boxes, int32_t* out_cls, int32_t* out_count) {
+  const int K = 4 * M;
+  for (int b = 0; b < B; ++b) {
+    int n = 0;
+    float* ob = out_boxes + (int64_t)b * K * 4;
+    int32_t* oc = out_cls + (int64_t)b * K;
+    if (!apply[b]) {
+      int s = src[b * 4];
+      int mv = m_valid[s] < M ? m_valid[s] : M;
+      for (int t = 0; t < mv; ++t) {
+        for (int j = 0; j < 4; ++j) ob[n * 4 + j] = gt_boxes[((int64_t)s * M + t) * 4 + j];
+        oc[n++] = gt_cls[(int64_t)s * M + t];
+      }
+    } else {
+      int xc = center[b * 2], yc = center[b * 2 + 1];
+      for (int k = 0; k < 4; ++k) {
+        int ox, oy, lx, ly, hx, hy;
+        mosaic_tile(k, xc, yc, S, &ox, &oy, &lx, &ly, &hx, &hy);
+        int s = src[b * 4 + k];
+        int mv = m_valid[s] < M ? m_valid[s] : M;
+        for (int t = 0; t < mv; ++t) {
+          const float* g = gt_boxes + ((int64_t)s * M + t) * 4;
+          float x1 = g[0] + (float)ox, y1 = g[1] + (float)oy, x2 = g[2] + (float)ox, y2 = g[3] + (float)oy;
+          float area0 = (x2 - x1) * (y2 - y1);
+          x1 = fminf(fmaxf(x1, (float)lx), (float)hx); x2 = fminf(fmaxf(x2, (float)lx), (float)hx);
+          y1 = fminf(fmaxf(y1, (float)ly), (float)hy); y2 = fminf(fmaxf(y2, (float)ly), (float)hy);
+          x1 *= 0.5f; y1 *= 0.5f; x2 *= 0.5f; y2 *= 0.5f;
+          float w = x2 - x1, h = y2 - y1;
+          int keep = (w > min_wh) && (h > min_wh) && ((w * h) * 4.0f > min_area_ratio * area0);
+          if (keep) {
+            ob[n * 4 + 0] = x1; ob[n * 4 + 1] = y1; ob[n * 4 + 2] = x2; ob[n * 4 + 3] = y2;
+            oc[n++] = gt_cls[(int64_t)s * M + t];
+          }
+        }
+      }
+    }
+    out_count[b] = n;
+    for (int i = n; i < K; ++i) {
+      ob[i * 4 + 0] = ob[i * 4 + 1] = ob[i * 4 + 2] = ob[i * 4 + 3] = 0.0f;
+      oc[i] = 0;
+    }
+  }
+}
+
 int orc_version(void) { return 1; }

@@ -459,3 +459,51 @@ def wbf_single(boxes, scores, labels, model_weight, weight_sum, iou_thr=0.55, sk
         out[i, 4] = r[0]
         out[i, 5] = r[1]
     return out
+
+
+# ------------------------------------------------------------------------------- Mosaic-4
+def mosaic4(images, gt_boxes, gt_cls, m_valid, src, center, apply, fill=114.0 / 255.0, min_wh=2.0, min_area_ratio=0.1):
+    """Independent restatement of the Mosaic-4 convention: builds the 2S x 2S canvas by
+    pasting whole source images with slice arithmetic (later tiles never overlap earlier ones), then averages
+    2x2 blocks in the order ((tl + tr) + (bl + br)) * 0.25."""
+    B, _, S, _ = images.shape
+    M = gt_boxes.shape[1]
+    out = torch.empty_like(images)
+    ob = torch.zeros((B, 4 * M, 4))
+    oc = torch.zeros((B, 4 * M), dtype=torch.int32)
+    cnt = torch.zeros((B,), dtype=torch.int32)
+    for b in range(B):
+        if not int(apply[b]):
+            s0 = int(src[b, 0])
+            out[b] = images[s0]
+            n = min(int(m_valid[s0]), M)
+            ob[b, :n], oc[b, :n], cnt[b] = gt_boxes[s0, :n], gt_cls[s0, :n], n
+            continue
+        xc, yc = int(center[b, 0]), int(center[b, 1])
+        canvas = torch.full((3, 2 * S, 2 * S), float(fill), dtype=images.dtype)
+        boxes, classes = [], []
+        for k in range(4):
+            ox = xc if (k & 1) else xc - S
+            oy = yc if (k & 2) else yc - S
+            # visible rectangle of this tile on the canvas
+            lx, hx = (xc, min(ox + S, 2 * S)) if (k & 1) else (max(ox, 0), xc)
+            ly, hy = (yc, min(oy + S, 2 * S)) if (k & 2) else (max(oy, 0), yc)
+            s_ = int(src[b, k])
+            if hx > lx and hy > ly:
+                canvas[:, ly:hy, lx:hx] = images[s_][:, ly - oy:hy - oy, lx - ox:hx - ox]
+            n = min(int(m_valid[s_]), M)
+            if n:
+                g = gt_boxes[s_, :n].clone()
+                area0 = (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
+                g[:, [0, 2]] = (g[:, [0, 2]] + float(ox)).clamp(float(lx), float(hx))
+                g[:, [1, 3]] = (g[:, [1, 3]] + float(oy)).clamp(float(ly), float(hy))
+                g = g * 0.5
+                w, h = g[:, 2] - g[:, 0], g[:, 3] - g[:, 1]
+                keep = (w > min_wh) & (h > min_wh) & ((w * h) * 4.0 > min_area_ratio * area0)
+                boxes.append(g[keep])
+                classes.append(gt_cls[s_, :n][keep])
+        out[b] = ((canvas[:, 0::2, 0::2] + canvas[:, 0::2, 1::2]) + (canvas[:, 1::2, 0::2] + canvas[:, 1::2, 1::2])) * 0.25
+        if boxes:
+            bb, cc = torch.cat(boxes), torch.cat(classes)
+            ob[b, : bb.shape[0]], oc[b, : bb.shape[0]], cnt[b] = bb, cc.to(torch.int32), bb.shape[0]
+    return out, ob, oc, cnt

@@ -143,6 +143,20 @@ def main():
         assert o2.shape[0] == wc[bi], "oracles disagree on wbf count"
         agree(wo[bi, : wc[bi]], o2, 1e-5, "wbf")
     d.update(wbf_boxes=wb.numpy(), wbf_scores=ws_.numpy(), wbf_labels=wl.numpy(), wbf_out=wo, wbf_count=wc)
+    # Mosaic-4
+    g = syn.make_generator(12)
+    mi = syn.make_images(4, 32, g)
+    mb, mc, mm = syn.make_targets(4, 32, g, "coco", 5, 6)
+    msrc = torch.stack([torch.tensor([b] + torch.randint(0, 4, (3,), generator=g).tolist()) for b in range(4)]).to(torch.int32)
+    mctr = torch.randint(16, 49, (4, 2), generator=g, dtype=torch.int32)
+    mapl = torch.tensor([1, 0, 1, 1], dtype=torch.int32)
+    mo = co.mosaic4(mi.numpy(), mb.numpy(), mc.numpy(), mm.numpy(), msrc.numpy(), mctr.numpy(), mapl.numpy(), min_wh=1.0)
+    mo2 = tr.mosaic4(mi, mb, mc, mm, msrc, mctr, mapl, min_wh=1.0)
+    for a_, b_, nm in zip(mo, mo2, ("image", "boxes", "cls", "count")):
+        agree(a_, b_.numpy(), 0.0, "mosaic " + nm)
+    d.update(mos_img=mi.numpy(), mos_boxes=mb.numpy(), mos_cls=mc.numpy(), mos_mv=mm.numpy(), mos_src=msrc.numpy(),
+             mos_center=mctr.numpy(), mos_apply=mapl.numpy(), mos_out=mo[0], mos_out_boxes=mo[1], mos_out_cls=mo[2],
+             mos_out_count=mo[3])
     np.savez_compressed(OUT, **d)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(d), "arrays")
 

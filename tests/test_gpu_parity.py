@@ -507,3 +507,64 @@ def test_graph_memset_nodes_are_rewritten(gpu, ops):
         assert torch.equal(y.cpu(), torch.arange(64, dtype=torch.float32) * 2)   # b was already zero when added
     nodes2, replaced2 = ops.graph_replace_memsets(g.raw_cuda_graph())
     assert replaced2 == 0
+
+
+# ------------------------------------------------------------------------------- Mosaic-4
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_mosaic4_matches_oracle(gpu, ops, layout):
+    """Pixels, boxes, classes and counts bit-exact (integer tile offsets, fixed summation order)."""
+    from heltondetection_amd import synthetic as syn
+    g = syn.make_generator(141)
+    B, S, M = 6, 64, 9
+    img = syn.make_images(B, S, g)
+    gtb, gtc, mv = syn.make_targets(B, S, g, "coco", 7, M)
+    src = torch.stack([torch.tensor([b] + torch.randint(0, B, (3,), generator=g).tolist()) for b in range(B)]).to(torch.int32)
+    center = torch.randint(S // 2, 3 * S // 2 + 1, (B, 2), generator=g, dtype=torch.int32)
+    center[0] = torch.tensor([S // 2, 3 * S // 2])      # extreme corners of the allowed range
+    center[1] = torch.tensor([3 * S // 2, S // 2])
+    apply = torch.tensor([1, 1, 0, 1, 1, 1], dtype=torch.int32)
+    ref = co.mosaic4(img.numpy(), gtb.numpy(), gtc.numpy(), mv.numpy(), src.numpy(), center.numpy(), apply.numpy(),
+                     min_wh=1.0)
+    imd = dev(img, gpu)
+    if layout == "nhwc":
+        imd = imd.contiguous(memory_format=torch.channels_last)
+    out, ob, oc, cnt = ops.mosaic4(imd, dev(gtb, gpu), dev(gtc, gpu), dev(mv, gpu), dev(src, gpu), dev(center, gpu),
+                                   dev(apply, gpu), min_wh=1.0)
+    assert out.stride() == imd.stride()
+    assert np.array_equal(out.cpu().numpy(), ref[0])
+    assert np.array_equal(cnt.cpu().numpy(), ref[3]) and ref[3].max() > M          # more boxes than one image had
+    assert np.array_equal(ob.cpu().numpy(), ref[1]) and np.array_equal(oc.cpu().numpy(), ref[2])
+    # pass-through image is untouched; mosaic boxes stay inside the image
+    assert torch.equal(out[2], imd[int(src[2, 0])])
+    v = ob[apply.bool().to(gpu)]
+    assert float(v.min()) >= 0.0 and float(v.max()) <= S
+
+
+def test_mosaic_module_draws_on_device_and_feeds_the_assigner(gpu, ops):
+    """augment.Mosaic: device-side draws (reproducible with a device generator), p=0 is the identity on images and
+    boxes, p=1 changes every image, and its padded output is consumed by the YOLOv5 assigner unchanged."""
+    from heltondetection_amd import synthetic as syn
+    from heltondetection_amd.augment import Mosaic
+    g = syn.make_generator(142)
+    B, S, M = 8, 128, 12
+    img = dev(syn.make_images(B, S, g), gpu).contiguous(memory_format=torch.channels_last)
+    gtb, gtc, mv = [dev(t, gpu) for t in syn.make_targets(B, S, g, "coco", 8, M)]
+    ident = Mosaic(p=0.0)(img, gtb, gtc, mv)
+    assert torch.equal(ident[0], img) and torch.equal(ident[3], mv)
+    for b in range(B):
+        n = int(mv[b])
+        assert torch.equal(ident[1][b, :n], gtb[b, :n]) and torch.equal(ident[2][b, :n], gtc[b, :n])
+    outs = []
+    for _ in range(2):
+        dg = torch.Generator(device=gpu).manual_seed(7)
+        outs.append(Mosaic(p=1.0, max_boxes=2 * M, generator=dg)(img, gtb, gtc, mv))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))               # same generator state, same batch
+    o_img, o_box, o_cls, o_cnt = outs[0]
+    assert o_box.shape == (B, 2 * M, 4) and int(o_cnt.max()) <= 2 * M
+    assert all(not torch.equal(o_img[b], img[b]) for b in range(B))
+    src, center, apply = Mosaic(p=0.5, generator=torch.Generator(device=gpu).manual_seed(3)).draw(64, S, gpu)
+    assert bool((src[:, 0] == torch.arange(64, device=gpu)).all()) and bool((src[:, 1:] != src[:, :1]).all())
+    assert int(center.min()) >= S // 2 and int(center.max()) <= 3 * S // 2 and 8 < int(apply.sum()) < 56
+    shapes = H.yolo_shapes(S, 13)
+    cell, tbox, cls = ops.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, o_box, o_cls, o_cnt, 4.0)
+    assert int((cell >= 0).sum()) > 0

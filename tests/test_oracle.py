@@ -123,6 +123,43 @@ def test_golden_ciou_and_wbf(gold):
     assert np.array_equal(out, gold["wbf_out"]) and np.array_equal(cnt, gold["wbf_count"])
 
 
+def test_golden_mosaic(gold):
+    out = co.mosaic4(gold["mos_img"], gold["mos_boxes"], gold["mos_cls"], gold["mos_mv"], gold["mos_src"],
+                     gold["mos_center"], gold["mos_apply"], min_wh=1.0)
+    assert np.array_equal(out[0], gold["mos_out"]) and np.array_equal(out[1], gold["mos_out_boxes"])
+    assert np.array_equal(out[2], gold["mos_out_cls"]) and np.array_equal(out[3], gold["mos_out_count"])
+
+
+def test_mosaic_known_answers():
+    """Centre at (S, S): the four images tile the canvas exactly and each lands, halved, in one output quadrant."""
+    S = 8
+    imgs = np.stack([np.full((3, S, S), v, np.float32) for v in (0.1, 0.2, 0.3, 0.4)])
+    boxes = np.zeros((4, 2, 4), np.float32)
+    boxes[:, 0] = [2.0, 2.0, 6.0, 8.0]
+    cls = np.arange(8, dtype=np.int32).reshape(4, 2)
+    mv = np.array([1, 1, 1, 1], np.int32)
+    src = np.array([[0, 1, 2, 3]] * 4, np.int32)
+    out, ob, oc, cnt = co.mosaic4(imgs, boxes, cls, mv, src, np.full((4, 2), S, np.int32), np.array([1, 0, 0, 0], np.int32),
+                                  min_wh=0.5)
+    h = S // 2
+    assert np.all(out[0, :, :h, :h] == np.float32(0.1)) and np.all(out[0, :, :h, h:] == np.float32(0.2))
+    assert np.all(out[0, :, h:, :h] == np.float32(0.3)) and np.all(out[0, :, h:, h:] == np.float32(0.4))
+    assert cnt[0] == 4 and list(oc[0, :4]) == [0, 2, 4, 6]
+    assert np.array_equal(ob[0, 0], [1, 1, 3, 4]) and np.array_equal(ob[0, 1], [5, 1, 7, 4])
+    assert np.array_equal(ob[0, 2], [1, 5, 3, 8]) and np.array_equal(ob[0, 3], [5, 5, 7, 8])
+    assert np.array_equal(out[1], imgs[0]) and cnt[1] == 1 and np.array_equal(ob[1, 0], boxes[0, 0])  # pass-through
+    # centre in a corner of its range: three tiles are mostly off-canvas, uncovered pixels take the fill value,
+    # and a box cut to under 10 % of its area (or under min_wh) is dropped
+    boxes2 = boxes.copy()
+    boxes2[0, 0] = [0.0, 0.0, 3.0, 3.0]   # lies in the part of the top-left tile that is off the canvas
+    out, ob, oc, cnt = co.mosaic4(imgs, boxes2, cls, mv, src, np.full((4, 2), S // 2, np.int32),
+                                  np.ones(4, np.int32), fill=0.5, min_wh=0.5)
+    assert np.all(out[0, :, :2, :2] == np.float32(0.1)) and np.all(out[0, :, 6:, 6:] == np.float32(0.5))
+    assert cnt[0] == 3 and list(oc[0, :3]) == [2, 4, 6]
+    # the top-right tile's box (2,2,6,8) -> canvas (6,-2,10,4) -> clipped (6,0,10,4) -> halved
+    assert np.array_equal(ob[0, 0], [3, 0, 5, 2])
+
+
 # ---------------------------------------------------------------- cross-implementation, fresh seeds
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_c_vs_torch_restatement_random(seed):
