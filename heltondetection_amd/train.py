@@ -56,8 +56,12 @@ class Trainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
                  use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = False,
-                 lowp_weights: bool = True):
+                 lowp_weights: bool = True, augment=None):
         self.model = model
+        # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head
+        # of every step (e.g. augment.Mosaic).  It is part of the captured region in hipGraph mode, so it must
+        # draw its random numbers on the device with the default generator (graph-safe Philox offsets).
+        self.augment = augment
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
@@ -96,6 +100,9 @@ class Trainer:
             from . import ops
             ops.bn_arena_reset(self.device)  # one kernel clears every fused-BN statistics slot
         use_amp = self.amp_dtype is not None and self.device.type == "cuda"
+        if self.augment is not None:
+            with torch.no_grad():
+                images, gt_boxes, gt_cls, m_valid = self.augment(images, gt_boxes, gt_cls, m_valid)
         if self.shadows is not None:
             self.shadows.refresh()
         LowpWeights.on = self.shadows is not None

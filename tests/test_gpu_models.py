@@ -215,3 +215,22 @@ def test_graphed_detector_replays_match_eager(gpu):
     other = syn.make_images(2, 160, g).to(gpu).contiguous(memory_format=torch.channels_last)
     det, cnt = gd(other)                      # different batch size: eager fallback
     assert det.shape[0] == 2
+
+
+def test_training_step_with_device_mosaic_captures_and_varies(gpu):
+    """augment.Mosaic inside the hipGraph-replayed step: the draws come from the default device generator, so
+    replays see fresh mosaics (the loss sequence on a constant batch is not constant) and stay finite."""
+    from heltondetection_amd.augment import Mosaic
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160)).to(gpu)
+    model = model.to(memory_format=torch.channels_last).train()
+    tr = Trainer(model, lr=0.0, total_steps=40, warmup_steps=1, device=gpu, use_graph=True,
+                 augment=Mosaic(p=1.0, max_boxes=16))
+    batch = _batch(4, 160, 8, 3, gpu, m_pad=8)
+    losses = [float(tr.step(*batch)[0]) for _ in range(12)]
+    assert tr._graph is not None, tr.graph_error
+    assert np.isfinite(losses).all()
+    replayed = losses[4:]
+    assert len(set(round(v, 5) for v in replayed)) > 3   # lr = 0: only the augmentation changes between replays
