@@ -21,20 +21,30 @@ from .evaluator import MeanAP
 
 
 def write_synthetic_coco(root: str, n_images: int, size: int, num_classes: int = 80, seed: int = 0,
-                         style: str = "coco", max_boxes: int = 40, write_pixels: bool = True) -> str:
+                         style: str = "coco", max_boxes: int = 40, write_pixels: bool = True,
+                         paint: bool = False) -> str:
     """Writes `root/images/%06d.png` (uniform-noise RGB, the synthetic images of SURVEY.md §8d) and
-    `root/annotations.json`; returns the annotation path.  Deterministic in `seed`."""
+    `root/annotations.json`; returns the annotation path.  Deterministic in `seed`.
+    paint=True draws every box as a rectangle in its class colour over the noise (later boxes on top), which
+    gives a detector something to learn; the default keeps the pure-noise images of the measurement spec."""
     os.makedirs(os.path.join(root, "images"), exist_ok=True)
     g = syn.make_generator(seed)
     images, annotations = [], []
     ann_id = 1
     for i in range(n_images):
         name = f"{i:06d}.png"
+        noise = syn.make_images(1, size, g)[0] if write_pixels else None
+        gtb, gtc, mv = syn.make_targets(1, size, g, style, num_classes, max_boxes)
         if write_pixels:
             from PIL import Image
-            px = (syn.make_images(1, size, g)[0].permute(1, 2, 0) * 255.0).round().clamp(0, 255).to(torch.uint8).numpy()
+            if paint:
+                for k in range(int(mv[0])):
+                    x1, y1, x2, y2 = [int(round(float(v))) for v in gtb[0, k]]
+                    c = int(gtc[0, k])
+                    colour = torch.tensor([((c * 37) % 97) / 96.0, ((c * 59 + 31) % 89) / 88.0, ((c * 83 + 7) % 101) / 100.0])
+                    noise[:, y1:y2, x1:x2] = 0.85 * colour[:, None, None] + 0.15 * noise[:, y1:y2, x1:x2]
+            px = (noise.permute(1, 2, 0) * 255.0).round().clamp(0, 255).to(torch.uint8).numpy()
             Image.fromarray(px, "RGB").save(os.path.join(root, "images", name))
-        gtb, gtc, mv = syn.make_targets(1, size, g, style, num_classes, max_boxes)
         images.append({"id": i + 1, "file_name": name, "width": size, "height": size})
         for k in range(int(mv[0])):
             x1, y1, x2, y2 = [float(v) for v in gtb[0, k]]
