@@ -500,7 +500,9 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
   return HD_OK;
 }
 
-extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C, const float* sums,
+// stat_rows: number of rows the sums cover (0 = R).  Larger than R when the caller all-reduced the sums across
+// ranks between _stats and _apply (synchronised BatchNorm): mean/var then are the global ones.
+extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows, int C, const float* sums,
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                      int act, void* y, hd_stream stream) {
@@ -512,8 +514,9 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C,
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
-  const float inv_R = 1.0f / (float)R;
-  const float unbias = R > 1 ? (float)R / (float)(R - 1) : 1.0f;
+  const int64_t RS = stat_rows > 0 ? stat_rows : R;
+  const float inv_R = 1.0f / (float)RS;
+  const float unbias = RS > 1 ? (float)RS / (float)(RS - 1) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
 #define HD_APPLY(T, A, XT)                                                                                         \
   hipLaunchKernelGGL((bn_apply_kernel<XT, A>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, reinterpret_cast<const XT*>(x), \
@@ -582,7 +585,7 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t
 }
 
 extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
-                                      int C, const float* save_mean, const float* save_invstd, const float* gamma,
+                                      int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                       const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                                       float* dbeta, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
@@ -596,7 +599,7 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_
   st = check_dy_stride(dy_row_stride, C, V, nvec, &ld);
   if (st != HD_OK) return st;
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
-  const float inv_R = 1.0f / (float)R;
+  const float inv_R = 1.0f / (float)(stat_rows > 0 ? stat_rows : R);
   hipStream_t s = (hipStream_t)stream;
 #define HD_DX(T, A, XT)                                                                                           \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<XT, A>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, reinterpret_cast<const XT*>(x), \

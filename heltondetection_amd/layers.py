@@ -40,6 +40,10 @@ class FusedBNAct:
     plain torch modules.  One statistics slot per BatchNorm2d module is kept in `_slots`."""
 
     enabled = True
+    # SyncBN (SURVEY.md §8e, optional second exchange): set to a torch.distributed process group and every fused
+    # BatchNorm takes its batch statistics over the shards of all ranks in the group.  Eager mode only: the
+    # all-reduce sits between two kernels of the layer, so such a step is not captured into a hipGraph.
+    sync_group = None
     _ACTS = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}
 
     @staticmethod
@@ -53,7 +57,8 @@ class FusedBNAct:
                     bn._hd_slot = slot
                 training = bn.training or bn.running_mean is None
                 return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                  bn.momentum if bn.momentum is not None else 0.1, act, training, slot)
+                                  bn.momentum if bn.momentum is not None else 0.1, act, training, slot,
+                                  FusedBNAct.sync_group if training else None)
         return FusedBNAct._ACTS[act](bn(x))
 
 

@@ -695,7 +695,7 @@ def _cl_row_stride(t: torch.Tensor, vec: int):
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None):
         lib = _lib.load()
         B, Cc, H, W = x.shape
         R = B * H * W
@@ -711,18 +711,25 @@ class _BNActFn(torch.autograd.Function):
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
         check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
-        check(lib.hd_bn_act_apply(_ptr(x), dt, R, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
+        stat_rows = 0
+        if sync_group is not None:
+            # synchronised BatchNorm: the per-channel (sum, sum of squares) of every rank are added between the
+            # statistics kernel and the apply kernel; ranks hold equal shards, so the sums cover R * world rows
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=sync_group)
+            stat_rows = R * dist.get_world_size(sync_group)
+        check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
                                   _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
                                   _ptr(y), st), "hd_bn_act_apply")
         ctx.save_for_backward(x, w, b, save)
-        ctx.meta = (dt, R, Cc, int(act), slot)
+        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x, w, b, save = ctx.saved_tensors
-        dt, R, Cc, act, slot = ctx.meta
+        dt, R, Cc, act, slot, sync_group, stat_rows = ctx.meta
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         ld = _cl_row_stride(dy, 4 if dt == 0 else 8)
@@ -739,9 +746,18 @@ class _BNActFn(torch.autograd.Function):
         st = _stream(x)
         check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
                                        act, _ptr(dsums), st), "hd_bn_act_bwd_reduce")
-        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), act,
-                                   _ptr(dsums), _ptr(dx), _ptr(dg[0]), _ptr(dg[1]), st), "hd_bn_act_bwd_dx")
-        return dx, dg[0], dg[1], None, None, None, None, None, None
+        local = None
+        if sync_group is not None:
+            # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
+            # parameter gradient); dx needs the sums over the whole synchronised batch
+            import torch.distributed as dist
+            local = dsums.view(rep, 2, Cc).sum(0)
+            dist.all_reduce(dsums, group=sync_group)
+        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
+                                   _ptr(b), act, _ptr(dsums), _ptr(dx), _ptr(dg[0]), _ptr(dg[1]), st), "hd_bn_act_bwd_dx")
+        if local is not None:
+            return dx, local[1], local[0], None, None, None, None, None, None, None
+        return dx, dg[0], dg[1], None, None, None, None, None, None, None
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:
@@ -750,15 +766,17 @@ def bn_act_slot(device, channels: int) -> _StatSlot:
 
 
 def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: float, act: str, training: bool,
-           slot: Optional[_StatSlot] = None) -> torch.Tensor:
-    """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip)."""
+           slot: Optional[_StatSlot] = None, sync_group=None) -> torch.Tensor:
+    """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip).
+    sync_group: a torch.distributed process group -> statistics (and the backward sums) are taken over the
+    batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable."""
     if not bn_act_supported(x):
         raise _lib.HdError("bn_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0")
     code = _ACT_CODE[act]
     if training:
         if slot is None:
             slot = bn_act_slot(x.device, x.shape[1])
-        return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot)
+        return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot, sync_group)
     lib = _lib.load()
     B, Cc, H, W = x.shape
     y = torch.empty_like(x)

@@ -65,6 +65,9 @@ class Trainer:
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        from .layers import FusedBNAct
+        if FusedBNAct.sync_group is not None:  # SyncBN all-reduces inside the layer: not capturable
+            self.use_graph = False
         self.graph_sync = bool(graph_sync)
         # bf16 weight shadows only make sense where autocast would otherwise cast per call
         self.shadows = None

@@ -340,7 +340,9 @@ hd_status hd_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, i
  *             dz = dy*act'(z) with z recomputed from x; _bwd_dx writes dx and dgamma/dbeta. */
 int hd_bn_act_replicas(void);
 hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C, float* sums, hd_stream stream);
-hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int C, const float* sums,
+/* stat_rows (apply, bwd_dx): rows the (d)sums cover; 0 = R.  > R when the caller all-reduced the sums across
+ * ranks between the two launches (synchronised BatchNorm over a data-parallel group). */
+hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows, int C, const float* sums,
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean,
                           float* save_invstd, int act, void* y, hd_stream stream);
@@ -352,8 +354,8 @@ hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const floa
 hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
                                const float* save_mean, const float* save_invstd, const float* gamma,
                                const float* beta, int act, float* dsums, hd_stream stream);
-hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
-                           const float* save_mean, const float* save_invstd, const float* gamma,
+hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
+                           int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
                            const float* beta, int act, const float* dsums, void* dx, float* dgamma,
                            float* dbeta, hd_stream stream);
 
