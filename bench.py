@@ -224,6 +224,14 @@ def micro_kernels(device):
     ms = timeit(lambda: ops.mosaic4(mimg, mgb, mgc, mmv, msrc, mctr, mapl))
     add("mosaic4 (image + boxes)", ms, 5 * 16 * 3 * 640 * 640 * 4, "B=16 640x640 p=1 (4 reads + 1 write per element)")
     del mimg
+    # WBF at config-5 density: 3 TTA views x ~500 objects of 10 classes per image
+    wb0 = torch.stack([syn.random_boxes(500, 1280.0, g, 4.0, 64.0) for _ in range(8)])
+    wbx = torch.cat([wb0 + torch.randn(wb0.shape, generator=g) * 1.5 for _ in range(3)], 1).clamp(0, 1280.0).to(device)
+    wsc = (torch.rand((8, 1500), generator=g) * 0.7 + 0.3).to(device)
+    wlb = torch.randint(0, 10, (8, 500), generator=g, dtype=torch.int32).repeat(1, 3).to(device)
+    wmw = torch.ones((8, 1500), device=device)
+    ms = timeit(lambda: ops.wbf(wbx, wsc, wlb, wmw, None, 3.0, 0.55, 0.05))
+    add("wbf (sort + per-label clustering + sort)", ms, 8 * 1500 * 24, "B=8 K=1500 (3 views x 500 objects, 10 classes)", "latency")
     # NMS at RPN-like sizes
     for Nn in (2000, 8000):
         bx = torch.stack([syn.random_boxes(Nn, 832.0, g, 16.0, 300.0) for _ in range(16)]).to(device)

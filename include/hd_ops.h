@@ -310,7 +310,8 @@ hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float conf_thr, fl
  * the fused box is the confidence-weighted mean (conf = score*model_weight), fused score =
  * sum(conf)/n * min(n, weight_sum)/weight_sum with weight_sum = sum of the view weights
  * (= number of views when all weights are 1; "avg" confidence).  out [B,K,6] = (x1,y1,x2,y2,score,label) sorted by
- * score descending (ties -> lower label, then older cluster), zero padded; out_count [B]. */
+ * score descending (ties -> lower label, then older cluster), zero padded; out_count [B].
+ * Limits: 0 <= label < 4096, K <= 2^20. */
 size_t hd_wbf_workspace_bytes(int B, int K);
 hd_status hd_wbf(const float* boxes, const float* scores, const int32_t* labels,
                  const float* model_weight, const int32_t* k_valid, int B, int K, float weight_sum,
