@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const float* __restrict_
     const int row = r0 + lane;
     const float my_obj = row < n ? base[(size_t)row * no + 4] : 0.0f;
     unsigned long long pass = __ballot(row < n && my_obj > conf_thr);
+    // lane j ends up holding the result of row r0 + j; nothing on this serial part waits for an atomic
+    float my_conf = -1.0f;
+    int my_cls = 0;
     while (pass) {
       const int j = __ffsll((long long)pass) - 1;
       pass &= pass - 1;
@@ -65,14 +68,27 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const float* __restrict_
           bc = oc;
         }
       }
-      const float conf = obj * best;
-      if (lane == 0 && conf > conf_thr) {
+      if (lane == j) {
+        my_conf = obj * best;
+        my_cls = bc;
+      }
+    }
+    // one reservation per 64-row chunk (was: one returning atomic per candidate; the per-image counters of a
+    // batch share a cache line, and ~300k of those serialised into 3.8 ms on a dense batch), then every
+    // passing lane writes its own record
+    const bool take = my_conf > conf_thr;
+    const unsigned long long m = __ballot(take);
+    if (m != 0ull) {
+      int pos0 = 0;
+      if (lane == 0) pos0 = atomicAdd(&w.n_keys[b], __popcll(m));
+      pos0 = __shfl(pos0, 0, 64);
+      if (take) {
+        const float* r = base + (size_t)row * no;
         const float cx = r[0], cy = r[1], bw = r[2], bh = r[3];
-        cand_box[(size_t)b * n + i] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
-        cand_cls[(size_t)b * n + i] = bc;
-        cand_conf[(size_t)b * n + i] = conf;
-        const int pos = atomicAdd(&w.n_keys[b], 1);
-        keys[pos] = make_key(conf, (uint32_t)i);
+        cand_box[(size_t)b * n + row] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
+        cand_cls[(size_t)b * n + row] = my_cls;
+        cand_conf[(size_t)b * n + row] = my_conf;
+        keys[pos0 + __popcll(m & ((1ull << lane) - 1ull))] = make_key(my_conf, (uint32_t)row);
       }
     }
   }
