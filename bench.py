@@ -331,9 +331,12 @@ def main():
 
     model = build_detector(dict(type="YOLOv5", variant=args.variant, num_classes=args.classes, img_size=args.size))
     model = model.to(device).to(memory_format=torch.channels_last).train()
+    # the hipGraph is captured after `graph_warmup` eager steps (the first one runs MIOpen's solver search, which
+    # cannot happen inside a capture); keep that inside the untimed warm-up whatever --warmup is
+    graph_warmup = min(3, max(1, args.warmup - 1))
     trainer = Trainer(model, lr=1e-3, amp_dtype=None if args.fp32 else torch.bfloat16,
-                      total_steps=args.steps + args.warmup + 1, warmup_steps=3, device=device,
-                      use_graph=not args.no_graph, graph_sync=False)
+                      total_steps=args.steps + args.warmup + 8, warmup_steps=3, device=device,
+                      use_graph=not args.no_graph, graph_sync=False, graph_warmup=graph_warmup)
     batches = make_batches(4, args.batch, args.size, args.classes, 1234 + rank, device)
 
     def log(msg):
@@ -351,6 +354,14 @@ def main():
         if i >= 1 and trainer._graph is None:
             eager_ms.append(dt)
         log(f"warm-up step {i}: {dt:.1f} ms")
+    # --warmup too small for the capture to have happened: finish it as untimed set-up (reported in config), so the
+    # K timed steps are K steady-state steps and not (K-1) steps plus a graph capture
+    extra_setup = 0
+    while trainer.use_graph and trainer._graph is None and extra_setup < graph_warmup + 2:
+        trainer.step(*batches[extra_setup % len(batches)])
+        extra_setup += 1
+    if extra_setup:
+        log(f"{extra_setup} extra untimed set-up step(s) to finish the hipGraph capture (--warmup {args.warmup})")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -454,6 +465,8 @@ def main():
                                                 no=args.classes + 5)},
         }
         out["config"]["hip_graph"] = trainer._graph is not None
+        if extra_setup:
+            out["config"]["extra_untimed_setup_steps"] = extra_setup
         if trainer.graph_error:
             out["config"]["hip_graph_error"] = trainer.graph_error[:200]
         log(f"timed region done: {out['value']} images/s (hipGraph={'on' if trainer._graph is not None else 'off'})")
