@@ -20,10 +20,18 @@ class GraphedDetector:
       outlive it."""
 
     def __init__(self, model: torch.nn.Module, example: torch.Tensor, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 warmup: int = 2, **predict_kwargs):
+                 warmup: int = 2, cast_conv_weights: bool = False, **predict_kwargs):
         if not example.is_cuda:
             raise ValueError("GraphedDetector needs a HIP device tensor as the example input")
         self.model = model.eval()
+        if cast_conv_weights and amp_dtype is not None:
+            # inference-only: store the convolution weights in the autocast dtype once, instead of autocast
+            # re-casting ~60 fp32 weights on every call (the model can no longer be trained in fp32 afterwards)
+            for m in self.model.modules():
+                if isinstance(m, torch.nn.Conv2d):
+                    m.weight.data = m.weight.data.to(amp_dtype)
+                    if m.bias is not None:
+                        m.bias.data = m.bias.data.to(amp_dtype)
         self.amp_dtype = amp_dtype
         self.kwargs = predict_kwargs
         self.device = example.device

@@ -215,6 +215,14 @@ def test_graphed_detector_replays_match_eager(gpu):
     other = syn.make_images(2, 160, g).to(gpu).contiguous(memory_format=torch.channels_last)
     det, cnt = gd(other)                      # different batch size: eager fallback
     assert det.shape[0] == 2
+    # inference-only variant: convolution weights stored in bf16 once -> fewer graph nodes, same detections
+    import copy
+    ref = [t.clone() for t in gd(imgs[1])]
+    gd2 = GraphedDetector(copy.deepcopy(model), imgs[0], cast_conv_weights=True, conf_thr=0.05, iou_thr=0.45,
+                          max_nms=2000, max_det=50)
+    out2 = gd2(imgs[1])
+    assert gd2.graph_nodes < gd.graph_nodes
+    assert torch.equal(out2[0], ref[0]) and torch.equal(out2[1], ref[1])
 
 
 def test_training_step_with_device_mosaic_captures_and_varies(gpu):
