@@ -167,3 +167,48 @@ def test_fullsize_loss_bookkeeping(gpu, ops):
         assert float(others.abs().amax(dim=2)[~matched].max()) == 0.0     # only matched cells carry box/class gradient
         ref_bias = gview.double().sum(dim=(0, 3, 4)).reshape(-1)
         assert float((biases[l].grad.double() - ref_bias).abs().max() / (ref_bias.abs().max() + 1e-12)) < 1e-4
+
+
+def test_mosaic_edge_cases(gpu, ops):
+    """No boxes at all, a one-image batch (all four tiles are the same image), pass-through for every image,
+    an odd image size (rejected: the canvas is averaged 2x2), and the full 1280^2 size of config 5."""
+    from heltondetection_amd import _lib, synthetic as syn
+    from heltondetection_amd.augment import Mosaic
+    g = syn.make_generator(171)
+    S = 64
+    img = syn.make_images(3, S, g).to(gpu)
+    src = torch.tensor([[0, 1, 2, 0], [1, 1, 1, 1], [2, 0, 0, 1]], dtype=torch.int32, device=gpu)
+    ctr = torch.full((3, 2), S, dtype=torch.int32, device=gpu)
+    one = torch.ones(3, dtype=torch.int32, device=gpu)
+    # M = 0
+    out, ob, oc, cnt = ops.mosaic4(img, torch.zeros((3, 0, 4), device=gpu), torch.zeros((3, 0), dtype=torch.int32, device=gpu),
+                                   torch.zeros(3, dtype=torch.int32, device=gpu), src, ctr, one)
+    assert ob.shape == (3, 0, 4) and int(cnt.sum()) == 0 and out.shape == img.shape
+    ref = co.mosaic4(img.cpu().numpy(), np.zeros((3, 1, 4), np.float32), np.zeros((3, 1), np.int32), np.zeros(3, np.int32),
+                     src.cpu().numpy(), ctr.cpu().numpy(), one.cpu().numpy())
+    assert np.array_equal(out.cpu().numpy(), ref[0])
+    # B = 1: Mosaic.draw must not index outside the batch, and the op runs
+    m = Mosaic(p=1.0, generator=torch.Generator(device=gpu).manual_seed(1))
+    s1, c1, a1 = m.draw(1, S, gpu)
+    assert s1.tolist() == [[0, 0, 0, 0]] and int(a1[0]) == 1
+    gtb, gtc, mv = [t.to(gpu) for t in syn.make_targets(1, S, g, "coco", 5, 6)]
+    o1 = ops.mosaic4(img[:1], gtb, gtc, mv, s1, c1, a1, min_wh=0.5)
+    r1 = co.mosaic4(img[:1].cpu().numpy(), gtb.cpu().numpy(), gtc.cpu().numpy(), mv.cpu().numpy(), s1.cpu().numpy(),
+                    c1.cpu().numpy(), a1.cpu().numpy(), min_wh=0.5)
+    assert np.array_equal(o1[0].cpu().numpy(), r1[0]) and np.array_equal(o1[3].cpu().numpy(), r1[3])
+    # apply == 0 everywhere: identity
+    z = torch.zeros(3, dtype=torch.int32, device=gpu)
+    own = torch.arange(3, dtype=torch.int32, device=gpu)[:, None].repeat(1, 4)
+    outz = ops.mosaic4(img, torch.zeros((3, 2, 4), device=gpu), torch.zeros((3, 2), dtype=torch.int32, device=gpu),
+                       torch.zeros(3, dtype=torch.int32, device=gpu), own, ctr, z)
+    assert torch.equal(outz[0], img)
+    # odd S is a shape error, not a silent wrong answer
+    with pytest.raises(_lib.HdError):
+        ops.mosaic4(torch.zeros((1, 3, 63, 63), device=gpu), gtb, gtc, mv, s1, c1, a1)
+    # config-5 size: every output pixel of a p=1 mosaic is a mean of four [0,1) values or fill
+    big = syn.make_images(2, 1280, g).to(gpu).contiguous(memory_format=torch.channels_last)
+    sb, cb, ab = m.draw(2, 1280, gpu)
+    ob_ = ops.mosaic4(big, torch.zeros((2, 1, 4), device=gpu), torch.zeros((2, 1), dtype=torch.int32, device=gpu),
+                      torch.zeros(2, dtype=torch.int32, device=gpu), sb, cb, ab)[0]
+    assert ob_.shape == big.shape and float(ob_.min()) >= 0.0 and float(ob_.max()) < 1.0
+    assert abs(float(ob_.mean()) - 0.5) < 0.03      # mean of uniform noise (fill 0.447 covers little)
