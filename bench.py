@@ -5,10 +5,14 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = forward (CSPDarknet+PAFPN on MIOpen, bf16 autocast, channels-last) + HIP build-targets +
-HIP fused loss + backward (HIP dense-gradient kernel, MIOpen conv backward) + bucketed RCCL
-all-reduce overlapped with backward + fused AdamW + LR schedule, on synthetic 640x640 batches
-already resident in HBM.  Weak scaling: bs=16 per GPU at every N.  Rank 0 prints ONE JSON line.
+A step = forward (CSPDarknet+PAFPN on MIOpen, bf16 autocast, channels-last, fused HIP BN+SiLU) + HIP
+build-targets + HIP fused loss + backward (HIP dense-gradient kernel, MIOpen conv backward) + bucketed
+RCCL all-reduce + fused AdamW + LR schedule, on synthetic 640x640 batches already resident in HBM.
+Forward + loss + backward + gradient packing replay from one hipGraph (--no-graph: eager, where the
+all-reduce is launched from autograd hooks and overlaps backward); with the graph the collectives run
+after the replay.  Weak scaling: bs=16 per GPU at every N.  Rank 0 prints ONE JSON line.
+Three guards keep a bad graph run from being reported (finite loss, replay-vs-eager loss, replay not
+slower than eager): if one trips, the steps are re-timed eagerly and config.hip_graph_error says so.
 
 Extra objects in that line:
   roofline      the dominant hand-written kernel inside the timed region (the dense-gradient
@@ -18,6 +22,7 @@ Extra objects in that line:
                 reference's CPU path is not in the snapshot) on the box's host cores, bounded sample.
   kernels       (N=1 only) HIP-event rooflines of the other hot-path kernels at BASELINE.json's
                 config shapes — parity-case workloads, not the headline metric.
+  inference     (N=1 only) eval forward + HIP decode + HIP NMS for the same model, eager and hipGraph.
 """
 from __future__ import annotations
 
