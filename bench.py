@@ -217,6 +217,9 @@ def micro_kernels(device):
     ms = timeit(lambda: ops.yolo_nms(dec, 0.25, 0.45, 30000, 300))
     add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 85 * 4,
         "B=16 n=25200 conf=0.25 on random logits: ~75% of rows are candidates (stress case)", "latency")
+    ms = timeit(lambda: ops.yolo_detect(views, strides, anchors, 0.25, 0.45, 30000, 300))
+    add("yolo_detect (raw cand+sort+mask+scan+emit)", ms, 16 * n * 85 * 4,
+        "B=16 n=25200 conf=0.25 on random logits, straight from the head outputs (no decoded tensor)", "latency")
     ms = timeit(lambda: ops.yolo_nms(dec, 0.9, 0.45, 30000, 300))
     add("yolo_nms (cand+sort+mask+scan+emit)", ms, 16 * n * 4,
         "B=16 n=25200 conf=0.9: ~15 candidates per image (detector-like pass rate; reads the objectness column)",
@@ -311,7 +314,7 @@ def inference_leg(model, batches, args, device):
         best = min(eager_ms, graph_ms) if graph_ms is not None else eager_ms
         return {"images_per_s": round(args.batch / best * 1e3, 1), "ms_per_batch_eager": round(eager_ms, 3),
                 "ms_per_batch_hipgraph": None if graph_ms is None else round(graph_ms, 3), "batch": args.batch,
-                "pipeline": "eval forward (bf16) + hd_yolo_decode + hd_yolo_nms(conf 0.25, iou 0.45, max_det 300)",
+                "pipeline": "eval forward (bf16) + hd_yolo_detect (decode fused into the NMS candidate pass; conf 0.25, iou 0.45, max_det 300)",
                 "mean_detections": round(float(cnt.float().mean()), 1)}
     finally:
         model.train(was_training)

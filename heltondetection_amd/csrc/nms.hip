@@ -1,5 +1,7 @@
 // nms.hip — hd_nms_batched and hd_yolo_nms on top of the shared engine (hd_nms_core.h).
 // SURVEY.md §8a rows "RPN proposal top-K + NMS" (class-agnostic / per-level) and "Per-class NMS".
+#include <algorithm>
+
 #include "hd_nms_core.h"
 
 using namespace hdnms;
@@ -114,6 +116,95 @@ __global__ __launch_bounds__(256) void yolo_det_kernel(const int32_t* __restrict
   }
 }
 
+// ---- hd_yolo_detect -------------------------------------------------------------------------
+// hd_yolo_decode + hd_yolo_nms without the decoded tensor: the candidate pass gates on the RAW objectness
+// logit (sigmoid applied exactly as the decode kernel does) and decodes box + classes only for rows that
+// pass, so inference never writes and re-reads B*n*no floats (137 MB at bs16 640^2 C=80).  Candidate index
+// = the row index of the decoded layout (level, anchor, y, x), hence identical keys, ties and detections.
+struct RawIndex {
+  int first_row[HD_MAX_LEVELS + 1];
+};
+
+__global__ __launch_bounds__(256) void yolo_raw_cand_kernel(const hd_yolo_levels lv, const RawIndex ix, int n,
+                                                            float conf_thr, CoreWs w, float4* __restrict__ cand_box,
+                                                            int32_t* __restrict__ cand_cls,
+                                                            float* __restrict__ cand_conf) {
+  const int b = blockIdx.y, l = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int na = lv.na, no = lv.no, H = lv.h[l], W = lv.w[l];
+  const int rows_l = na * H * W;
+  const long long so = lv.so[l];
+  const float stride = lv.stride[l];
+  u64* keys = w.keys + (size_t)b * w.key_cap;
+  const float* base = lv.pred[l] + (long long)b * lv.sb[l];
+  // rows are walked in MEMORY order of a channels-last head output, m = (y*W + x)*na + a, so the 64 objectness
+  // logits of a wave sit 4*no bytes apart in one contiguous span; other layouts only change the address
+  for (int m0 = wave * 64; m0 < rows_l; m0 += n_waves * 64) {
+    const int m = m0 + lane;
+    const bool ok = m < rows_l;
+    const int a = ok ? m % na : 0;
+    const int cell = ok ? m / na : 0;
+    const int y = cell / W, x = cell - y * W;
+    const float* r = base + (long long)a * lv.sa[l] + (long long)y * lv.sy[l] + (long long)x * lv.sx[l];
+    const float my_obj = ok ? hd_sigmoid(r[4 * so]) : 0.0f;
+    unsigned long long pass = __ballot(ok && my_obj > conf_thr);
+    float my_conf = -1.0f;
+    int my_cls = 0;
+    while (pass) {
+      const int j = __ffsll((long long)pass) - 1;
+      pass &= pass - 1;
+      // row j's address, rebuilt wave-uniformly
+      const int mj = m0 + j;
+      const int aj = mj % na, cj = mj / na;
+      const int yj = cj / W, xj = cj - yj * W;
+      const float* rj = base + (long long)aj * lv.sa[l] + (long long)yj * lv.sy[l] + (long long)xj * lv.sx[l];
+      const float obj = __shfl(my_obj, j, 64);
+      float best = -1.0f;
+      int bc = 0;
+      for (int c = 5 + lane; c < no; c += 64) {
+        const float v = hd_sigmoid(rj[c * so]);
+        if (v > best) {
+          best = v;
+          bc = c - 5;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        if (ob > best || (ob == best && oc < bc)) {
+          best = ob;
+          bc = oc;
+        }
+      }
+      if (lane == j) {
+        my_conf = obj * best;
+        my_cls = bc;
+      }
+    }
+    const bool take = my_conf > conf_thr;
+    const unsigned long long mm = __ballot(take);
+    if (mm != 0ull) {
+      int pos0 = 0;
+      if (lane == 0) pos0 = atomicAdd(&w.n_keys[b], __popcll(mm));
+      pos0 = __shfl(pos0, 0, 64);
+      if (take) {
+        // the decode kernel's expressions, in its order
+        const float s0 = hd_sigmoid(r[0]), s1 = hd_sigmoid(r[so]), s2 = hd_sigmoid(r[2 * so]), s3 = hd_sigmoid(r[3 * so]);
+        const float cx = (s0 * 2.0f - 0.5f + (float)x) * stride, cy = (s1 * 2.0f - 0.5f + (float)y) * stride;
+        const float bw = (s2 * 2.0f) * (s2 * 2.0f) * lv.anchor_w[l][a], bh = (s3 * 2.0f) * (s3 * 2.0f) * lv.anchor_h[l][a];
+        const int i = ix.first_row[l] + (a * H + y) * W + x;  // row of the decoded layout
+        cand_box[(size_t)b * n + i] = make_float4(cx - bw * 0.5f, cy - bh * 0.5f, cx + bw * 0.5f, cy + bh * 0.5f);
+        cand_cls[(size_t)b * n + i] = my_cls;
+        cand_conf[(size_t)b * n + i] = my_conf;
+        keys[pos0 + __popcll(mm & ((1ull << lane) - 1ull))] = make_key(my_conf, (uint32_t)i);
+      }
+    }
+  }
+}
+
 struct YoloWs {
   float4* cand_box;
   int32_t* cand_cls;
@@ -200,6 +291,59 @@ extern "C" hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float c
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(gx, B), dim3(256), 0, s, dec, n, no, conf_thr, w, y.cand_box, y.cand_cls,
                      y.cand_conf);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  hd_status st = run_core(w, B, y.cand_box, y.cand_cls, (long long)n, iou_thr, max_det, y.keep, det_count, s);
+  if (st != HD_OK) return st;
+  hipLaunchKernelGGL(yolo_det_kernel, dim3((max_det + 255) / 256, B), dim3(256), 0, s, y.keep, det_count, n, max_det,
+                     y.cand_box, y.cand_cls, y.cand_conf, det);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+static int yolo_total_rows(const hd_yolo_levels* lv, RawIndex* ix) {
+  long long n = 0;
+  for (int l = 0; l <= HD_MAX_LEVELS; ++l) {
+    if (ix) ix->first_row[l] = (int)n;
+    if (l < lv->n_levels) n += (long long)lv->na * lv->h[l] * lv->w[l];
+  }
+  return n > 0x7fffffffLL ? -1 : (int)n;
+}
+
+extern "C" size_t hd_yolo_detect_workspace_bytes(const hd_yolo_levels* lv, int B, int max_nms, int max_det) {
+  if (!lv || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS) return 0;
+  const int n = yolo_total_rows(lv, nullptr);
+  return n > 0 ? hd_yolo_nms_workspace_bytes(B, n, max_nms, max_det) : 0;
+}
+
+extern "C" hd_status hd_yolo_detect(const hd_yolo_levels* lv, int B, float conf_thr, float iou_thr, int max_nms,
+                                    int max_det, float* det, int32_t* det_count, void* workspace,
+                                    size_t workspace_bytes, hd_stream stream) {
+  if (!lv) return HD_ERR_NULL;
+  if (B <= 0 || max_det <= 0 || max_det > (1 << 20) || B > 65535 || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS ||
+      lv->na <= 0 || lv->na > HD_MAX_ANCHORS || lv->no < 6)
+    return HD_ERR_SHAPE;
+  for (int l = 0; l < lv->n_levels; ++l) {
+    if (!lv->pred[l]) return HD_ERR_NULL;
+    if (lv->h[l] <= 0 || lv->w[l] <= 0) return HD_ERR_SHAPE;
+  }
+  if (!det || !det_count) return HD_ERR_NULL;
+  RawIndex ix;
+  const int n = yolo_total_rows(lv, &ix);
+  if (n <= 0) return HD_ERR_SHAPE;
+  if (!workspace) return HD_ERR_WORKSPACE;
+  if (!hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  YoloWs y = yolo_layout(workspace, B, n, max_det);
+  CoreWs w = core_layout(reinterpret_cast<char*>(workspace) + y.core_off, B, n, max_nms);
+  if (w.cap > kMaxCand) return HD_ERR_SHAPE;
+  if (workspace_bytes < y.bytes + w.bytes) return HD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hd_fill32(w.n_keys, 0u, (size_t)B, s) != HD_OK) return HD_ERR_LAUNCH;
+  int max_rows = 0;
+  for (int l = 0; l < lv->n_levels; ++l) max_rows = std::max(max_rows, lv->na * lv->h[l] * lv->w[l]);
+  int gx = (max_rows + 255) / 256;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(yolo_raw_cand_kernel, dim3(gx, B, lv->n_levels), dim3(256), 0, s, *lv, ix, n, conf_thr, w, y.cand_box,
+                     y.cand_cls, y.cand_conf);
   HD_RETURN_IF_LAUNCH_FAILED();
   hd_status st = run_core(w, B, y.cand_box, y.cand_cls, (long long)n, iou_thr, max_det, y.keep, det_count, s);
   if (st != HD_OK) return st;

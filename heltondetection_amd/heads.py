@@ -76,8 +76,8 @@ class YOLOv5Head(nn.Module):
 
     @torch.no_grad()
     def predict(self, preds, conf_thr=0.25, iou_thr=0.45, max_nms=30000, max_det=300):
-        dec = ops.yolo_decode(preds, self.strides, self.anchors)
-        return ops.yolo_nms(dec, conf_thr, iou_thr, max_nms, max_det)
+        # decode + per-class NMS in one pass over the raw head outputs (no decoded [B, n, no] tensor)
+        return ops.yolo_detect(preds, self.strides, self.anchors, conf_thr, iou_thr, max_nms, max_det)
 
 
 # =============================================================================== FasterRCNN heads

@@ -516,6 +516,23 @@ def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, sl
     return [a.elapsed_time(b) for a, b in evs]
 
 
+def yolo_detect(preds: Sequence[torch.Tensor], strides, anchors, conf_thr: float = 0.25, iou_thr: float = 0.45,
+                max_nms: int = 30000, max_det: int = 300):
+    """`yolo_nms(yolo_decode(preds))` without the decoded tensor (csrc/nms.hip: yolo_raw_cand_kernel): the raw head
+    outputs [B,na,H,W,no] are gated on sigmoid(objectness) and only passing rows are decoded.  Identical output:
+    det [B,max_det,6] = (x1,y1,x2,y2,conf,cls), count [B]."""
+    lib = _lib.load()
+    st = _yolo_levels([p.detach() for p in preds], strides, anchors)
+    B = preds[0].shape[0]
+    dev = preds[0].device
+    det = torch.empty((B, max_det, 6), dtype=_F32, device=dev)
+    cnt = torch.empty((B,), dtype=_I32, device=dev)
+    ws, wsb = _ws(lib.hd_yolo_detect_workspace_bytes(C.byref(st), B, int(max_nms), int(max_det)), dev)
+    check(lib.hd_yolo_detect(C.byref(st), B, float(conf_thr), float(iou_thr), int(max_nms), int(max_det), _ptr(det),
+                             _ptr(cnt), _ptr(ws), wsb, _stream(det)), "hd_yolo_detect")
+    return det, cnt
+
+
 class _CIoUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):

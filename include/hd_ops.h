@@ -301,6 +301,14 @@ hd_status hd_yolo_nms(const float* dec, int B, int n, int no, float conf_thr, fl
                       int max_nms, int max_det, float* det, int32_t* det_count, void* workspace,
                       size_t workspace_bytes, hd_stream stream);
 
+/* hd_yolo_decode followed by hd_yolo_nms, without materialising the decoded tensor: the candidate pass reads
+ * the raw head outputs, gates on sigmoid(objectness) > conf_thr and decodes only the rows that pass.
+ * Detections are identical (values, order, ties) to the two-step path. */
+size_t hd_yolo_detect_workspace_bytes(const hd_yolo_levels* lv, int B, int max_nms, int max_det);
+hd_status hd_yolo_detect(const hd_yolo_levels* lv, int B, float conf_thr, float iou_thr, int max_nms,
+                         int max_det, float* det, int32_t* det_count, void* workspace,
+                         size_t workspace_bytes, hd_stream stream);
+
 /* ---- Weighted Boxes Fusion (README.md:19) ---------------------------------- */
 
 /* Per image: boxes [B,K,4], scores [B,K], labels [B,K] int32, model_weight [B,K] (weight of the

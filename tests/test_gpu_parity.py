@@ -353,6 +353,33 @@ def test_yolo_nms(gpu, ops):
     assert np.array_equal(det.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("layout", ["dense", "channels_last"])
+@pytest.mark.parametrize("conf", [0.3, 0.02])
+def test_yolo_detect_equals_decode_then_nms(gpu, ops, layout, conf):
+    """hd_yolo_detect (candidate pass on the raw head outputs) must give exactly the detections of
+    hd_yolo_decode + hd_yolo_nms and of the oracle: same candidates, same keys, same ties."""
+    B, size, no = 2, 160, 85
+    preds = H.yolo_preds(B, size, no, 93, scale=2.0)
+    dec = co.yolo_decode([p.numpy() for p in preds], H.YOLO_STRIDES, H.YOLO_ANCHORS)
+    rd, rc = co.yolo_nms(dec, conf, 0.45, 3000, 100)
+    assert rc.min() > 3
+    if layout == "dense":
+        views = [dev(p, gpu) for p in preds]
+    else:
+        views = []
+        for p in preds:
+            _, na, Hh, Ww, _ = p.shape
+            conv = p.permute(0, 1, 4, 2, 3).reshape(B, na * no, Hh, Ww).to(gpu).contiguous(memory_format=torch.channels_last)
+            views.append(conv.view(B, na, no, Hh, Ww).permute(0, 1, 3, 4, 2))
+    det, cnt = ops.yolo_detect(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, conf, 0.45, 3000, 100)
+    d2, c2 = ops.yolo_nms(ops.yolo_decode(views, H.YOLO_STRIDES, H.YOLO_ANCHORS), conf, 0.45, 3000, 100)
+    assert torch.equal(cnt, c2) and torch.equal(det, d2)          # bit-identical to the two-step HIP path
+    # vs the oracle: same detections; values within the decode tolerance (device expf vs libm differ by ulps)
+    d = det.cpu().numpy()
+    assert np.array_equal(cnt.cpu().numpy(), rc) and np.array_equal(d[..., 5], rd[..., 5])
+    assert np.allclose(d[..., :5], rd[..., :5], rtol=1e-5, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------- WBF
 def test_wbf(gpu, ops):
     B, K, T = 3, 600, 3
