@@ -23,6 +23,8 @@ Extra objects in that line:
   kernels       (N=1 only) HIP-event rooflines of the other hot-path kernels at BASELINE.json's
                 config shapes — parity-case workloads, not the headline metric.
   inference     (N=1 only) eval forward + HIP decode + HIP NMS for the same model, eager and hipGraph.
+  roofline_bn   the four fused BN+SiLU kernels (the largest hand-written share of the step by total time) on the
+                step's largest layer, timed like `roofline`.
 """
 from __future__ import annotations
 
@@ -472,6 +474,18 @@ def main():
                          "traffic": pmc_traffic("yolo_grad_dense_kernel", batch=args.batch, size=args.size,
                                                 no=args.classes + 5)},
         }
+        # By total time the fused BN+SiLU kernels are the largest hand-written share of the step (57 layers x 4
+        # launches); their roofline is measured the same way on the step's largest layer (the stem output)
+        try:
+            bn = ops.time_bn_act_kernels((args.batch, model.backbone.stem.conv.out_channels, args.size // 2, args.size // 2),
+                                         torch.float32 if args.fp32 else torch.bfloat16, "silu", iters=20, device=device)
+            out["roofline_bn"] = [{"kernel": k, "bound": "hbm", "achieved": round(nb / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                   "avg_launch_ms": round(ms, 5), "algorithmic_bytes_per_launch": nb,
+                                   "layer": f"[{args.batch},{model.backbone.stem.conv.out_channels},{args.size // 2},{args.size // 2}]"}
+                                  for k, (ms, nb) in bn.items()]
+        except Exception as e:  # never lose the headline number to a secondary measurement
+            out["roofline_bn_error"] = repr(e)[:200]
         out["config"]["hip_graph"] = trainer._graph is not None
         if extra_setup:
             out["config"]["extra_untimed_setup_steps"] = extra_setup

@@ -831,6 +831,58 @@ def mosaic4(images: torch.Tensor, gt_boxes: torch.Tensor, gt_cls: torch.Tensor, 
     return out, ob, oc, cnt
 
 
+def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: int = 20, device=None):
+    """Measurement helper for bench.py: the four fused-BN kernels on one channels-last tensor of `shape`
+    ([B,C,H,W]), each launched `iters` times back to back on the current stream with a HIP event pair per launch
+    (saturated stream, so a pair spans the kernel only).  Returns {kernel: (median ms, algorithmic bytes)}."""
+    lib = _lib.load()
+    device = torch.device(device or "cuda")
+    x = torch.randn(shape, device=device).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn_like(x)
+    B, Cc, H, W = shape
+    R = B * H * W
+    dt = 0 if dtype == torch.float32 else 1
+    rep = lib.hd_bn_act_replicas()
+    sums = torch.zeros(rep * 4 * Cc, dtype=_F32, device=device)
+    dsums = sums[rep * 2 * Cc:]
+    w = torch.ones(Cc, dtype=_F32, device=device)
+    b = torch.zeros(Cc, dtype=_F32, device=device)
+    save = torch.zeros((2, Cc), dtype=_F32, device=device)
+    y = torch.empty_like(x)
+    dg = torch.empty((2, Cc), dtype=_F32, device=device)
+    st = _stream(x)
+    code = _ACT_CODE[act]
+    tb = x.numel() * x.element_size()
+
+    def run(fn):
+        for _ in range(3):
+            fn()
+        evs = []
+        for _ in range(iters):
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            e.record()
+            evs.append((a, e))
+        torch.cuda.synchronize(device)
+        ts = sorted(a.elapsed_time(e) for a, e in evs)
+        return ts[len(ts) // 2]
+
+    out = {}
+    out["bn_stats_kernel"] = (run(lambda: check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")), tb)
+    sums.zero_()
+    check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")
+    out["bn_apply_kernel"] = (run(lambda: check(lib.hd_bn_act_apply(
+        _ptr(x), dt, R, 0, Cc, _ptr(sums), _ptr(w), _ptr(b), 1e-3, 0.03, None, None, _ptr(save[0]), _ptr(save[1]), code,
+        _ptr(y), st), "apply")), 2 * tb)
+    out["bn_bwd_reduce_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_reduce(
+        _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, _ptr(dsums), st), "reduce")), 2 * tb)
+    out["bn_bwd_dx_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_dx(
+        _ptr(x), _ptr(dy), 0, dt, R, 0, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, _ptr(dsums), _ptr(y),
+        _ptr(dg[0]), _ptr(dg[1]), st), "dx")), 3 * tb)
+    return out
+
+
 # ------------------------------------------------------------------------------- hipGraph hygiene
 def graph_replace_memsets(raw_graph) -> Tuple[int, int]:
     """raw_graph: the hipGraph_t of a captured but not yet instantiated graph
