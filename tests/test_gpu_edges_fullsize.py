@@ -212,3 +212,69 @@ def test_mosaic_edge_cases(gpu, ops):
                       torch.zeros(2, dtype=torch.int32, device=gpu), sb, cb, ab)[0]
     assert ob_.shape == big.shape and float(ob_.min()) >= 0.0 and float(ob_.max()) < 1.0
     assert abs(float(ob_.mean()) - 0.5) < 0.03      # mean of uniform noise (fill 0.447 covers little)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_newest_ops_shape_sweep(gpu, ops, seed):
+    """Seeded sweep over awkward shapes for the ops added last (RoI max-pooling, Mosaic-4, fused decode+NMS):
+    every case must equal the oracle exactly (RoIPool, Mosaic) or the two-step HIP path exactly (detect)."""
+    from heltondetection_amd import synthetic as syn
+    rng = np.random.default_rng(1000 + seed)
+    g = syn.make_generator(2000 + seed)
+    # --- RoI max-pooling: odd channel counts, P in {1..7}, 1-3 levels, planar and channels-last features
+    C = int(rng.choice([3, 8, 65, 130]))
+    P = int(rng.integers(1, 8))
+    L = int(rng.integers(1, 4))
+    strides = [4, 8, 16][:L]
+    B = int(rng.integers(1, 4))
+    feats = [torch.randn((B, C, int(np.ceil(96 / s)), int(np.ceil(96 / s))), generator=g) for s in strides]
+    R = int(rng.integers(1, 40))
+    rb = syn.random_boxes(R, 96.0, g, 2.0, 90.0)
+    rb[0] = torch.tensor([-5.0, -5.0, 120.0, 130.0])            # hangs off every side
+    rois = torch.cat([torch.randint(0, B, (R, 1), generator=g).float(), rb], 1)
+    fd = [f.to(gpu) for f in feats]
+    if seed % 2:
+        fd = [f.contiguous(memory_format=torch.channels_last) for f in fd]
+    out, arg = ops.roi_pool(fd, rois.to(gpu), P, [1.0 / s for s in strides], 2, 56.0, 4, return_argmax=True)
+    ref, rarg = co.roi_pool_fwd([f.numpy() for f in feats], rois.numpy(), P, [1.0 / s for s in strides], 2, 56.0, 4)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(arg.cpu().numpy(), rarg)
+    # --- Mosaic-4: S in {2, 6, 34, 50}, B 1..5, M 0..7, random centres over the whole allowed range
+    S = int(rng.choice([2, 6, 34, 50]))
+    Bm = int(rng.integers(1, 6))
+    M = int(rng.integers(0, 8))
+    img = syn.make_images(Bm, S, g)
+    if M:
+        gtb, gtc, mv = syn.make_targets(Bm, max(S, 16), g, "coco", 5, M)
+        gtb = gtb.clamp(max=float(S))
+    else:
+        gtb, gtc, mv = torch.zeros((Bm, 0, 4)), torch.zeros((Bm, 0), dtype=torch.int32), torch.zeros(Bm, dtype=torch.int32)
+    src = torch.from_numpy(rng.integers(0, Bm, (Bm, 4)).astype(np.int32))
+    ctr = torch.from_numpy(rng.integers(S // 2, 3 * S // 2 + 1, (Bm, 2)).astype(np.int32))
+    apl = torch.from_numpy(rng.integers(0, 2, (Bm,)).astype(np.int32))
+    imd = img.to(gpu).contiguous(memory_format=torch.channels_last) if seed % 2 == 0 else img.to(gpu)
+    o = ops.mosaic4(imd, gtb.to(gpu), gtc.to(gpu), mv.to(gpu), src.to(gpu), ctr.to(gpu), apl.to(gpu), min_wh=0.25)
+    Mo = max(M, 1)
+    r = co.mosaic4(img.numpy(), gtb.numpy() if M else np.zeros((Bm, 1, 4), np.float32),
+                   gtc.numpy() if M else np.zeros((Bm, 1), np.int32), mv.numpy(), src.numpy(), ctr.numpy(), apl.numpy(),
+                   min_wh=0.25)
+    assert np.array_equal(o[0].cpu().numpy(), r[0]) and np.array_equal(o[3].cpu().numpy(), r[3])
+    if M:
+        assert np.array_equal(o[1].cpu().numpy(), r[1]) and np.array_equal(o[2].cpu().numpy(), r[2])
+    # --- fused decode + NMS vs decode then NMS: class counts 1..90, odd image sizes, strided (channels-last) heads
+    nc = int(rng.choice([1, 2, 20, 59, 90]))
+    no = 5 + nc
+    size = int(rng.choice([96, 128, 160]))
+    Bd = int(rng.integers(1, 4))
+    preds = H.yolo_preds(Bd, size, no, 3000 + seed, scale=2.5)
+    views = []
+    for p in preds:
+        _, na, Hh, Ww, _ = p.shape
+        if seed % 2:
+            conv = p.permute(0, 1, 4, 2, 3).reshape(Bd, na * no, Hh, Ww).to(gpu).contiguous(memory_format=torch.channels_last)
+            views.append(conv.view(Bd, na, no, Hh, Ww).permute(0, 1, 3, 4, 2))
+        else:
+            views.append(p.to(gpu))
+    conf = float(rng.choice([0.01, 0.2, 0.5]))
+    d1, c1 = ops.yolo_detect(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, conf, 0.5, 4000, 64)
+    d2, c2 = ops.yolo_nms(ops.yolo_decode(views, H.YOLO_STRIDES, H.YOLO_ANCHORS), conf, 0.5, 4000, 64)
+    assert torch.equal(c1, c2) and torch.equal(d1, d2)
