@@ -78,8 +78,8 @@ class _ResBottleneck(nn.Module):
             idt = FusedBNAct.apply(self.downsample[1], self.downsample[0](x), None)
         y = FusedBNAct.apply(self.bn1, self.conv1(x), "relu")
         y = FusedBNAct.apply(self.bn2, self.conv2(y), "relu")
-        y = FusedBNAct.apply(self.bn3, self.conv3(y), None)
-        return self.relu(y + idt)
+        # relu(bn3(conv3) + identity) in one fused kernel (residual added before the activation)
+        return FusedBNAct.apply(self.bn3, self.conv3(y), "relu", idt, False)
 
 
 @BACKBONES.register()

@@ -205,8 +205,10 @@ __device__ __forceinline__ float rep_sum(const float* __restrict__ p, int idx, i
 }
 
 // ---- forward apply ------------------------------------------------------------------------------
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, long long nvec, int C, float inv_R,
+// RES: 0 no residual; 1 y = act(bn(x) + r) (ResNet bottleneck tail); 2 y = act(bn(x)) + r (YOLO bottleneck)
+template <typename T, int ACT, int RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, long long nvec,
+                                                       int C, float inv_R,
                                                        float unbias, const float* __restrict__ sums,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float momentum,
@@ -247,18 +249,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     float v[4][V];
 #pragma unroll
     for (int u = 0; u < 4; ++u) RowVec<T>::load(x + (i + u * stride) * V, v[u]);
+    if (RES == 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
-      RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+        for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
+        RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+      }
+    } else {
+      float rv[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) RowVec<T>::load(res + (i + u * stride) * V, rv[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float z = fmaf(a[k], v[u][k], b[k]);
+          v[u][k] = RES == 1 ? act_fwd<ACT>(z + rv[u][k]) : act_fwd<ACT>(z) + rv[u][k];
+        }
+        RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+      }
     }
   }
   for (; i < nvec; i += stride) {
-    float v[V];
+    float v[V], rv[V];
     RowVec<T>::load(x + i * V, v);
+    if (RES != 0) RowVec<T>::load(res + i * V, rv);
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(fmaf(a[k], v[k], b[k]));
+    for (int k = 0; k < V; ++k) {
+      const float z = fmaf(a[k], v[k], b[k]);
+      v[k] = RES == 0 ? act_fwd<ACT>(z) : (RES == 1 ? act_fwd<ACT>(z + rv[k]) : act_fwd<ACT>(z) + rv[k]);
+    }
     RowVec<T>::store(y + i * V, v);
   }
 }
@@ -305,9 +326,11 @@ __device__ __forceinline__ const T* dy_at(const T* dy, long long i, int cg, int 
 }
 
 // ---- backward reductions ------------------------------------------------------------------------
-template <typename T, int ACT>
+// RES (backward kernels): 0, or 1 = the forward added `res` before the activation, so act' is taken at bn(x) + res
+template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            long long ld_dy, long long nvec, int C,
+                                                            const T* __restrict__ res, long long ld_dy, long long nvec,
+                                                            int C,
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_invstd,
                                                             const float* __restrict__ gamma,
@@ -337,34 +360,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
   long long i = i0;
   for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
-    uint4 rx[2], rg[2];
+    uint4 rx[2], rg[2], rr[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       rx[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
       rg[u] = *reinterpret_cast<const uint4*>(dy_at(dy, i + u * stride, cg, C, ld_dy));
+      if (RES) rr[u] = *reinterpret_cast<const uint4*>(res + (i + u * stride) * V);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      float xv[V], gv[V];
+      float xv[V], gv[V], rv[V];
       RowVec<T>::unpack(rx[u], xv);
       RowVec<T>::unpack(rg[u], gv);
+      if (RES) RowVec<T>::unpack(rr[u], rv);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const float xh = fmaf(is[k], xv[k], c0[k]);
-        const float dz = gv[k] * act_grad<ACT>(fmaf(ga[k], xh, be[k]));
+        float z = fmaf(ga[k], xh, be[k]);
+        if (RES) z += rv[k];
+        const float dz = gv[k] * act_grad<ACT>(z);
         s1[k] += dz;
         s2[k] = fmaf(dz, xh, s2[k]);
       }
     }
   }
   for (; i < nvec; i += stride) {
-    float xv[V], gv[V];
+    float xv[V], gv[V], rv[V];
     RowVec<T>::load(x + i * V, xv);
     RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
+    if (RES) RowVec<T>::load(res + i * V, rv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float xh = fmaf(is[k], xv[k], c0[k]);
-      const float dz = gv[k] * act_grad<ACT>(fmaf(ga[k], xh, be[k]));
+      float z = fmaf(ga[k], xh, be[k]);
+      if (RES) z += rv[k];
+      const float dz = gv[k] * act_grad<ACT>(z);
       s1[k] += dz;
       s2[k] = fmaf(dz, xh, s2[k]);
     }
@@ -374,8 +404,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   else fold_atomic<V>(s_acc, s1, s2, g, C, dst);
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const T* __restrict__ res, T* __restrict__ dres,
                                                         long long ld_dy, long long nvec, int C, float inv_R,
                                                         const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd,
@@ -414,32 +445,42 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
   }
   long long i = i0;
   for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
-    float xv[2][V], gv[2][V];
+    float xv[2][V], gv[2][V], rv[2][V];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       RowVec<T>::load(x + (i + u * stride) * V, xv[u]);
       RowVec<T>::load(dy_at(dy, i + u * stride, cg, C, ld_dy), gv[u]);
+      if (RES) RowVec<T>::load(res + (i + u * stride) * V, rv[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        const float dz = gv[u][k] * act_grad<ACT>(fmaf(az[k], xv[u][k], bz[k]));
+        float z = fmaf(az[k], xv[u][k], bz[k]);
+        if (RES) z += rv[u][k];
+        const float dz = gv[u][k] * act_grad<ACT>(z);
         xv[u][k] = fmaf(A[k], dz, fmaf(P[k], xv[u][k], Q[k]));
+        if (RES) rv[u][k] = dz;  // d(res) = dz
       }
       RowVec<T>::store(dx + (i + u * stride) * V, xv[u]);
+      if (RES) RowVec<T>::store(dres + (i + u * stride) * V, rv[u]);
     }
   }
   for (; i < nvec; i += stride) {
-    float xv[V], gv[V];
+    float xv[V], gv[V], rv[V];
     RowVec<T>::load(x + i * V, xv);
     RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
+    if (RES) RowVec<T>::load(res + i * V, rv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const float dz = gv[k] * act_grad<ACT>(fmaf(az[k], xv[k], bz[k]));
+      float z = fmaf(az[k], xv[k], bz[k]);
+      if (RES) z += rv[k];
+      const float dz = gv[k] * act_grad<ACT>(z);
       xv[k] = fmaf(A[k], dz, fmaf(P[k], xv[k], Q[k]));
+      if (RES) rv[k] = dz;
     }
     RowVec<T>::store(dx + i * V, xv);
+    if (RES) RowVec<T>::store(dres + i * V, rv);
   }
 }
 
@@ -505,10 +546,13 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
 extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows, int C, const float* sums,
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                                     int act, void* y, hd_stream stream) {
+                                     int act, const void* res, int res_mode, void* y, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !sums || !gamma || !beta || !save_mean || !save_invstd || !y) return HD_ERR_NULL;
+  if (res_mode < 0 || res_mode > 2) return HD_ERR_SHAPE;
+  if ((res_mode != 0) != (res != nullptr)) return HD_ERR_NULL;
+  if (res && !hd_aligned16(res)) return HD_ERR_ALIGN;
   if ((running_mean == nullptr) != (running_var == nullptr)) return HD_ERR_NULL;
   if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
@@ -518,13 +562,21 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
   const float inv_R = 1.0f / (float)RS;
   const float unbias = RS > 1 ? (float)RS / (float)(RS - 1) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
-#define HD_APPLY(T, A, XT)                                                                                         \
-  hipLaunchKernelGGL((bn_apply_kernel<XT, A>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, reinterpret_cast<const XT*>(x), \
-                     nvec, C, inv_R, unbias, sums, gamma, beta, eps, momentum, running_mean, running_var,        \
-                     save_mean, save_invstd, reinterpret_cast<XT*>(y))
+#define HD_APPLY_R(T, A, RS_, XT)                                                                                  \
+  hipLaunchKernelGGL((bn_apply_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
+                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(res), nvec, C, inv_R, unbias,    \
+                     sums, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,         \
+                     reinterpret_cast<XT*>(y))
+#define HD_APPLY(T, A, XT)                     \
+  do {                                         \
+    if (res_mode == 0) HD_APPLY_R(T, A, 0, XT); \
+    else if (res_mode == 1) HD_APPLY_R(T, A, 1, XT); \
+    else HD_APPLY_R(T, A, 2, XT);              \
+  } while (0)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_APPLY, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_APPLY, __hip_bfloat16);
 #undef HD_APPLY
+#undef HD_APPLY_R
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -560,11 +612,12 @@ static hd_status check_dy_stride(int64_t dy_row_stride, int C, int V, long long 
 
 extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                                           int C, const float* save_mean, const float* save_invstd, const float* gamma,
-                                          const float* beta, int act, float* dsums, hd_stream stream) {
+                                          const float* beta, int act, const void* res, float* dsums,
+                                          hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !dy || !save_mean || !save_invstd || !gamma || !beta || !dsums) return HD_ERR_NULL;
-  if (!hd_aligned16(x) || !hd_aligned16(dy)) return HD_ERR_ALIGN;
+  if (!hd_aligned16(x) || !hd_aligned16(dy) || (res && !hd_aligned16(res))) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
   int64_t ld = 0;
@@ -573,26 +626,34 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t
   const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
-#define HD_RED(T, A, XT)                                                                                          \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<XT, A>), dim3(l.grid), dim3(l.block), lds, s,                         \
-                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), (long long)ld, nvec, C,    \
-                     save_mean, save_invstd, gamma, beta, dsums)
+#define HD_RED_R(T, A, RS_, XT)                                                                                    \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), lds, s,                    \
+                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
+                     (long long)ld, nvec, C, save_mean, save_invstd, gamma, beta, dsums)
+#define HD_RED(T, A, XT)                \
+  do {                                  \
+    if (res) HD_RED_R(T, A, 1, XT);     \
+    else HD_RED_R(T, A, 0, XT);         \
+  } while (0)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_RED, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_RED, __hip_bfloat16);
 #undef HD_RED
+#undef HD_RED_R
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
 extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                                       int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
-                                      const float* beta, int act, const float* dsums, void* dx, float* dgamma,
-                                      float* dbeta, hd_stream stream) {
+                                      const float* beta, int act, const void* res, const float* dsums, void* dx,
+                                      void* dres, float* dgamma, float* dbeta, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !dy || !save_mean || !save_invstd || !gamma || !beta || !dsums || !dx || !dgamma || !dbeta)
     return HD_ERR_NULL;
-  if (!hd_aligned16(x) || !hd_aligned16(dy) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
+  if ((res == nullptr) != (dres == nullptr)) return HD_ERR_NULL;
+  if (!hd_aligned16(x) || !hd_aligned16(dy) || !hd_aligned16(dx) || (res && (!hd_aligned16(res) || !hd_aligned16(dres))))
+    return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
   int64_t ld = 0;
@@ -601,13 +662,20 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   const float inv_R = 1.0f / (float)(stat_rows > 0 ? stat_rows : R);
   hipStream_t s = (hipStream_t)stream;
-#define HD_DX(T, A, XT)                                                                                           \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<XT, A>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, reinterpret_cast<const XT*>(x), \
-                     reinterpret_cast<const XT*>(dy), (long long)ld, nvec, C, inv_R, save_mean, save_invstd, gamma, beta, dsums,  \
-                     reinterpret_cast<XT*>(dx), dgamma, dbeta)
+#define HD_DX_R(T, A, RS_, XT)                                                                                     \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
+                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
+                     reinterpret_cast<XT*>(dres), (long long)ld, nvec, C, inv_R, save_mean, save_invstd, gamma, beta, \
+                     dsums, reinterpret_cast<XT*>(dx), dgamma, dbeta)
+#define HD_DX(T, A, XT)               \
+  do {                                \
+    if (res) HD_DX_R(T, A, 1, XT);    \
+    else HD_DX_R(T, A, 0, XT);        \
+  } while (0)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_DX, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_DX, __hip_bfloat16);
 #undef HD_DX
+#undef HD_DX_R
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

@@ -47,7 +47,9 @@ class FusedBNAct:
     _ACTS = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}
 
     @staticmethod
-    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act):
+    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False):
+        """residual: added inside the fused kernel, before (`act(bn(x) + r)`) or after (`act(bn(x)) + r`) the
+        activation; the unfused fallback computes the same expression with torch ops."""
         if FusedBNAct.enabled and x.is_cuda:
             from . import ops
             if ops.bn_act_supported(x):
@@ -58,8 +60,12 @@ class FusedBNAct:
                 training = bn.training or bn.running_mean is None
                 return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                   bn.momentum if bn.momentum is not None else 0.1, act, training, slot,
-                                  FusedBNAct.sync_group if training else None)
-        return FusedBNAct._ACTS[act](bn(x))
+                                  FusedBNAct.sync_group if training else None, residual, residual_after_act)
+        if residual is None:
+            return FusedBNAct._ACTS[act](bn(x))
+        if residual_after_act:
+            return FusedBNAct._ACTS[act](bn(x)) + residual
+        return FusedBNAct._ACTS[act](bn(x) + residual)
 
 
 class ConvBNAct(nn.Module):
@@ -74,11 +80,13 @@ class ConvBNAct(nn.Module):
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut)."""
         y = self.conv(x)
         if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
-            return FusedBNAct.apply(self.bn, y, self.act_name)
-        return self.act(self.bn(y))
+            return FusedBNAct.apply(self.bn, y, self.act_name, residual, True)
+        y = self.act(self.bn(y))
+        return y if residual is None else y + residual
 
 
 class Bottleneck(nn.Module):
@@ -90,8 +98,8 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x):
-        y = self.cv2(self.cv1(x))
-        return x + y if self.add else y
+        # the shortcut add rides in the second conv's fused BN+activation kernel
+        return self.cv2(self.cv1(x), x if self.add else None)
 
 
 class C3(nn.Module):

@@ -712,8 +712,14 @@ def _cl_row_stride(t: torch.Tensor, vec: int):
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None, res=None,
+                res_mode=0):
         lib = _lib.load()
+        if res is not None:
+            if res.shape != x.shape or res.dtype != x.dtype or res.stride() != x.stride():
+                res = res.to(x.dtype).contiguous(memory_format=torch.channels_last)
+                if res.shape != x.shape:
+                    raise _lib.HdError("bn_act: the residual must have the shape of the normalised tensor")
         B, Cc, H, W = x.shape
         R = B * H * W
         dt = 0 if x.dtype == torch.float32 else 1
@@ -737,16 +743,19 @@ class _BNActFn(torch.autograd.Function):
             stat_rows = R * dist.get_world_size(sync_group)
         check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
                                   _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
-                                  _ptr(y), st), "hd_bn_act_apply")
-        ctx.save_for_backward(x, w, b, save)
-        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows)
+                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), st), "hd_bn_act_apply")
+        # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
+        keep_res = res if (res is not None and int(res_mode) == 1) else None
+        ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
+        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows, 0 if res is None else int(res_mode))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, b, save = ctx.saved_tensors
-        dt, R, Cc, act, slot, sync_group, stat_rows = ctx.meta
+        x, w, b, save, *rest = ctx.saved_tensors
+        dt, R, Cc, act, slot, sync_group, stat_rows, res_mode = ctx.meta
+        res = rest[0] if rest else None
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         ld = _cl_row_stride(dy, 4 if dt == 0 else 8)
@@ -761,8 +770,9 @@ class _BNActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
+        dres = torch.empty_like(x) if res is not None else None
         check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
-                                       act, _ptr(dsums), st), "hd_bn_act_bwd_reduce")
+                                       act, _ptr(res), _ptr(dsums), st), "hd_bn_act_bwd_reduce")
         local = None
         if sync_group is not None:
             # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
@@ -771,10 +781,13 @@ class _BNActFn(torch.autograd.Function):
             local = dsums.view(rep, 2, Cc).sum(0)
             dist.all_reduce(dsums, group=sync_group)
         check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
-                                   _ptr(b), act, _ptr(dsums), _ptr(dx), _ptr(dg[0]), _ptr(dg[1]), st), "hd_bn_act_bwd_dx")
+                                   _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), st),
+              "hd_bn_act_bwd_dx")
+        # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
+        gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
         if local is not None:
-            return dx, local[1], local[0], None, None, None, None, None, None, None
-        return dx, dg[0], dg[1], None, None, None, None, None, None, None
+            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None
+        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:
@@ -783,23 +796,32 @@ def bn_act_slot(device, channels: int) -> _StatSlot:
 
 
 def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: float, act: str, training: bool,
-           slot: Optional[_StatSlot] = None, sync_group=None) -> torch.Tensor:
+           slot: Optional[_StatSlot] = None, sync_group=None, residual: Optional[torch.Tensor] = None,
+           residual_after_act: bool = False) -> torch.Tensor:
     """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip).
     sync_group: a torch.distributed process group -> statistics (and the backward sums) are taken over the
-    batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable."""
+    batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable.
+    residual: a tensor shaped like x that is added inside the apply kernel — before the activation
+    (`act(bn(x) + r)`, the ResNet bottleneck tail) or after it (`act(bn(x)) + r`, the YOLOv5 shortcut)."""
     if not bn_act_supported(x):
         raise _lib.HdError("bn_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0")
     code = _ACT_CODE[act]
     if training:
         if slot is None:
             slot = bn_act_slot(x.device, x.shape[1])
-        return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot, sync_group)
+        return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot, sync_group, residual,
+                              (2 if residual_after_act else 1) if residual is not None else 0)
     lib = _lib.load()
     B, Cc, H, W = x.shape
     y = torch.empty_like(x)
+    fused_act = code if (residual is None or residual_after_act) else 0
     check(lib.hd_bn_act_infer(_ptr(x), 0 if x.dtype == torch.float32 else 1, B * H * W, Cc, _ptr(weight.detach().float()),
-                              _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), code,
+                              _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), fused_act,
                               _ptr(y), _stream(x)), "hd_bn_act_infer")
+    if residual is not None:  # inference: the add (and a pre-add activation) stay plain torch ops
+        y = y + residual
+        if not residual_after_act:
+            y = {1: torch.nn.functional.silu, 2: torch.relu, 0: (lambda t: t)}[code](y)
     return y
 
 
@@ -874,12 +896,12 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
     check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")
     out["bn_apply_kernel"] = (run(lambda: check(lib.hd_bn_act_apply(
         _ptr(x), dt, R, 0, Cc, _ptr(sums), _ptr(w), _ptr(b), 1e-3, 0.03, None, None, _ptr(save[0]), _ptr(save[1]), code,
-        _ptr(y), st), "apply")), 2 * tb)
+        None, 0, _ptr(y), st), "apply")), 2 * tb)
     out["bn_bwd_reduce_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_reduce(
-        _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, _ptr(dsums), st), "reduce")), 2 * tb)
+        _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), st), "reduce")), 2 * tb)
     out["bn_bwd_dx_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_dx(
-        _ptr(x), _ptr(dy), 0, dt, R, 0, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, _ptr(dsums), _ptr(y),
-        _ptr(dg[0]), _ptr(dg[1]), st), "dx")), 3 * tb)
+        _ptr(x), _ptr(dy), 0, dt, R, 0, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), _ptr(y),
+        None, _ptr(dg[0]), _ptr(dg[1]), st), "dx")), 3 * tb)
     return out
 
 

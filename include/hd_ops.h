@@ -354,7 +354,12 @@ hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C, float* sum
 hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows, int C, const float* sums,
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean,
-                          float* save_invstd, int act, void* y, hd_stream stream);
+                          float* save_invstd, int act, const void* res, int res_mode, void* y,
+                          hd_stream stream);
+/* Residual input (same dtype/shape as x, dense rows): res_mode 0 = none (res NULL); 1 = y = act(bn(x) + res), the
+ * ResNet bottleneck tail; 2 = y = act(bn(x)) + res, the YOLOv5 bottleneck shortcut.  Backward: only mode 1 needs the
+ * kernels' help — pass the same `res` to _bwd_reduce and _bwd_dx (act' is taken at bn(x) + res) and _bwd_dx also
+ * writes d(res) = dz into dres; for mode 2 d(res) is dy itself and the backward entry points are called with NULL. */
 hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var,
                           float eps, int act, void* y, hd_stream stream);
@@ -362,11 +367,11 @@ hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const floa
  * of a wider channels-last tensor (the gradient of a concatenation input), multiple of the vector width. */
 hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
                                const float* save_mean, const float* save_invstd, const float* gamma,
-                               const float* beta, int act, float* dsums, hd_stream stream);
+                               const float* beta, int act, const void* res, float* dsums, hd_stream stream);
 hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                            int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
-                           const float* beta, int act, const float* dsums, void* dx, float* dgamma,
-                           float* dbeta, hd_stream stream);
+                           const float* beta, int act, const void* res, const float* dsums, void* dx,
+                           void* dres, float* dgamma, float* dbeta, hd_stream stream);
 
 /* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
 

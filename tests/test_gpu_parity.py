@@ -496,6 +496,42 @@ def test_bn_act_backward_reads_cat_gradient_slices_in_place(gpu, ops, dtype):
         assert H.rel_err(bd[k].grad.cpu().numpy(), br[k].grad.numpy()) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,after", [("relu", False), ("silu", True), ("silu", False), (None, False)])
+def test_bn_act_with_residual_matches_torch(gpu, ops, dtype, act, after):
+    """Residual input of the fused BatchNorm: act(bn(x) + r) (ResNet bottleneck tail) and act(bn(x)) + r (YOLOv5
+    shortcut), forward and all four gradients against float64 PyTorch; inference mode computes the same."""
+    g = torch.Generator().manual_seed(161)
+    B, C, Hh, Ww = 3, 16, 8, 9
+    x = (torch.randn((B, C, Hh, Ww), generator=g) * 1.4 + 0.1).to(dtype)
+    r = torch.randn((B, C, Hh, Ww), generator=g).to(dtype)
+    w = torch.rand(C, generator=g) + 0.5
+    b = torch.randn(C, generator=g) * 0.3
+    go = torch.randn((B, C, Hh, Ww), generator=g).to(dtype)
+    f = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}[act]
+    xr, rr = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    z = torch.nn.functional.batch_norm(xr, None, None, wr, br, True, 0.03, 1e-3)
+    yr = f(z) + rr if after else f(z + rr)
+    yr.backward(go.double())
+    cl = lambda t: t.to(gpu).contiguous(memory_format=torch.channels_last)
+    xd, rd = cl(x).requires_grad_(True), cl(r).requires_grad_(True)
+    wd, bd = w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+    ops.bn_arena_reset(gpu)
+    y = ops.bn_act(xd, wd, bd, rm, rv, 1e-3, 0.03, act, True, residual=rd, residual_after_act=after)
+    y.backward(cl(go))
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    for got, ref in ((xd.grad, xr.grad), (rd.grad, rr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert H.rel_err(got.float().cpu().numpy(), ref.numpy()) < tol
+    # inference mode: running statistics, same expression
+    yi = ops.bn_act(xd.detach(), wd, bd, rm, rv, 1e-3, 0.03, act, False, residual=rd.detach(), residual_after_act=after)
+    zi = torch.nn.functional.batch_norm(x.double(), rm.cpu().double(), rv.cpu().double(), w.double(), b.double(), False, 0.03, 1e-3)
+    yir = f(zi) + r.double() if after else f(zi + r.double())
+    assert H.rel_err(yi.float().cpu().numpy(), yir.numpy()) < tol
+
+
 # ------------------------------------------------------------------------------- hipGraph memset rewrite
 def test_graph_memset_nodes_are_rewritten(gpu, ops):
     """Capture a small graph containing real hipMemsetAsync calls (1-byte pattern on an odd length, 4-byte

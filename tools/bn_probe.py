@@ -17,9 +17,9 @@ for (B,Cc,H) in [(16,32,320),(16,64,160),(16,32,160),(16,128,80),(16,64,80),(16,
     st = ops._stream(x)
     t1 = timeit(lambda: lib.hd_bn_act_stats(ops._ptr(x),1,R,Cc,ops._ptr(sums),st))
     sums.zero_(); lib.hd_bn_act_stats(ops._ptr(x),1,R,Cc,ops._ptr(sums),st)
-    t2 = timeit(lambda: lib.hd_bn_act_apply(ops._ptr(x),1,R,0,Cc,ops._ptr(sums),ops._ptr(w),ops._ptr(b),1e-3,0.03,None,None,ops._ptr(save[0]),ops._ptr(save[1]),1,ops._ptr(y),st))
+    t2 = timeit(lambda: lib.hd_bn_act_apply(ops._ptr(x),1,R,0,Cc,ops._ptr(sums),ops._ptr(w),ops._ptr(b),1e-3,0.03,None,None,ops._ptr(save[0]),ops._ptr(save[1]),1,None,0,ops._ptr(y),st))
     ds = sums[32*Cc:]
-    t3 = timeit(lambda: lib.hd_bn_act_bwd_reduce(ops._ptr(x),ops._ptr(dy),0,1,R,Cc,ops._ptr(save[0]),ops._ptr(save[1]),ops._ptr(w),ops._ptr(b),1,ops._ptr(ds),st))
-    t4 = timeit(lambda: lib.hd_bn_act_bwd_dx(ops._ptr(x),ops._ptr(dy),0,1,R,0,Cc,ops._ptr(save[0]),ops._ptr(save[1]),ops._ptr(w),ops._ptr(b),1,ops._ptr(ds),ops._ptr(y),ops._ptr(dg[0]),ops._ptr(dg[1]),st))
+    t3 = timeit(lambda: lib.hd_bn_act_bwd_reduce(ops._ptr(x),ops._ptr(dy),0,1,R,Cc,ops._ptr(save[0]),ops._ptr(save[1]),ops._ptr(w),ops._ptr(b),1,None,ops._ptr(ds),st))
+    t4 = timeit(lambda: lib.hd_bn_act_bwd_dx(ops._ptr(x),ops._ptr(dy),0,1,R,0,Cc,ops._ptr(save[0]),ops._ptr(save[1]),ops._ptr(w),ops._ptr(b),1,None,ops._ptr(ds),ops._ptr(y),None,ops._ptr(dg[0]),ops._ptr(dg[1]),st))
     mb = x.numel()*2/1e6
     print(f"B{B} C{Cc} {H}x{H} ({mb:6.1f} MB): stats {t1:6.1f}us ({mb/t1*1e6/1e6:5.2f} TB/s)  apply {t2:6.1f}us ({2*mb/t2:5.2f})  bwd_reduce {t3:6.1f}us ({2*mb/t3:5.2f})  bwd_dx {t4:6.1f}us ({3*mb/t4:5.2f})")
