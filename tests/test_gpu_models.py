@@ -242,3 +242,24 @@ def test_training_step_with_device_mosaic_captures_and_varies(gpu):
     assert np.isfinite(losses).all()
     replayed = losses[4:]
     assert len(set(round(v, 5) for v in replayed)) > 3   # lr = 0: only the augmentation changes between replays
+
+
+@pytest.mark.parametrize("variant", ["n", "m"])
+def test_other_yolov5_widths_train_and_detect(gpu, variant):
+    """Width presets other than `s`: `m` has 48/96/192/... channels, whose bf16 vector-group count is not a
+    power of two and takes the fused BatchNorm's LDS-atomic fold instead of the shuffle/slot fold."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant=variant, num_classes=8, img_size=160)).to(gpu)
+    model = model.to(memory_format=torch.channels_last).train()
+    tr = Trainer(model, lr=1e-3, total_steps=20, warmup_steps=2, device=gpu, use_graph=True)
+    batch = _batch(2, 160, 8, 3, gpu, m_pad=8)
+    losses = [float(tr.step(*batch)[0]) for _ in range(8)]
+    assert tr._graph is not None, tr.graph_error
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        det, cnt = model.forward_test(batch[0], conf_thr=0.01)
+    assert det.shape == (2, 300, 6) and (cnt >= 0).all()
