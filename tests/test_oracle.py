@@ -174,6 +174,46 @@ def test_c_vs_torch_restatement_random(seed):
     assert np.array_equal(k1, k2.numpy()) and np.array_equal(c1, c2.numpy())
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_c_vs_torch_restatement_roi_pool_and_mosaic(seed):
+    """The two independent restatements of the newest ops on fresh random cases (exact equality: integer bin
+    bounds / tile offsets and a fixed summation order), including the autograd gradient of RoI max-pooling."""
+    from heltondetection_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    g = syn.make_generator(seed)
+    # RoI max-pooling over 1-3 levels; gradient = scatter to argmax == autograd through slices + amax
+    L = int(rng.integers(1, 4))
+    strides = [4, 8, 16][:L]
+    B, C, P = int(rng.integers(1, 3)), int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    feats = [torch.randn((B, C, int(np.ceil(80 / s)), int(np.ceil(80 / s))), generator=g) for s in strides]
+    R = int(rng.integers(1, 12))
+    rb = H.boxes_batch(1, R, 80, seed + 50, 3.0, 70.0)[0]
+    rois = torch.cat([torch.randint(0, B, (R, 1), generator=g).float(), rb], 1)
+    scales = [1.0 / s for s in strides]
+    out, arg = co.roi_pool_fwd([f.numpy() for f in feats], rois.numpy(), P, scales, 2, 56.0, 4)
+    ft = [f.clone().requires_grad_(True) for f in feats]
+    out_t = tr.roi_pool(ft, rois, P, scales, 2, 56.0, 4)
+    assert np.array_equal(out, out_t.detach().numpy())
+    go = torch.randn(out_t.shape, generator=g)
+    out_t.backward(go)
+    gf = co.roi_pool_bwd([tuple(f.shape) for f in feats], rois.numpy(), go.numpy(), arg, scales, 2, 56.0, 4)
+    for a, f in zip(gf, ft):  # random features: maxima are unique, so autograd's routing is the argmax
+        assert np.allclose(a, f.grad.numpy() if f.grad is not None else 0.0, rtol=1e-6, atol=1e-6)
+    # Mosaic-4
+    S = int(rng.choice([4, 10, 26]))
+    Bm, M = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+    img = syn.make_images(Bm, S, g)
+    gtb, gtc, mv = syn.make_targets(Bm, max(S, 16), g, "coco", 4, M)
+    gtb = gtb.clamp(max=float(S))
+    src = torch.from_numpy(rng.integers(0, Bm, (Bm, 4)).astype(np.int32))
+    ctr = torch.from_numpy(rng.integers(S // 2, 3 * S // 2 + 1, (Bm, 2)).astype(np.int32))
+    apl = torch.from_numpy(rng.integers(0, 2, (Bm,)).astype(np.int32))
+    a = co.mosaic4(img.numpy(), gtb.numpy(), gtc.numpy(), mv.numpy(), src.numpy(), ctr.numpy(), apl.numpy(), min_wh=0.3)
+    b = tr.mosaic4(img, gtb, gtc, mv, src, ctr, apl, min_wh=0.3)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y.numpy())
+
+
 def test_yolo_loss_grad_vs_autograd():
     preds = H.yolo_preds(2, 96, 11, 5)
     from heltondetection_amd import synthetic as syn
