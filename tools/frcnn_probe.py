@@ -4,6 +4,16 @@ from heltondetection_amd import synthetic as syn, ops
 from heltondetection_amd.detectors import build_detector
 from heltondetection_amd.train import Trainer
 dev = torch.device('cuda:0')
+if '--find' in sys.argv:
+    # MIOpen's solver search for ResNet50 at 832^2 is one long call inside the first step (> 7 min on a fresh box):
+    # a heartbeat keeps the run visibly alive
+    import threading, time as _t
+    def _beat():
+        t0 = _t.time()
+        while True:
+            _t.sleep(30)
+            print(f"[heartbeat] {int(_t.time() - t0)} s", flush=True)
+    threading.Thread(target=_beat, daemon=True).start()
 torch.backends.cudnn.benchmark = '--find' in sys.argv
 torch.manual_seed(0)
 B, S = 16, 832
