@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -81,7 +81,7 @@ SIGNATURES = {
     "hd_nms_workspace_bytes": (_Z, [_I, _I, _I]),
     "hd_nms_batched": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "hd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "hd_rpn_proposals": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "hd_rpn_proposals": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "hd_roi_level_map": (_I, [_P, _I, _I, _I, _F, _I, _P, _P]),
     "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
     "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),

@@ -42,14 +42,21 @@ class MaxIoUAssigner:
         labels = torch.where(mx >= self.pos, torch.ones_like(labels), labels)
         if self.low:
             B, M = gam.shape
+            N = labels.shape[1]
             valid = (gam >= 0) & (gmx > 0)
-            idx = torch.where(valid, gam, torch.zeros_like(gam)).long()
-            # scatter "1" at the best box of every valid gt, and re-point its match to that gt
-            upd = torch.zeros_like(labels)
-            upd.scatter_(1, idx, valid.to(labels.dtype))
+            # Padded gts and gts without any overlap go to a dummy column N (sliced off below): scattering them
+            # onto a real box would collide with a valid gt whose best box is that one, and scatter_ with duplicate
+            # indices is not deterministic on the GPU.  Two valid gts sharing one best box: every write of `upd` is
+            # the same 1, and `forced` takes the higher gt index ('amax' — the last writer of the sequential
+            # per-gt loop in the public MaxIoUAssigner).
+            idx = torch.where(valid, gam, torch.full_like(gam, N)).long()
+            upd = torch.zeros((B, N + 1), dtype=labels.dtype, device=labels.device)
+            upd.scatter_(1, idx, torch.ones_like(gam, dtype=labels.dtype))
+            upd = upd[:, :N]
             labels = torch.where(upd > 0, torch.ones_like(labels), labels)
-            gt_index = torch.arange(M, device=am.device, dtype=am.dtype)[None, :].expand(B, M)
-            forced = torch.full_like(am, -1)
-            forced.scatter_(1, idx, torch.where(valid, gt_index, torch.full_like(gt_index, -1)))
-            am = torch.where((upd > 0) & (forced >= 0), forced, am)
+            gt_index = torch.arange(M, device=am.device, dtype=am.dtype)[None, :].expand(B, M).contiguous()
+            forced = torch.full((B, N + 1), -1, dtype=am.dtype, device=am.device)
+            forced.scatter_reduce_(1, idx, gt_index, "amax", include_self=True)
+            forced = forced[:, :N]
+            am = torch.where(forced >= 0, forced, am)
         return labels, am, mx

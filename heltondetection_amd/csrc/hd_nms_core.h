@@ -20,13 +20,16 @@
 //
 // The result is bit-identical to the serial algorithm in oracle/hd_oracle.c: nms_one().
 #pragma once
+#include <atomic>
+
 #include "hd_common.h"
 
 namespace hdnms {
 
 constexpr int kSortThreads = 1024;
 constexpr int kSortTile = 16384;  // keys per LDS tile: 128 KiB of dynamic LDS (the CU has 160 KiB)
-constexpr int kMaxCand = 65536;   // 1024 lanes x one 64-bit removed-word each
+constexpr int kMaxCand = 65536;
+constexpr int kMaxDevices = 64;  // device ordinals with a cached "LDS opt-in done" flag (others re-issue it)   // 1024 lanes x one 64-bit removed-word each
 
 typedef unsigned long long u64;
 
@@ -350,12 +353,17 @@ inline hd_status run_core(const CoreWs& w, int B, const float4* cand_box, const 
                           int32_t* keep_count, hipStream_t s) {
   const int tile = w.key_cap < kSortTile ? w.key_cap : kSortTile;
   const size_t sort_lds = (size_t)tile * sizeof(u64);
-  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS needs the opt-in once per DEVICE (the attribute lives with the device's code
+  // object).  One flag per device ordinal; a race between two threads only repeats an idempotent host call.
+  static std::atomic<unsigned char> attr_set[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return HD_ERR_NO_DEVICE;
+  const bool tracked = dev >= 0 && dev < kMaxDevices;
+  if (!tracked || !attr_set[dev].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_gather_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortTile * (int)sizeof(u64)) != hipSuccess)
       return HD_ERR_LAUNCH;
-    attr_set = true;
+    if (tracked) attr_set[dev].store(1, std::memory_order_release);
   }
   hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(B), dim3(kSortThreads), sort_lds, s, w, cand_box, cand_cls,
                      cand_stride);

@@ -158,18 +158,21 @@ __global__ __launch_bounds__(256) void rpn_emit_kernel(const int32_t* __restrict
                                                        const int32_t* __restrict__ count, int NA, int post,
                                                        const float4* __restrict__ cand_box,
                                                        const float* __restrict__ logits, float4* __restrict__ rois,
-                                                       float* __restrict__ roi_scores) {
+                                                       float* __restrict__ roi_scores,
+                                                       int32_t* __restrict__ roi_index /* may be null */) {
   const int b = blockIdx.y;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < post; k += gridDim.x * blockDim.x) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc = 0.0f;
+    int gi = -1;
     if (k < count[b]) {
-      const int gi = keep[(size_t)b * post + k];
+      gi = keep[(size_t)b * post + k];
       r = cand_box[(size_t)b * NA + gi];
       sc = hd_sigmoid(logits[(size_t)b * NA + gi]);
     }
     rois[(size_t)b * post + k] = r;
     roi_scores[(size_t)b * post + k] = sc;
+    if (roi_index) roi_index[(size_t)b * post + k] = gi;
   }
 }
 
@@ -216,8 +219,8 @@ extern "C" size_t hd_rpn_proposals_workspace_bytes(int B, int NA, int n_levels, 
 extern "C" hd_status hd_rpn_proposals(const float* logits, const float* deltas, const float* anchors, int B,
                                       int NA, int n_levels, const int* level_sizes, int pre_nms_topk,
                                       int post_nms_topk, float iou_thr, float min_size, float img_h, float img_w,
-                                      float* rois, float* roi_scores, int32_t* count, void* workspace,
-                                      size_t workspace_bytes, hd_stream stream) {
+                                      float* rois, float* roi_scores, int32_t* roi_index, int32_t* count,
+                                      void* workspace, size_t workspace_bytes, hd_stream stream) {
   if (B <= 0 || NA <= 0 || n_levels <= 0 || n_levels > HD_MAX_LEVELS || pre_nms_topk <= 0 || post_nms_topk <= 0 ||
       B > 65535)
     return HD_ERR_SHAPE;
@@ -251,7 +254,7 @@ extern "C" hd_status hd_rpn_proposals(const float* logits, const float* deltas, 
   hd_status st = run_core(w, B, r.cand_box, r.cand_cls, (long long)NA, iou_thr, post_nms_topk, r.keep, count, s);
   if (st != HD_OK) return st;
   hipLaunchKernelGGL(rpn_emit_kernel, dim3((post_nms_topk + 255) / 256, B), dim3(256), 0, s, r.keep, count, NA,
-                     post_nms_topk, r.cand_box, logits, reinterpret_cast<float4*>(rois), roi_scores);
+                     post_nms_topk, r.cand_box, logits, reinterpret_cast<float4*>(rois), roi_scores, roi_index);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

@@ -23,10 +23,10 @@ class YOLOv5(nn.Module):
                                 in_channels=self.neck.out_channels)
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
+                # num_batches_tracked stays a buffer (checkpoints of stock torch BatchNorm2d modules load with
+                # strict=True, and ours load there); the fused HIP path never touches it — momentum is fixed, so
+                # the counter is not read, and there is no per-layer "add 1" launch
                 m.eps, m.momentum = 1e-3, 0.03
-                # momentum is fixed, so the step counter is never read; dropping it removes one
-                # 4 us "add 1" kernel per BN layer per step (57 launches for YOLOv5s)
-                m.num_batches_tracked = None
 
     def extract(self, images):
         return self.neck(self.backbone(images))

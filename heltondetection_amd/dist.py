@@ -42,7 +42,7 @@ def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "views", "pending", "work", "offsets")
+    __slots__ = ("params", "flat", "views", "pending", "work", "packed")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -56,6 +56,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.packed = False
 
 
 class GradReducer:
@@ -91,6 +92,7 @@ class GradReducer:
             for p in b.params:
                 self._bucket_of[p] = b
         self._avg_native = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self._next = 0  # index of the next bucket whose collective may be launched (strict bucket order)
         self._hooks = []
         for p in params:
             src = self._src.get(p)
@@ -104,21 +106,27 @@ class GradReducer:
         b = self._bucket_of[p]
         b.pending -= 1
         if b.pending == 0:
-            self._launch(b)
+            self._pack(b)
+            self._flush()
 
     def _grad_of(self, p):
         src = self._src.get(p)
         return p.grad if src is None else src.grad
 
-    def _launch(self, b: _Bucket):
-        # one multi-tensor copy per gradient dtype (fp32 from parameters, bf16 from weight shadows):
-        # _foreach_copy_ keeps its single-launch path only for dtype-homogeneous lists
+    def _pack(self, b: _Bucket):
+        """Copies the bucket's gradients into its flat buffer (one multi-tensor copy per gradient dtype: fp32 from
+        parameters, bf16 from weight shadows — _foreach_copy_ keeps its single-launch path only for
+        dtype-homogeneous lists), zero-fills the slots of parameters that received no gradient this step, and
+        re-points .grad at the views.  Never launches a collective: that is _flush()'s job, in bucket order."""
         groups: Dict[torch.dtype, Tuple[list, list]] = {}
         for p, v in zip(b.params, b.views):
             g = self._grad_of(p)
-            vs, gs = groups.setdefault(g.dtype, ([], []))
-            vs.append(v)
-            gs.append(g)
+            if g is None:
+                v.zero_()  # unused parameter: contributes zeros to the average
+            elif g.data_ptr() != v.data_ptr():
+                vs, gs = groups.setdefault(g.dtype, ([], []))
+                vs.append(v)
+                gs.append(g)
         for vs, gs in groups.values():
             torch._foreach_copy_(vs, gs)
         for p, v in zip(b.params, b.views):
@@ -126,46 +134,53 @@ class GradReducer:
             src = self._src.get(p)
             if src is not None:
                 src.grad = None
-        if self.world > 1 and not self.defer:
-            if self._avg_native:
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            else:
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.pending = 0
+        b.packed = True
+
+    def _flush(self, force: bool = False):
+        """Launches the all-reduce of every packed bucket whose predecessors have been launched, strictly in
+        bucket-index order: gradient-readiness order can differ between ranks (a bucket left incomplete on one
+        rank is packed last there), and collectives issued in different orders on different ranks hang or mix
+        up buffers on RCCL.  Deferred mode (hipGraph replay) launches nothing until finish() forces it."""
+        if self.world <= 1 or (self.defer and not force):
+            return
+        op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
+        while self._next < len(self.buckets) and self.buckets[self._next].packed:
+            b = self.buckets[self._next]
+            b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+            self._next += 1
 
     def prepare(self):
         """Call before backward: drop last step's gradient views so autograd hands over fresh grads."""
+        self._next = 0
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+            b.packed = False
             for p in b.params:
                 p.grad = None
                 src = self._src.get(p)
                 if src is not None:
                     src.grad = None
 
-    def finish(self):
-        """Call after backward: wait for every bucket (the current stream then depends on RCCL's)."""
+    def pack_incomplete(self):
+        """Call right after backward (inside the captured region in hipGraph mode, so the packing copies of
+        buckets with unused parameters are graph nodes too and replay every step): packs the buckets autograd
+        did not complete.  Idempotent."""
         for b in self.buckets:
-            if b.pending != 0:
-                # parameters that received no gradient this step (unused branch): reduce zeros
-                for p, v in zip(b.params, b.views):
-                    g = self._grad_of(p)
-                    if g is None or g.data_ptr() != v.data_ptr():
-                        if g is None:
-                            v.zero_()
-                        else:
-                            v.copy_(g)
-                        p.grad = v
-                        if p in self._src:
-                            self._src[p].grad = None
-                b.pending = 0
-                if self.world > 1:
-                    op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
-                    b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
-        if self.world > 1 and self.defer:
-            op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
-            for b in self.buckets:
-                b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+            if not b.packed:
+                self._pack(b)
+        self._flush()
+
+    def finish(self):
+        """Call after backward: every bucket is reduced exactly once, in bucket order; then wait for all of
+        them (the current stream then depends on RCCL's)."""
+        self.pack_incomplete()
+        if self.defer:
+            # replay mode: the hooks did not run this step (the graph replayed their packing copies), so the
+            # launch cursor is wherever the capture step left it
+            self._next = 0
+        self._flush(force=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()

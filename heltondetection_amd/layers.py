@@ -50,7 +50,8 @@ class FusedBNAct:
     def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False):
         """residual: added inside the fused kernel, before (`act(bn(x) + r)`) or after (`act(bn(x)) + r`) the
         activation; the unfused fallback computes the same expression with torch ops."""
-        if FusedBNAct.enabled and x.is_cuda:
+        # momentum=None (cumulative moving average) needs the step counter: that case stays on torch's BatchNorm
+        if FusedBNAct.enabled and x.is_cuda and bn.momentum is not None:
             from . import ops
             if ops.bn_act_supported(x):
                 slot = getattr(bn, "_hd_slot", None)
@@ -58,8 +59,7 @@ class FusedBNAct:
                     slot = ops.bn_act_slot(x.device, x.shape[1])
                     bn._hd_slot = slot
                 training = bn.training or bn.running_mean is None
-                return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                  bn.momentum if bn.momentum is not None else 0.1, act, training, slot,
+                return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, training, slot,
                                   FusedBNAct.sync_group if training else None, residual, residual_after_act)
         if residual is None:
             return FusedBNAct._ACTS[act](bn(x))

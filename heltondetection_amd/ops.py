@@ -196,8 +196,10 @@ def nms_batched(boxes: torch.Tensor, scores: torch.Tensor, cls: Optional[torch.T
 
 
 def rpn_proposals(logits: torch.Tensor, deltas: torch.Tensor, anchors: torch.Tensor, level_sizes: Sequence[int],
-                  pre_nms_topk: int, post_nms_topk: int, iou_thr: float, min_size: float, img_h: float, img_w: float):
-    """Returns (rois [B,post,4], scores [B,post], count [B])."""
+                  pre_nms_topk: int, post_nms_topk: int, iou_thr: float, min_size: float, img_h: float, img_w: float,
+                  return_index: bool = False):
+    """Returns (rois [B,post,4], scores [B,post], count [B]) and, with return_index, the anchor index of every
+    kept proposal [B,post] int32 (-1 padded) — the NMS keep set itself."""
     lib = _lib.load()
     logits, deltas, anchors = _need(logits, _F32, "logits"), _need(deltas, _F32, "deltas"), _need(anchors, _F32, "anchors")
     B, NA = logits.shape
@@ -207,11 +209,14 @@ def rpn_proposals(logits: torch.Tensor, deltas: torch.Tensor, anchors: torch.Ten
     rois = torch.empty((B, post_nms_topk, 4), dtype=_F32, device=dev)
     sc = torch.empty((B, post_nms_topk), dtype=_F32, device=dev)
     cnt = torch.empty((B,), dtype=_I32, device=dev)
+    idx = torch.empty((B, post_nms_topk), dtype=_I32, device=dev) if return_index else None
     ws, wsb = _ws(lib.hd_rpn_proposals_workspace_bytes(B, NA, L, pre_nms_topk, post_nms_topk), dev)
-    check(lib.hd_rpn_proposals(_ptr(logits), _ptr(deltas), _ptr(anchors), B, NA, L, ls, int(pre_nms_topk),
-                               int(post_nms_topk), float(iou_thr), float(min_size), float(img_h), float(img_w),
-                               _ptr(rois), _ptr(sc), _ptr(cnt), _ptr(ws), wsb, _stream(logits)), "hd_rpn_proposals")
-    return rois, sc, cnt
+    with _timed("rpn_proposals"):
+        check(lib.hd_rpn_proposals(_ptr(logits), _ptr(deltas), _ptr(anchors), B, NA, L, ls, int(pre_nms_topk),
+                                   int(post_nms_topk), float(iou_thr), float(min_size), float(img_h), float(img_w),
+                                   _ptr(rois), _ptr(sc), _ptr(idx), _ptr(cnt), _ptr(ws), wsb, _stream(logits)),
+              "hd_rpn_proposals")
+    return (rois, sc, cnt, idx) if return_index else (rois, sc, cnt)
 
 
 # ------------------------------------------------------------------------------- RoIAlign

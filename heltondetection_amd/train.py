@@ -113,6 +113,9 @@ class Trainer:
             with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
                 loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
             loss.backward()
+            # buckets autograd left incomplete (parameters without a gradient this step) are packed here, inside
+            # the captured region in hipGraph mode, so their packing copies replay with the graph
+            self.reducer.pack_incomplete()
         finally:
             LowpWeights.on = False
         return loss.detach(), parts
@@ -139,13 +142,24 @@ class Trainer:
     def step(self, images, gt_boxes, gt_cls, m_valid):
         batch = (images, gt_boxes, gt_cls, m_valid)
         if self.use_graph and self._graph is None and self._eager_steps >= self._graph_warmup:
+            err = None
             try:
                 self._capture(batch)
             except Exception as e:  # stay correct: fall back to eager and remember why
-                self.graph_error = repr(e)
+                err = repr(e)
+            if self.reducer.world > 1:
+                # every rank must take the same branch: a rank that fell back to eager would launch its collectives
+                # from the autograd hooks while the others launch theirs after the replay
+                import torch.distributed as dist
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.reducer.group)
+                if int(ok.item()) == 0 and err is None:
+                    err = "hipGraph capture failed on another rank"
+            if err is not None:
+                self.graph_error = err
                 self.use_graph = False
                 self.reducer.defer = False
-                self._graph = None
+                self._graph = self._static = self._static_out = None
                 torch.cuda.synchronize(self.device)
         if self._graph is not None:
             for dst, src in zip(self._static, batch):

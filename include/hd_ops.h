@@ -133,14 +133,17 @@ hd_status hd_nms_batched(const float* boxes, const float* scores, const int32_t*
  * NMS per level (level acts as the class id), keep the best `post_nms_topk` overall
  * by logit.  Outputs are padded with zeros; scores are sigmoid(logit).
  * logits [B,NA], deltas [B,NA,4], anchors [NA,4] in the hd_anchor_grid order,
- * level_sizes: host [n_levels], sum = NA.  rois [B,post,4], roi_scores [B,post], count [B]. */
+ * level_sizes: host [n_levels], sum = NA.  rois [B,post,4], roi_scores [B,post], count [B].
+ * roi_index [B,post] int32 or NULL: the anchor index (0..NA-1) each kept proposal came from, in output
+ * order, -1 padded — the NMS keep set itself, for callers (and parity tests) that need indices
+ * rather than boxes. */
 size_t hd_rpn_proposals_workspace_bytes(int B, int NA, int n_levels, int pre_nms_topk,
                                         int post_nms_topk);
 hd_status hd_rpn_proposals(const float* logits, const float* deltas, const float* anchors, int B,
                            int NA, int n_levels, const int* level_sizes, int pre_nms_topk,
                            int post_nms_topk, float iou_thr, float min_size, float img_h,
-                           float img_w, float* rois, float* roi_scores, int32_t* count,
-                           void* workspace, size_t workspace_bytes, hd_stream stream);
+                           float img_w, float* rois, float* roi_scores, int32_t* roi_index,
+                           int32_t* count, void* workspace, size_t workspace_bytes, hd_stream stream);
 
 /* ---- RoIAlign over pyramid levels (README.md:65,73) ------------------------ */
 

@@ -165,17 +165,18 @@ def nms_batched(boxes, scores, cls=None, n_valid=None, score_thr=-np.inf, iou_th
 
 
 def rpn_proposals(logits, deltas, anchors, level_sizes, pre_nms_topk, post_nms_topk, iou_thr,
-                  min_size, img_h, img_w):
+                  min_size, img_h, img_w, return_index=False):
     logits, deltas, anchors = _f(logits), _f(deltas), _f(anchors)
     B, NA = logits.shape
     ls = np.ascontiguousarray(level_sizes, dtype=np.int32)
     rois = np.empty((B, post_nms_topk, 4), np.float32)
     sc = np.empty((B, post_nms_topk), np.float32)
     cnt = np.empty((B,), np.int32)
+    idx = np.empty((B, post_nms_topk), np.int32)
     lib().orc_rpn_proposals(_p(logits), _p(deltas), _p(anchors), C.c_int(B), C.c_int(NA), C.c_int(len(ls)), _p(ls),
                             C.c_int(pre_nms_topk), C.c_int(post_nms_topk), C.c_float(iou_thr), C.c_float(min_size),
-                            C.c_float(img_h), C.c_float(img_w), _p(rois), _p(sc), _p(cnt))
-    return rois, sc, cnt
+                            C.c_float(img_h), C.c_float(img_w), _p(rois), _p(sc), _p(idx), _p(cnt))
+    return (rois, sc, cnt, idx) if return_index else (rois, sc, cnt)
 
 
 # ---------------------------------------------------------------------------- RoIAlign

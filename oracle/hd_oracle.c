@@ -245,12 +245,13 @@ void orc_nms_batched(const float* boxes, const float* scores, const int32_t* cls
 void orc_rpn_proposals(const float* logits, const float* deltas, const float* anchors, int B,
                        int NA, int n_levels, const int* level_sizes, int pre_nms_topk,
                        int post_nms_topk, float iou_thr, float min_size, float img_h, float img_w,
-                       float* rois, float* roi_scores, int32_t* count) {
+                       float* rois, float* roi_scores, int32_t* roi_index /* [B,post] or NULL */, int32_t* count) {
   int cap = 0;
   for (int l = 0; l < n_levels; ++l) cap += level_sizes[l] < pre_nms_topk ? level_sizes[l] : pre_nms_topk;
   float* cb = (float*)malloc(sizeof(float) * 4 * (size_t)(cap > 0 ? cap : 1));
   float* cs = (float*)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1));
   int32_t* cl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1));
+  int32_t* ci = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)); /* candidate -> anchor index */
   int32_t* keep = (int32_t*)malloc(sizeof(int32_t) * (size_t)(post_nms_topk > 0 ? post_nms_topk : 1));
   orc_sortrec* rec = (orc_sortrec*)malloc(sizeof(orc_sortrec) * (size_t)(NA > 0 ? NA : 1));
   for (int b = 0; b < B; ++b) {
@@ -271,6 +272,7 @@ void orc_rpn_proposals(const float* logits, const float* deltas, const float* an
         memcpy(cb + (int64_t)nc * 4, bx, sizeof(bx));
         cs[nc] = ok ? lg[gi] : -INFINITY;
         cl[nc] = l;
+        ci[nc] = gi;
         ++nc;
       }
       off += n;
@@ -282,13 +284,15 @@ void orc_rpn_proposals(const float* logits, const float* deltas, const float* an
       if (i < cnt) {
         memcpy(r, cb + (int64_t)keep[i] * 4, 4 * sizeof(float));
         roi_scores[(int64_t)b * post_nms_topk + i] = sigmoidf_(cs[keep[i]]);
+        if (roi_index) roi_index[(int64_t)b * post_nms_topk + i] = ci[keep[i]];
       } else {
         r[0] = r[1] = r[2] = r[3] = 0.0f;
         roi_scores[(int64_t)b * post_nms_topk + i] = 0.0f;
+        if (roi_index) roi_index[(int64_t)b * post_nms_topk + i] = -1;
       }
     }
   }
-  free(rec); free(keep); free(cl); free(cs); free(cb);
+  free(rec); free(keep); free(ci); free(cl); free(cs); free(cb);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -152,12 +152,14 @@ def nms_batched(boxes, scores, cls=None, n_valid=None, score_thr=-float("inf"), 
 
 def rpn_proposals(logits, deltas, anchors, level_sizes, pre_nms_topk, post_nms_topk, iou_thr, min_size,
                   img_h, img_w):
+    """-> (rois, scores, count, index): index [B,post] = anchor index of every kept proposal, -1 padded."""
     B, NA = logits.shape
     rois = torch.zeros((B, post_nms_topk, 4))
     sc = torch.zeros((B, post_nms_topk))
     cnt = torch.zeros((B,), dtype=torch.int32)
+    idx = torch.full((B, post_nms_topk), -1, dtype=torch.int32)
     for b in range(B):
-        cb, cs, cl = [], [], []
+        cb, cs, cl, ci = [], [], [], []
         off = 0
         for l, n in enumerate(level_sizes):
             lg = logits[b, off:off + n]
@@ -167,13 +169,15 @@ def rpn_proposals(logits, deltas, anchors, level_sizes, pre_nms_topk, post_nms_t
             cb.append(bx)
             cs.append(torch.where(ok, logits[b, order], torch.full_like(logits[b, order], -float("inf"))))
             cl.append(torch.full((len(order),), l, dtype=torch.int32))
+            ci.append(order.to(torch.int32))
             off += n
-        cb, cs, cl = torch.cat(cb), torch.cat(cs), torch.cat(cl)
+        cb, cs, cl, ci = torch.cat(cb), torch.cat(cs), torch.cat(cl), torch.cat(ci)
         k = nms_single(cb, cs, cl, -float("inf"), iou_thr, 0, post_nms_topk)
         cnt[b] = len(k)
         rois[b, : len(k)] = cb[k]
         sc[b, : len(k)] = torch.sigmoid(cs[k])
-    return rois, sc, cnt
+        idx[b, : len(k)] = ci[k]
+    return rois, sc, cnt, idx
 
 
 # ------------------------------------------------------------------------------- RoIAlign

@@ -66,10 +66,11 @@ def main():
     logits = torch.randn((2, NA), generator=g).numpy()
     deltas = (torch.randn((2, NA, 4), generator=g) * 0.2).numpy()
     lsz = [h * w * 3 for h, w in hw]
-    rois, rsc, rcnt = co.rpn_proposals(logits, deltas, anchors, lsz, 100, 40, 0.7, 2.0, 96.0, 96.0)
+    rois, rsc, rcnt, ridx = co.rpn_proposals(logits, deltas, anchors, lsz, 100, 40, 0.7, 2.0, 96.0, 96.0, return_index=True)
     r2 = tr.rpn_proposals(torch.from_numpy(logits), torch.from_numpy(deltas), torch.from_numpy(anchors), lsz, 100, 40, 0.7, 2.0, 96.0, 96.0)
     agree(rcnt, r2[2].numpy(), 0.0, "rpn count"); agree(rois, r2[0].numpy(), 1e-5, "rpn rois"); agree(rsc, r2[1].numpy(), 1e-5, "rpn scores")
-    d.update(rpn_logits=logits, rpn_deltas=deltas, rpn_rois=rois, rpn_scores=rsc, rpn_count=rcnt)
+    agree(ridx, r2[3].numpy(), 0.0, "rpn kept anchor indices")
+    d.update(rpn_logits=logits, rpn_deltas=deltas, rpn_rois=rois, rpn_scores=rsc, rpn_count=rcnt, rpn_index=ridx)
     # RoIAlign
     g = syn.make_generator(6)
     feats = [torch.randn((2, 8, 96 // s, 96 // s), generator=g).numpy() for s in strides]

@@ -6,6 +6,9 @@ import torch
 
 from heltondetection_amd import synthetic as syn
 
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_v1.npz")
 YOLO_ANCHORS = [[[10, 13], [16, 30], [33, 23]], [[30, 61], [62, 45], [59, 119]], [[116, 90], [156, 198], [373, 326]]]
 YOLO_STRIDES = [8, 16, 32]
 

@@ -142,3 +142,93 @@ def test_grad_reducer_with_bf16_grad_sources_two_ranks_gloo(tmp_path):
         assert torch.equal(a, b)
     for red, l0, l1 in zip(s0["reduced"][:2], s0["local"], s1["local"]):
         assert torch.allclose(red, (l0 + l1) / 2, rtol=1e-6, atol=1e-9)  # fp32 mean of the bf16 shard gradients
+
+
+class _PartlyUsed(torch.nn.Module):
+    """`b` never takes part in the forward pass: its bucket stays incomplete after backward."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = torch.nn.Linear(4, 4)
+        self.b = torch.nn.Linear(4, 4)
+        self.c = torch.nn.Linear(4, 4)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.a(x)))
+
+
+def _unused_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from heltondetection_amd.dist import GradReducer, init_distributed
+    init_distributed("gloo")
+    out = {}
+    for defer in (False, True):
+        model = _PartlyUsed()
+        # tiny buckets: a/b/c land in different buckets, and b's bucket is never completed by autograd
+        red = GradReducer(model, bucket_bytes=32, first_bucket_bytes=32, defer_collectives=defer)
+        assert len(red.buckets) >= 3
+        x = torch.full((2, 4), float(rank + 1))
+        launches = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            launches.append(t.data_ptr())
+            return real(t, *a, **k)
+
+        dist.all_reduce = counting
+        try:
+            for step in range(2):
+                red.prepare()
+                model(x).sum().backward()
+                red.pack_incomplete()
+                red.finish()
+                # every bucket reduced exactly once per step, in bucket order
+                assert launches == [b.flat.data_ptr() for b in red.buckets], (defer, step)
+                launches.clear()
+            # "replay": the hooks do not run and prepare() is not called (the hipGraph replays the packing copies);
+            # finish() must again reduce every bucket exactly once and leave .grad on the flat views
+            if defer:
+                for b in red.buckets:
+                    b.flat.fill_(float(rank + 1))
+                red.finish()
+                assert launches == [b.flat.data_ptr() for b in red.buckets]
+                launches.clear()
+                assert all(torch.allclose(b.flat, torch.full_like(b.flat, 1.5)) for b in red.buckets)
+                assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                           for b in red.buckets for p, v in zip(b.params, b.views))
+                # restore real gradients for the comparison below
+                red.prepare()
+                model(x).sum().backward()
+                red.finish()
+                launches.clear()
+        finally:
+            dist.all_reduce = real
+        out[defer] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    torch.save(out, os.path.join(tmp, f"u{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_reducer_unused_parameter_reduced_once_gloo(tmp_path):
+    """a bucket with a gradient-less parameter was all-reduced twice in deferred mode (mean 3.0 instead
+    of 2.0 for constant per-rank gradients) — every bucket must be reduced exactly once, eager and deferred alike."""
+    world, port = 2, _free_port()
+    mp.spawn(_unused_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    u0, u1 = torch.load(tmp_path / "u0.pt"), torch.load(tmp_path / "u1.pt")
+    # serial reference
+    ref = None
+    for rk in range(world):
+        m = _PartlyUsed()
+        m(torch.full((2, 4), float(rk + 1))).sum().backward()
+        gs = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+        ref = gs if ref is None else {n: ref[n] + gs[n] for n in gs}
+    ref = {n: v / world for n, v in ref.items()}
+    for defer in (False, True):
+        for n in ref:
+            assert torch.equal(u0[defer][n], u1[defer][n]), (defer, n)
+            assert torch.allclose(u0[defer][n], ref[n], rtol=1e-6, atol=1e-8), (defer, n)
+        assert float(u0[defer]["b.weight"].abs().max()) == 0.0  # the unused layer's mean gradient is zero

@@ -164,7 +164,8 @@ def test_nms_idempotent_large(gpu, ops):
 
 
 # ------------------------------------------------------------------------------- RPN proposals
-@pytest.mark.parametrize("size,A,pre,post", [(256, 3, 300, 100), (416, 3, 1000, 300)])
+# 832 / pre 2000 / post 1000 is BASELINE config 3's own proposal stage (5 levels x 3 anchors, NA = 57 723 per image)
+@pytest.mark.parametrize("size,A,pre,post", [(256, 3, 300, 100), (416, 3, 1000, 300), (832, 3, 2000, 1000)])
 def test_rpn_proposals(gpu, ops, size, A, pre, post):
     B = 2
     strides = [4, 8, 16, 32, 64]
@@ -176,14 +177,30 @@ def test_rpn_proposals(gpu, ops, size, A, pre, post):
     g = torch.Generator().manual_seed(41)
     logits = torch.randn((B, NA), generator=g)
     deltas = torch.randn((B, NA, 4), generator=g) * 0.2
-    rois, sc, cnt = ops.rpn_proposals(dev(logits, gpu), dev(deltas, gpu), dev(torch.from_numpy(anchors), gpu), level_sizes,
-                                      pre, post, 0.7, 2.0, float(size), float(size))
-    r_rois, r_sc, r_cnt = co.rpn_proposals(logits.numpy(), deltas.numpy(), anchors, level_sizes, pre, post, 0.7, 2.0,
-                                           float(size), float(size))
+    rois, sc, cnt, idx = ops.rpn_proposals(dev(logits, gpu), dev(deltas, gpu), dev(torch.from_numpy(anchors), gpu),
+                                           level_sizes, pre, post, 0.7, 2.0, float(size), float(size), return_index=True)
+    r_rois, r_sc, r_cnt, r_idx = co.rpn_proposals(logits.numpy(), deltas.numpy(), anchors, level_sizes, pre, post, 0.7, 2.0,
+                                                  float(size), float(size), return_index=True)
     assert np.array_equal(cnt.cpu().numpy(), r_cnt)
-    # decoded boxes go through expf: compare with tolerance; the kept SET/ORDER is checked via the boxes
+    # the keep set, bit-exact: the anchor index of every surviving proposal, in output order, -1 padded
+    # (north_star: "bit-exact for anchor indices / NMS keep masks")
+    assert np.array_equal(idx.cpu().numpy(), r_idx)
+    # decoded boxes go through expf (device libm vs glibc differ by ulps): tolerance on the coordinates only
     assert np.abs(rois.cpu().numpy() - r_rois).max() < 1e-2 * 1e-2 * size + 1e-3
     assert np.abs(sc.cpu().numpy() - r_sc).max() < TOL
+    # without the index output the other outputs are unchanged
+    rois2, sc2, cnt2 = ops.rpn_proposals(dev(logits, gpu), dev(deltas, gpu), dev(torch.from_numpy(anchors), gpu), level_sizes,
+                                         pre, post, 0.7, 2.0, float(size), float(size))
+    assert torch.equal(rois2, rois) and torch.equal(sc2, sc) and torch.equal(cnt2, cnt)
+
+
+def test_rpn_proposals_golden_index(gpu, ops):
+    gold = np.load(H.GOLDEN)
+    rois, sc, cnt, idx = ops.rpn_proposals(dev(torch.from_numpy(gold["rpn_logits"]), gpu), dev(torch.from_numpy(gold["rpn_deltas"]), gpu),
+                                           dev(torch.from_numpy(gold["anchor_grid"]), gpu), [432, 108, 27], 100, 40, 0.7, 2.0,
+                                           96.0, 96.0, return_index=True)
+    assert np.array_equal(cnt.cpu().numpy(), gold["rpn_count"])
+    assert np.array_equal(idx.cpu().numpy(), gold["rpn_index"])
 
 
 # ------------------------------------------------------------------------------- RoIAlign

@@ -46,10 +46,14 @@ def test_golden_nms(gold):
 
 
 def test_golden_rpn(gold):
-    rois, sc, cnt = co.rpn_proposals(gold["rpn_logits"], gold["rpn_deltas"], gold["anchor_grid"], [432, 108, 27], 100, 40,
-                                     0.7, 2.0, 96.0, 96.0)
+    rois, sc, cnt, idx = co.rpn_proposals(gold["rpn_logits"], gold["rpn_deltas"], gold["anchor_grid"], [432, 108, 27], 100,
+                                          40, 0.7, 2.0, 96.0, 96.0, return_index=True)
     assert np.array_equal(cnt, gold["rpn_count"])
     assert np.array_equal(rois, gold["rpn_rois"]) and np.array_equal(sc, gold["rpn_scores"])
+    assert np.array_equal(idx, gold["rpn_index"])  # the keep set itself (anchor indices, -1 padded)
+    i2 = tr.rpn_proposals(torch.from_numpy(gold["rpn_logits"]), torch.from_numpy(gold["rpn_deltas"]),
+                          torch.from_numpy(gold["anchor_grid"]), [432, 108, 27], 100, 40, 0.7, 2.0, 96.0, 96.0)[3]
+    assert np.array_equal(i2.numpy(), gold["rpn_index"])
 
 
 def test_golden_roi_align(gold):
