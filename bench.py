@@ -248,14 +248,37 @@ def micro_kernels(device):
         sc = torch.rand((16, Nn), generator=g).to(device)
         ms = timeit(lambda: ops.nms_batched(bx, sc, None, None, -1.0, 0.7, 0, 1000))
         add("nms_batched (sort+mask+scan)", ms, 16 * 28 * Nn, f"B=16 N={Nn} thr=0.7 max_out=1000", "latency")
-    # RoIAlign config 3: 832^2 bs16, P2-P5 channels-last, 512 RoIs per image
-    feats = [torch.randn((16, 256, 832 // s, 832 // s), device=device).contiguous(memory_format=torch.channels_last)
-             for s in (4, 8, 16, 32)]
-    R = 16 * 512
-    rb = syn.random_boxes(R, 832.0, g, 16.0, 400.0)
-    rois = torch.cat([torch.arange(16).repeat_interleave(512)[:, None].float(), rb], 1).to(device)
-    ms = timeit(lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
-    add("roi_align_kernel<fwd>", ms, R * 256 * 49 * 4, f"R={R} C=256 P=7 s=2 (out bytes only)")
+    # RoIAlign config 3: 832^2 bs16, P2-P5 channels-last, 512 RoIs per image (forward, the inference-side count) and
+    # 128 per image (the train step's sampled RoIs, forward + backward), float32 and bfloat16 maps.
+    # Algorithmic bytes: the output (or incoming gradient) tensor + every feature byte under at least one RoI,
+    # bounded above by the four maps (forward reads them, backward read-modify-writes the f32 gradient maps).
+    for dt, dn in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        feats = [torch.randn((16, 256, 832 // s, 832 // s), device=device).to(dt).contiguous(memory_format=torch.channels_last)
+                 for s in (4, 8, 16, 32)]
+        map_bytes = sum(f.numel() * f.element_size() for f in feats)
+        for per_img in (512, 128):
+            R = 16 * per_img
+            rb = syn.random_boxes(R, 832.0, g, 16.0, 400.0)
+            rois = torch.cat([torch.arange(16).repeat_interleave(per_img)[:, None].float(), rb], 1).to(device)
+            esz = 4 if dt == torch.float32 else 2
+            ms = timeit(lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
+            add(f"roi_align_fwd_cl_kernel<{dn}>", ms, R * 256 * 49 * esz + map_bytes,
+                f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the four maps once)")
+            if per_img == 128:
+                fr = [f.detach().requires_grad_(True) for f in feats]
+                out = ops.roi_align(fr, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True)
+                go = torch.randn_like(out)
+                ops.enable_timing("roi_align_bwd")
+                for _ in range(8):
+                    out.backward(go, retain_graph=True)
+                torch.cuda.synchronize()
+                tb = sorted(ops.collect_timing()["roi_align_bwd"])
+                ops.disable_timing()
+                add("roi_align_bwd_cl_kernel", tb[len(tb) // 2], R * 256 * 49 * esz + 2 * sum(f.numel() * 4 for f in feats),
+                    f"R={R} C=256 P=7 s=2 grad {dn} -> f32 maps (kernel only; float atomics, bytes = grad in + maps read-modify-write)",
+                    "atomic")
+                del fr, out, go
+        del feats
     # RPN proposals, config 3: 832^2, 5 levels x 3 anchors, pre 2000 / post 1000
     strides_r = [4, 8, 16, 32, 64]
     hw = [(math.ceil(832 / s), math.ceil(832 / s)) for s in strides_r]

@@ -30,6 +30,7 @@ class RoiLevels(C.Structure):
         ("k_min", C.c_int),
         ("canonical_scale", C.c_float),
         ("canonical_level", C.c_int),
+        ("dtype", C.c_int),
     ]
 
 
@@ -83,8 +84,8 @@ SIGNATURES = {
     "hd_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "hd_rpn_proposals": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "hd_roi_level_map": (_I, [_P, _I, _I, _I, _F, _I, _P, _P]),
-    "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
-    "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P]),
+    "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
+    "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
     "hd_roi_pool_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_yolo_decode": (_I, [_P, _I, _P, _P]),

@@ -1,20 +1,36 @@
 // roi_align.hip — RoIAlign (default) and quantised RoI max-pooling (the "-RoIPooling" variant)
 // over pyramid levels, forward and backward
 // (reference README.md:65,73 "RoIAlign" default, README.md:73 "FasterRCNN-FPNP2-RoIPooling";
-// SURVEY.md §8a "RoIAlign over FPN levels").
+// SURVEY.md §8a "RoIAlign over FPN levels": f32, or bf16 features with f32 accumulation).
 //
-// A gather: per RoI bin, sampling_ratio^2 bilinear samples x 4 taps x C channels.  The layout
-// decision that matters on MI355X: features are consumed through explicit strides and the fast
-// case is channels-last (sc == 1) — a wave then reads 64 consecutive channels of one tap as one
-// 256-byte coalesced request, and neighbouring samples/bins of the same RoI hit the same lines
-// in L1/L2 (a RoI touches ~ (roi_h*roi_w) * C * 4 bytes once from HBM; everything else is
-// on-chip reuse).  Lanes = channels, so the tap coordinates and weights are wave-uniform scalar
-// work and all vector work is loads + FMAs.
+// A gather: per RoI bin, sampling_ratio^2 bilinear samples x 4 taps x C channels.  Bilinear weights
+// factor into a row part and a column part, and so does the sample grid of a bin, so
+//     out[ph][pw][c] = 1/count * sum_{(y, wy) in rows(ph)} sum_{(x, wx) in cols(pw)} wy * wx * f[y][x][c]
+// (a sample outside [-1, size] zeroes its own row or column weight — exactly the "contributes 0" rule).
 //
-// One workgroup = one (RoI, pooled row ph); 256 lanes stride over channels.  The level of a
-// RoI is found with exact area thresholds (no log2 rounding), identical to the oracle.
-// Backward is the transposed scatter with float atomics (summation order not fixed).
+// Fast path (channels-last features, sampling_ratio 1 or 2), roi_align_fwd_cl_kernel:
+//   * one workgroup per RoI; a thread owns (pooled row ph, 16 bytes of channels: 8 bf16 or 4 f32), so a
+//     wave instruction moves 1 KiB instead of 256 B and the rows of a RoI run side by side;
+//   * the <= 2*SR row taps of each ph and the 2 column taps of every column sample are computed once
+//     per RoI by the first lanes and parked in LDS (the loop reads them back as broadcasts);
+//   * a thread walks its row's column samples left to right keeping the two most recent COLUMN VALUES
+//     colval(x) = sum_y wy f[y][x] in registers: consecutive samples are < 1 px apart for every RoI the
+//     level map sends to a level (7..14 px wide there), so each feature pixel under the RoI row is
+//     loaded once per ph instead of once per tap (28 column taps -> roi_w + 2 column loads);
+//   * blockIdx -> RoI is XCD-aware: blocks b and b + 8 share an XCD (round-robin dispatch), so XCD k
+//     is given the contiguous RoI range [k*R/8, (k+1)*R/8) = the RoIs of two images, whose feature maps
+//     then stay in that XCD's L2 (speed only; nothing depends on the placement).
+// Backward fast path, roi_align_bwd_cl_kernel: workgroup = (RoI, ph), lane = channel (so every atomic
+// wave instruction covers 256 contiguous bytes, the shape the memory-side atomic units run at full
+// rate for), same separable walk transposed: the column gradients are accumulated in registers while the
+// samples move right and each finished column is flushed with one float atomic per distinct row tap:
+// rows x (roi_w + 2) atomics per (RoI, ph) instead of 16 per bin.
+// Everything else (NCHW features, adaptive sampling_ratio <= 0, sampling_ratio > 2, odd strides) runs
+// roi_align_kernel: one workgroup per (RoI, ph), lanes = channels, explicit strides.
+// The level of a RoI is found with exact area thresholds (no log2 rounding), identical to the oracle.
+// Backward uses float atomics (summation order not fixed).
 #include "hd_common.h"
+#include "hd_vec.h"
 
 namespace {
 
@@ -92,12 +108,20 @@ __global__ __launch_bounds__(256) void roi_level_map_kernel(const float* __restr
   if (r < R) out[r] = roi_level_of(rois + (size_t)r * 5, k_min, n_levels, s0, k0);
 }
 
-// grid (R, P)
-template <bool BWD>
-__global__ __launch_bounds__(256) void roi_align_kernel(const hd_roi_levels lv, const float* __restrict__ rois, int C,
-                                                        int P, int sampling_ratio, int aligned, float* out,
-                                                        long long out_sr, long long out_sc, long long out_sh,
-                                                        long long out_sw) {
+// ---- element access of the generic (any-stride) kernels ------------------------------------------
+__device__ __forceinline__ float ld_elem(const float* p) { return *p; }
+__device__ __forceinline__ float ld_elem(const __hip_bfloat16* p) {
+  return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(p)) << 16);
+}
+__device__ __forceinline__ void st_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_elem(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+// Generic forward: grid (R, P), lanes = channels, explicit strides, any sampling ratio.
+template <typename TF, typename TO>
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const hd_roi_levels lv, const float* __restrict__ rois, int C,
+                                                            int P, int sampling_ratio, int aligned, TO* __restrict__ out,
+                                                            long long out_sr, long long out_sc, long long out_sh,
+                                                            long long out_sw) {
   const int r = blockIdx.x, ph = blockIdx.y;
   const float* roi = rois + (size_t)r * 5;
   const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
@@ -105,34 +129,325 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const hd_roi_levels lv, 
   const int H = lv.h[l], W = lv.w[l];
   const RoiGeom g = roi_geometry(roi, lv.spatial_scale[l], P, sampling_ratio, aligned);
   const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
-  float* fbase = const_cast<float*>(lv.feat[l]) + (long long)bi * lv.sb[l];
+  const TF* fbase = reinterpret_cast<const TF*>(lv.feat[l]) + (long long)bi * lv.sb[l];
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float* f = fbase + (long long)c * sc;
+    const TF* f = fbase + (long long)c * sc;
     for (int pw = 0; pw < P; ++pw) {
-      float* o = out + r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
       float acc = 0.0f;
-      float go = 0.0f;
-      if (BWD) go = *o / g.count;
       for (int iy = 0; iy < g.gh; ++iy) {
         const float y = g.start_h + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.gh;
         for (int ix = 0; ix < g.gw; ++ix) {
           const float x = g.start_w + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.gw;
           const Taps t = bilinear_taps(H, W, y, x);
           if (!t.ok) continue;
-          if (!BWD) {
-            const float v1 = f[t.yl * sh + t.xl * sw], v2 = f[t.yl * sh + t.xh * sw];
-            const float v3 = f[t.yh * sh + t.xl * sw], v4 = f[t.yh * sh + t.xh * sw];
-            acc += t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
-          } else {
-            atomicAdd(f + t.yl * sh + t.xl * sw, go * t.w1);
-            atomicAdd(f + t.yl * sh + t.xh * sw, go * t.w2);
-            atomicAdd(f + t.yh * sh + t.xl * sw, go * t.w3);
-            atomicAdd(f + t.yh * sh + t.xh * sw, go * t.w4);
-          }
+          const float v1 = ld_elem(f + t.yl * sh + t.xl * sw), v2 = ld_elem(f + t.yl * sh + t.xh * sw);
+          const float v3 = ld_elem(f + t.yh * sh + t.xl * sw), v4 = ld_elem(f + t.yh * sh + t.xh * sw);
+          acc += t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
         }
       }
-      if (!BWD) *o = acc / g.count;
+      st_elem(out + r * out_sr + c * out_sc + ph * out_sh + pw * out_sw, acc / g.count);
     }
+  }
+}
+
+// Generic backward: float atomics into f32 gradient maps, grad_out f32 or bf16.
+template <typename TG>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const hd_roi_levels lv, const float* __restrict__ rois, int C,
+                                                            int P, int sampling_ratio, int aligned,
+                                                            const TG* __restrict__ grad_out, long long out_sr,
+                                                            long long out_sc, long long out_sh, long long out_sw) {
+  const int r = blockIdx.x, ph = blockIdx.y;
+  const float* roi = rois + (size_t)r * 5;
+  const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
+  const int bi = (int)roi[0];
+  const int H = lv.h[l], W = lv.w[l];
+  const RoiGeom g = roi_geometry(roi, lv.spatial_scale[l], P, sampling_ratio, aligned);
+  const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
+  float* fbase = reinterpret_cast<float*>(const_cast<void*>(lv.feat[l])) + (long long)bi * lv.sb[l];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float* f = fbase + (long long)c * sc;
+    for (int pw = 0; pw < P; ++pw) {
+      const float go = ld_elem(grad_out + r * out_sr + c * out_sc + ph * out_sh + pw * out_sw) / g.count;
+      for (int iy = 0; iy < g.gh; ++iy) {
+        const float y = g.start_h + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.gh;
+        for (int ix = 0; ix < g.gw; ++ix) {
+          const float x = g.start_w + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.gw;
+          const Taps t = bilinear_taps(H, W, y, x);
+          if (!t.ok) continue;
+          atomicAdd(f + t.yl * sh + t.xl * sw, go * t.w1);
+          atomicAdd(f + t.yl * sh + t.xh * sw, go * t.w2);
+          atomicAdd(f + t.yh * sh + t.xl * sw, go * t.w3);
+          atomicAdd(f + t.yh * sh + t.xh * sw, go * t.w4);
+        }
+      }
+    }
+  }
+}
+
+// ---- separable fast path (channels-last, sampling_ratio 1 or 2) -----------------------------------
+constexpr int kMaxP = 16;  // pooled size the LDS tap tables are sized for
+
+// One axis of bilinear_taps(): the two cells and their weights; a sample outside [-1, size] is flagged
+// (the oracle skips it, which is not the same as weight 0 when a feature is non-finite).
+struct Tap1 {
+  int lo, hi;
+  float wlo, whi;
+  bool ok;
+};
+__device__ __forceinline__ Tap1 tap1(int size, float v) {
+  Tap1 t;
+  t.ok = !(v < -1.0f || v > (float)size);
+  if (v <= 0.0f) v = 0.0f;
+  int lo = (int)v, hi;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    v = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  const float l = v - (float)lo;
+  t.lo = lo; t.hi = hi;
+  t.wlo = 1.0f - l; t.whi = l;
+  return t;
+}
+
+template <int V>
+__device__ __forceinline__ void store_vec(float* p, const float* v) {
+#pragma unroll
+  for (int i = 0; i < V; i += 4) *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+}
+template <int V>
+__device__ __forceinline__ void store_vec(__hip_bfloat16* p, const float* v) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  uint32_t w[V / 2];
+#pragma unroll
+  for (int i = 0; i < V / 2; ++i) {
+    const f32x2 f = {v[2 * i], v[2 * i + 1]};
+    const bf16x2 r = __builtin_convertvector(f, bf16x2);
+    w[i] = *reinterpret_cast<const uint32_t*>(&r);
+  }
+  if (V == 8) *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2 % (V / 2)], w[3 % (V / 2)]);
+  else *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+}
+
+// XCD-aware block -> RoI: grid = 8 * ceil(R/8); blocks with equal blockIdx % 8 share an XCD and get a
+// contiguous range of RoIs (RoIs are ordered by image, so an XCD's L2 serves one or two images' maps).
+__device__ __forceinline__ int roi_of_block(int R) {
+  const int per = (int)(gridDim.x >> 3);
+  return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+
+// Row taps of pooled row ph into (element offset y*sh | -1 = skip, weight / count); duplicates merged.
+template <int SR>
+__device__ __forceinline__ void row_taps(const RoiGeom& g, int H, int sh, int ph, int* yo, float* yw) {
+  const float inv_count = 1.0f / g.count;  // count = SR*SR in {1, 4}: the scaling is exact
+#pragma unroll
+  for (int iy = 0; iy < SR; ++iy) {
+    const float y = g.start_h + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)SR;
+    const Tap1 t = tap1(H, y);
+    yo[2 * iy] = t.ok ? t.lo * sh : -1;
+    yo[2 * iy + 1] = t.ok ? t.hi * sh : -1;
+    yw[2 * iy] = t.wlo * inv_count;
+    yw[2 * iy + 1] = t.whi * inv_count;
+  }
+  // taps are nondecreasing in y: fold a tap onto an equal earlier one (its own slot is then skipped)
+#pragma unroll
+  for (int k = 1; k < 2 * SR; ++k) {
+#pragma unroll
+    for (int m = 0; m < k; ++m) {
+      if (yo[k] >= 0 && yo[k] == yo[m]) {
+        yw[m] += yw[k];
+        yo[k] = -1;
+      }
+    }
+  }
+}
+
+template <typename TF, typename TO, int SR>
+__global__ __launch_bounds__(512) void roi_align_fwd_cl_kernel(const hd_roi_levels lv, const float* __restrict__ rois,
+                                                               int R, int C, int P, int aligned, TO* __restrict__ out,
+                                                               long long out_sr, long long out_sh, long long out_sw) {
+  constexpr int V = RowVec<TF>::N;
+  __shared__ int s_yo[kMaxP][2 * SR];
+  __shared__ float s_yw[kMaxP][2 * SR];
+  __shared__ int s_xl[kMaxP * SR], s_xh[kMaxP * SR];
+  __shared__ float s_xwl[kMaxP * SR], s_xwh[kMaxP * SR];
+  const int r = roi_of_block(R);
+  if (r >= R) return;  // whole workgroup
+  const float* roi = rois + (size_t)r * 5;
+  const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
+  const int bi = (int)roi[0];
+  const int H = lv.h[l], W = lv.w[l];
+  const RoiGeom g = roi_geometry(roi, lv.spatial_scale[l], P, SR, aligned);
+  const int sh = (int)lv.sh[l], sw = (int)lv.sw[l];
+  for (int i = threadIdx.x; i < 2 * P * SR; i += blockDim.x) {
+    if (i < P * SR) {  // column sample i = pw*SR + ix
+      const int pw = i / SR, ix = i - pw * SR;
+      const float x = g.start_w + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)SR;
+      const Tap1 t = tap1(W, x);
+      s_xl[i] = t.ok ? t.lo * sw : -1;
+      s_xh[i] = t.ok ? t.hi * sw : -1;
+      s_xwl[i] = t.wlo;
+      s_xwh[i] = t.whi;
+    } else if ((i - P * SR) % SR == 0) {  // one thread per pooled row builds that row's (merged) taps
+      const int ph = (i - P * SR) / SR;
+      int yo[2 * SR];
+      float yw[2 * SR];
+      row_taps<SR>(g, H, sh, ph, yo, yw);
+#pragma unroll
+      for (int k = 0; k < 2 * SR; ++k) {
+        s_yo[ph][k] = yo[k];
+        s_yw[ph][k] = yw[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int cg = C / V;
+  const TF* fimg = reinterpret_cast<const TF*>(lv.feat[l]) + (long long)bi * lv.sb[l];
+  for (int item = threadIdx.x; item < P * cg; item += blockDim.x) {
+    const int ph = item / cg, gq = item - ph * cg;
+    const TF* f = fimg + gq * V;
+    int yo[2 * SR];
+    float yw[2 * SR];
+#pragma unroll
+    for (int k = 0; k < 2 * SR; ++k) {
+      yo[k] = s_yo[ph][k];
+      yw[k] = s_yw[ph][k];
+    }
+    // column value colval(x)[c] = sum_k yw[k] * f[y_k][x][c]: 2*SR independent 16-byte loads
+    auto load_col = [&](int xoff, float* cv) {
+      uint4 raw[2 * SR];
+#pragma unroll
+      for (int k = 0; k < 2 * SR; ++k)
+        if (yo[k] >= 0) raw[k] = *reinterpret_cast<const uint4*>(f + yo[k] + xoff);
+#pragma unroll
+      for (int j = 0; j < V; ++j) cv[j] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * SR; ++k)
+        if (yo[k] >= 0) {
+          float v[V];
+          RowVec<TF>::unpack(raw[k], v);
+#pragma unroll
+          for (int j = 0; j < V; ++j) cv[j] = fmaf(yw[k], v[j], cv[j]);
+        }
+    };
+    float c0v[V], c1v[V];  // the two most recent column values, at element offsets c0 <= c1
+    int c0 = -1, c1 = -1;
+    TO* o = out + (long long)r * out_sr + (long long)ph * out_sh + gq * V;
+    for (int pw = 0; pw < P; ++pw) {
+      float acc[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = 0.0f;
+#pragma unroll
+      for (int ix = 0; ix < SR; ++ix) {
+        const int s = pw * SR + ix;
+        const int xl = s_xl[s], xh = s_xh[s];  // workgroup-uniform: the branches below do not diverge
+        if (xl < 0) continue;
+        const float wl = s_xwl[s], wh = s_xwh[s];
+        if (xl == c1) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) c0v[j] = c1v[j];
+          c0 = c1;
+        } else if (xl != c0) {
+          load_col(xl, c0v);
+          c0 = xl;
+        }
+        if (xh == c0) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) c1v[j] = c0v[j];
+          c1 = c0;
+        } else if (xh != c1) {
+          load_col(xh, c1v);
+          c1 = xh;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(wl, c0v[j], fmaf(wh, c1v[j], acc[j]));
+      }
+      store_vec<V>(o + (long long)pw * out_sw, acc);
+    }
+  }
+}
+
+// grid = R*P workgroups (RoI, ph); thread = channel; f32 gradient maps (channels-last), grad_out f32 | bf16
+template <typename TG, int SR>
+__global__ __launch_bounds__(256) void roi_align_bwd_cl_kernel(const hd_roi_levels lv, const float* __restrict__ rois,
+                                                               int C, int P, int aligned,
+                                                               const TG* __restrict__ grad_out, long long out_sr,
+                                                               long long out_sh, long long out_sw) {
+  __shared__ int s_xl[kMaxP * SR], s_xh[kMaxP * SR];
+  __shared__ float s_xwl[kMaxP * SR], s_xwh[kMaxP * SR];
+  const int r = (int)(blockIdx.x / (unsigned)P), ph = (int)(blockIdx.x % (unsigned)P);
+  const float* roi = rois + (size_t)r * 5;
+  const int l = roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level);
+  const int bi = (int)roi[0];
+  const int H = lv.h[l], W = lv.w[l];
+  const RoiGeom g = roi_geometry(roi, lv.spatial_scale[l], P, SR, aligned);
+  const int sh = (int)lv.sh[l], sw = (int)lv.sw[l];
+  for (int i = threadIdx.x; i < P * SR; i += blockDim.x) {
+    const int pw = i / SR, ix = i - pw * SR;
+    const float x = g.start_w + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)SR;
+    const Tap1 t = tap1(W, x);
+    s_xl[i] = t.ok ? t.lo * sw : -1;
+    s_xh[i] = t.ok ? t.hi * sw : -1;
+    s_xwl[i] = t.wlo;
+    s_xwh[i] = t.whi;
+  }
+  int yo[2 * SR];
+  float yw[2 * SR];
+  row_taps<SR>(g, H, sh, ph, yo, yw);  // workgroup-uniform (every thread computes the same 2*SR taps)
+  __syncthreads();
+  float* fimg = reinterpret_cast<float*>(const_cast<void*>(lv.feat[l])) + (long long)bi * lv.sb[l];
+  const TG* gbase = grad_out + (long long)r * out_sr + (long long)ph * out_sh;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float* f = fimg + c;
+    auto flush = [&](int xoff, float v) {
+      if (xoff < 0) return;
+#pragma unroll
+      for (int k = 0; k < 2 * SR; ++k)
+        if (yo[k] >= 0) atomicAdd(f + yo[k] + xoff, yw[k] * v);
+    };
+    // pending column gradients: column a (value va) and its right neighbour b (value vb)
+    int a = -1, b = -1;
+    float va = 0.0f, vb = 0.0f;
+    float gnext = ld_elem(gbase + c);
+    for (int pw = 0; pw < P; ++pw) {
+      const float gv = gnext;
+      if (pw + 1 < P) gnext = ld_elem(gbase + (long long)(pw + 1) * out_sw + c);
+#pragma unroll
+      for (int ix = 0; ix < SR; ++ix) {
+        const int s = pw * SR + ix;
+        const int xl = s_xl[s], xh = s_xh[s];  // workgroup-uniform, nondecreasing in s
+        if (xl < 0) continue;
+        const float wl = s_xwl[s], wh = s_xwh[s];
+        if (xl != a) {
+          flush(a, va);
+          if (xl == b) {
+            a = b;
+            va = vb;
+          } else {
+            flush(b, vb);
+            a = xl;
+            va = 0.0f;
+          }
+          b = -1;
+          vb = 0.0f;
+        }
+        va = fmaf(wl, gv, va);
+        if (xh == a) {
+          va = fmaf(wh, gv, va);
+        } else {
+          if (xh != b) {
+            flush(b, vb);
+            b = xh;
+            vb = 0.0f;
+          }
+          vb = fmaf(wh, gv, vb);
+        }
+      }
+    }
+    flush(a, va);
+    flush(b, vb);
   }
 }
 
@@ -168,7 +483,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const hd_roi_levels l
   const int H = lv.h[l], W = lv.w[l];
   const PoolGeom g = pool_geometry(roi, lv.spatial_scale[l], P);
   const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
-  const float* fbase = lv.feat[l] + (long long)bi * lv.sb[l];
+  const float* fbase = reinterpret_cast<const float*>(lv.feat[l]) + (long long)bi * lv.sb[l];
   const int hs = clampi((int)floorf((float)ph * g.bin_h) + g.start_h, 0, H);
   const int he = clampi((int)ceilf((float)(ph + 1) * g.bin_h) + g.start_h, 0, H);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -205,7 +520,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const hd_roi_levels l
   const int bi = (int)roi[0];
   const int W = lv.w[l];
   const long long sc = lv.sc[l], sh = lv.sh[l], sw = lv.sw[l];
-  float* fbase = const_cast<float*>(lv.feat[l]) + (long long)bi * lv.sb[l];
+  float* fbase = reinterpret_cast<float*>(const_cast<void*>(lv.feat[l])) + (long long)bi * lv.sb[l];
   for (int c = threadIdx.x; c < C; c += blockDim.x)
     for (int pw = 0; pw < P; ++pw) {
       const long long o = r * out_sr + c * out_sc + ph * out_sh + pw * out_sw;
@@ -214,9 +529,10 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const hd_roi_levels l
     }
 }
 
-inline hd_status check_roi_args(const hd_roi_levels* lv, const float* rois, int R, int C, int P, const float* out) {
+inline hd_status check_roi_args(const hd_roi_levels* lv, const float* rois, int R, int C, int P, const void* out) {
   if (!lv) return HD_ERR_NULL;
   if (R < 0 || C <= 0 || P <= 0 || P > 65535 || lv->n_levels <= 0 || lv->n_levels > HD_MAX_LEVELS) return HD_ERR_SHAPE;
+  if (lv->dtype != 0 && lv->dtype != 1) return HD_ERR_SHAPE;
   if (R == 0) return HD_OK;
   if (!rois || !out) return HD_ERR_NULL;
   for (int l = 0; l < lv->n_levels; ++l) {
@@ -224,6 +540,27 @@ inline hd_status check_roi_args(const hd_roi_levels* lv, const float* rois, int 
     if (lv->h[l] <= 0 || lv->w[l] <= 0) return HD_ERR_SHAPE;
   }
   return HD_OK;
+}
+
+// The separable fast path needs channels-last maps whose 16-byte vectors are aligned, 32-bit in-image offsets,
+// and a channels-last output/gradient tensor (out_sc == 1) aligned for its vector stores.
+inline bool roi_fast_ok(const hd_roi_levels* lv, int C, int P, int sampling_ratio, int feat_elem, int vec,
+                        const void* out, int out_elem, int out_vec, long long out_sr, long long out_sc, long long out_sh,
+                        long long out_sw) {
+  if (sampling_ratio != 1 && sampling_ratio != 2) return false;
+  if (P > kMaxP || C % vec != 0 || out_sc != 1) return false;
+  const long long fa = 16 / feat_elem;  // elements per 16 bytes
+  for (int l = 0; l < lv->n_levels; ++l) {
+    if (lv->sc[l] != 1 || !hd_aligned16(lv->feat[l])) return false;
+    if (lv->sb[l] % fa || lv->sh[l] % fa || lv->sw[l] % fa) return false;
+    if (lv->sh[l] <= 0 || lv->sw[l] <= 0 || (long long)lv->h[l] * lv->sh[l] >= (1ll << 31) ||
+        (long long)lv->w[l] * lv->sw[l] >= (1ll << 31))
+      return false;
+  }
+  const long long oa = out_vec;  // output vectors of out_vec elements must stay aligned
+  if ((reinterpret_cast<uintptr_t>(out) % (size_t)(out_vec * out_elem > 16 ? 16 : out_vec * out_elem)) != 0) return false;
+  if (out_sr % oa || out_sh % oa || out_sw % oa) return false;
+  return true;
 }
 
 }  // namespace
@@ -240,27 +577,88 @@ extern "C" hd_status hd_roi_level_map(const float* rois, int R, int k_min, int n
 }
 
 extern "C" hd_status hd_roi_align_fwd(const hd_roi_levels* levels, const float* rois, int R, int C, int P,
-                                      int sampling_ratio, int aligned, float* out, int64_t out_sr, int64_t out_sc,
-                                      int64_t out_sh, int64_t out_sw, hd_stream stream) {
+                                      int sampling_ratio, int aligned, void* out, int out_dtype, int64_t out_sr,
+                                      int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream) {
   hd_status st = check_roi_args(levels, rois, R, C, P, out);
   if (st != HD_OK || R == 0) return st;
-  const int threads = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : 64));
-  hipLaunchKernelGGL((roi_align_kernel<false>), dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *levels, rois, C,
-                     P, sampling_ratio, aligned, out, (long long)out_sr, (long long)out_sc, (long long)out_sh,
-                     (long long)out_sw);
+  if (out_dtype != 0 && out_dtype != 1) return HD_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const bool fbf = levels->dtype == 1, obf = out_dtype == 1;
+  const int vec = fbf ? 8 : 4;
+  if (roi_fast_ok(levels, C, P, sampling_ratio, fbf ? 2 : 4, vec, out, obf ? 2 : 4, vec, out_sr, out_sc, out_sh, out_sw)) {
+    int threads = (P * (C / vec) + 63) / 64 * 64;
+    threads = threads < 64 ? 64 : (threads > 512 ? 512 : threads);
+    const unsigned grid = (unsigned)((R + 7) / 8) * 8u;
+#define HD_ROI_FWD(TF, TO, SR)                                                                                       \
+  hipLaunchKernelGGL((roi_align_fwd_cl_kernel<TF, TO, SR>), dim3(grid), dim3(threads), 0, s, *levels, rois, R, C, P, \
+                     aligned, reinterpret_cast<TO*>(out), (long long)out_sr, (long long)out_sh, (long long)out_sw)
+#define HD_ROI_FWD_SR(TF, TO)              \
+  do {                                     \
+    if (sampling_ratio == 1) HD_ROI_FWD(TF, TO, 1); \
+    else HD_ROI_FWD(TF, TO, 2);            \
+  } while (0)
+    if (fbf && obf) HD_ROI_FWD_SR(__hip_bfloat16, __hip_bfloat16);
+    else if (fbf) HD_ROI_FWD_SR(__hip_bfloat16, float);
+    else if (obf) HD_ROI_FWD_SR(float, __hip_bfloat16);
+    else HD_ROI_FWD_SR(float, float);
+#undef HD_ROI_FWD_SR
+#undef HD_ROI_FWD
+    HD_RETURN_IF_LAUNCH_FAILED();
+    return HD_OK;
+  }
+  const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
+#define HD_ROI_GEN(TF, TO)                                                                                          \
+  hipLaunchKernelGGL((roi_align_fwd_kernel<TF, TO>), dim3(R, P), dim3(threads), 0, s, *levels, rois, C, P,          \
+                     sampling_ratio, aligned, reinterpret_cast<TO*>(out), (long long)out_sr, (long long)out_sc,     \
+                     (long long)out_sh, (long long)out_sw)
+  if (fbf && obf) HD_ROI_GEN(__hip_bfloat16, __hip_bfloat16);
+  else if (fbf) HD_ROI_GEN(__hip_bfloat16, float);
+  else if (obf) HD_ROI_GEN(float, __hip_bfloat16);
+  else HD_ROI_GEN(float, float);
+#undef HD_ROI_GEN
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
 extern "C" hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, int R, int C, int P,
-                                      int sampling_ratio, int aligned, const float* grad_out, int64_t out_sr,
-                                      int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream) {
+                                      int sampling_ratio, int aligned, const void* grad_out, int grad_dtype,
+                                      int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw,
+                                      hd_stream stream) {
   hd_status st = check_roi_args(grad_levels, rois, R, C, P, grad_out);
   if (st != HD_OK || R == 0) return st;
-  const int threads = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : 64));
-  hipLaunchKernelGGL((roi_align_kernel<true>), dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *grad_levels, rois,
-                     C, P, sampling_ratio, aligned, const_cast<float*>(grad_out), (long long)out_sr,
-                     (long long)out_sc, (long long)out_sh, (long long)out_sw);
+  if (grad_levels->dtype != 0) return HD_ERR_SHAPE;  // the accumulators are float32
+  if (grad_dtype != 0 && grad_dtype != 1) return HD_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const bool gbf = grad_dtype == 1;
+  // lane = channel: only the maps' channel stride and 32-bit offsets matter (vec = 1, any alignment)
+  if (roi_fast_ok(grad_levels, C, P, sampling_ratio, 16, 1, grad_out, 1, 1, out_sr, out_sc, out_sh, out_sw) &&
+      (long long)R * P < (1ll << 31)) {
+    const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
+    const unsigned grid = (unsigned)((long long)R * P);
+#define HD_ROI_BWD(TG, SR)                                                                                     \
+  hipLaunchKernelGGL((roi_align_bwd_cl_kernel<TG, SR>), dim3(grid), dim3(threads), 0, s, *grad_levels, rois, C, P, \
+                     aligned, reinterpret_cast<const TG*>(grad_out), (long long)out_sr, (long long)out_sh,     \
+                     (long long)out_sw)
+    if (gbf) {
+      if (sampling_ratio == 1) HD_ROI_BWD(__hip_bfloat16, 1);
+      else HD_ROI_BWD(__hip_bfloat16, 2);
+    } else {
+      if (sampling_ratio == 1) HD_ROI_BWD(float, 1);
+      else HD_ROI_BWD(float, 2);
+    }
+#undef HD_ROI_BWD
+    HD_RETURN_IF_LAUNCH_FAILED();
+    return HD_OK;
+  }
+  const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
+  if (gbf)
+    hipLaunchKernelGGL((roi_align_bwd_kernel<__hip_bfloat16>), dim3(R, P), dim3(threads), 0, s, *grad_levels, rois, C, P,
+                       sampling_ratio, aligned, reinterpret_cast<const __hip_bfloat16*>(grad_out), (long long)out_sr,
+                       (long long)out_sc, (long long)out_sh, (long long)out_sw);
+  else
+    hipLaunchKernelGGL((roi_align_bwd_kernel<float>), dim3(R, P), dim3(threads), 0, s, *grad_levels, rois, C, P,
+                       sampling_ratio, aligned, reinterpret_cast<const float*>(grad_out), (long long)out_sr,
+                       (long long)out_sc, (long long)out_sh, (long long)out_sw);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -270,6 +668,7 @@ extern "C" hd_status hd_roi_pool_fwd(const hd_roi_levels* levels, const float* r
                                      int64_t out_sw, hd_stream stream) {
   hd_status st = check_roi_args(levels, rois, R, C, P, out);
   if (st != HD_OK || R == 0) return st;
+  if (levels->dtype != 0) return HD_ERR_SHAPE;  // the pooling variant is float32-only
   if (!argmax) return HD_ERR_NULL;
   const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
   hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *levels, rois, C, P, out,
@@ -283,6 +682,7 @@ extern "C" hd_status hd_roi_pool_bwd(const hd_roi_levels* grad_levels, const flo
                                      int64_t out_sh, int64_t out_sw, hd_stream stream) {
   hd_status st = check_roi_args(grad_levels, rois, R, C, P, grad_out);
   if (st != HD_OK || R == 0) return st;
+  if (grad_levels->dtype != 0) return HD_ERR_SHAPE;
   if (!argmax) return HD_ERR_NULL;
   const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
   hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(R, P), dim3(threads), 0, (hipStream_t)stream, *grad_levels, rois, C, P,

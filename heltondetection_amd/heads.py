@@ -227,11 +227,15 @@ class RoIHead(nn.Module):
 
     # ---- RoI features ------------------------------------------------------------------------
     def extract(self, feats: List[torch.Tensor], rois5: torch.Tensor) -> torch.Tensor:
-        f32 = [f.float() for f in feats[: len(self.scales)]]
-        if self.roi_op == "pool":
-            return ops.roi_pool(f32, rois5, self.P, self.scales[: len(f32)], self.k_min, 224.0, 4,
+        fs = list(feats[: len(self.scales)])
+        if self.roi_op == "pool":  # the quantised max-pool variant is float32-only
+            return ops.roi_pool([f.float() for f in fs], rois5, self.P, self.scales[: len(fs)], self.k_min, 224.0, 4,
                                 channels_last_out=self.decoupled)
-        return ops.roi_align(f32, rois5, self.P, self.scales[: len(f32)], self.sr, True, self.k_min, 224.0, 4,
+        # the pyramid is consumed in its own dtype (bf16 under autocast: no float32 copy of P2..P5, bf16 RoI features
+        # for the bf16 towers); accumulation inside the kernel is float32
+        if fs[0].dtype not in (torch.float32, torch.bfloat16):
+            fs = [f.float() for f in fs]
+        return ops.roi_align(fs, rois5, self.P, self.scales[: len(fs)], self.sr, True, self.k_min, 224.0, 4,
                              channels_last_out=self.decoupled)
 
     def forward(self, feats, rois5):

@@ -221,12 +221,15 @@ def rpn_proposals(logits: torch.Tensor, deltas: torch.Tensor, anchors: torch.Ten
 
 # ------------------------------------------------------------------------------- RoIAlign
 def _roi_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], k_min: int, canonical_scale: float,
-                canonical_level: int) -> RoiLevels:
+                canonical_level: int, allow_bf16: bool = False) -> RoiLevels:
     st = RoiLevels()
     st.n_levels = len(feats)
+    dt = feats[0].dtype
+    ok = (_F32, torch.bfloat16) if allow_bf16 else (_F32,)
     for l, f in enumerate(feats):
-        if not f.is_cuda or f.dtype != _F32 or f.dim() != 4:
-            raise _lib.HdError("roi_align: features must be float32 [B,C,H,W] tensors on a HIP device")
+        if not f.is_cuda or f.dtype not in ok or f.dtype != dt or f.dim() != 4:
+            raise _lib.HdError("roi levels: features must be [B,C,H,W] tensors of one dtype (float32%s) on a HIP device"
+                               % (" or bfloat16" if allow_bf16 else ""))
         st.feat[l] = f.data_ptr()
         st.h[l], st.w[l] = f.shape[2], f.shape[3]
         st.spatial_scale[l] = float(scales[l])
@@ -234,6 +237,7 @@ def _roi_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], k_min: i
     st.k_min = int(k_min)
     st.canonical_scale = float(canonical_scale)
     st.canonical_level = int(canonical_level)
+    st.dtype = 0 if dt == _F32 else 1
     return st
 
 
@@ -250,20 +254,21 @@ def roi_level_map(rois: torch.Tensor, k_min: int, n_levels: int, canonical_scale
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, P, scales, sampling_ratio, aligned, k_min, canonical_scale, canonical_level,
-                channels_last_out, *feats):
+                channels_last_out, out_dtype, *feats):
         lib = _lib.load()
         rois = _need(rois.detach(), _F32, "rois")
         feats_d = [f.detach() for f in feats]
-        st = _roi_levels(feats_d, scales, k_min, canonical_scale, canonical_level)
+        st = _roi_levels(feats_d, scales, k_min, canonical_scale, canonical_level, allow_bf16=True)
         R, Cc = rois.shape[0], feats[0].shape[1]
-        out = torch.empty((R, Cc, P, P), dtype=_F32, device=rois.device,
+        out = torch.empty((R, Cc, P, P), dtype=out_dtype, device=rois.device,
                           memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
-        check(lib.hd_roi_align_fwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
-                                   _ptr(out), out.stride(0), out.stride(1), out.stride(2), out.stride(3),
-                                   _stream(rois)), "hd_roi_align_fwd")
+        with _timed("roi_align_fwd"):
+            check(lib.hd_roi_align_fwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
+                                       _ptr(out), 0 if out_dtype == _F32 else 1, out.stride(0), out.stride(1),
+                                       out.stride(2), out.stride(3), _stream(rois)), "hd_roi_align_fwd")
         ctx.save_for_backward(rois)
         ctx.meta = (P, tuple(scales), sampling_ratio, aligned, k_min, canonical_scale, canonical_level,
-                    [(tuple(f.shape), f.is_contiguous(memory_format=torch.channels_last)) for f in feats])
+                    [(tuple(f.shape), f.is_contiguous(memory_format=torch.channels_last), f.dtype) for f in feats])
         return out
 
     @staticmethod
@@ -271,24 +276,34 @@ class _RoIAlignFn(torch.autograd.Function):
         lib = _lib.load()
         (rois,) = ctx.saved_tensors
         P, scales, sampling_ratio, aligned, k_min, cs, cl, shapes = ctx.meta
-        grad_out = _need(grad_out, _F32, "grad_out", contiguous=False)
+        if grad_out.dtype not in (_F32, torch.bfloat16):
+            grad_out = grad_out.float()
+        # float32 accumulators for the atomics whatever the feature dtype (a bf16 running sum would round on
+        # every add); cast once at the end for bf16 features
         grads = [torch.empty(shape, dtype=_F32, device=rois.device,
                              memory_format=torch.channels_last if cl_fmt else torch.contiguous_format).zero_()
-                 for shape, cl_fmt in shapes]
+                 for shape, cl_fmt, _ in shapes]
         st = _roi_levels(grads, scales, k_min, cs, cl)
         R, Cc = rois.shape[0], shapes[0][0][1]
-        check(lib.hd_roi_align_bwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
-                                   _ptr(grad_out), grad_out.stride(0), grad_out.stride(1), grad_out.stride(2),
-                                   grad_out.stride(3), _stream(rois)), "hd_roi_align_bwd")
-        return (None,) * 9 + tuple(grads)
+        with _timed("roi_align_bwd"):
+            check(lib.hd_roi_align_bwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
+                                       _ptr(grad_out), 0 if grad_out.dtype == _F32 else 1, grad_out.stride(0),
+                                       grad_out.stride(1), grad_out.stride(2), grad_out.stride(3), _stream(rois)),
+                  "hd_roi_align_bwd")
+        grads = [g if dt == _F32 else g.to(dt) for g, (_, _, dt) in zip(grads, shapes)]
+        return (None,) * 10 + tuple(grads)
 
 
 def roi_align(feats: Sequence[torch.Tensor], rois: torch.Tensor, P: int, scales: Sequence[float],
               sampling_ratio: int = 2, aligned: bool = True, k_min: int = 2, canonical_scale: float = 224.0,
-              canonical_level: int = 4, channels_last_out: bool = False) -> torch.Tensor:
-    """feats: list of [B,C,H,W] (any strides; channels-last is the fast layout); rois [R,5] -> [R,C,P,P]."""
+              canonical_level: int = 4, channels_last_out: bool = False, out_dtype=None) -> torch.Tensor:
+    """feats: list of [B,C,H,W] float32 or bfloat16 maps (any strides; channels-last with sampling_ratio 1 or 2 is
+    the fast path); rois [R,5] -> [R,C,P,P] in `out_dtype` (default: the features' dtype), accumulated in float32."""
+    out_dtype = feats[0].dtype if out_dtype is None else out_dtype
+    if out_dtype not in (_F32, torch.bfloat16):
+        raise _lib.HdError("roi_align: out_dtype must be float32 or bfloat16")
     return _RoIAlignFn.apply(rois, int(P), tuple(scales), int(sampling_ratio), bool(aligned), int(k_min),
-                             float(canonical_scale), int(canonical_level), bool(channels_last_out), *feats)
+                             float(canonical_scale), int(canonical_level), bool(channels_last_out), out_dtype, *feats)
 
 
 class _RoIPoolFn(torch.autograd.Function):

@@ -149,7 +149,7 @@ hd_status hd_rpn_proposals(const float* logits, const float* deltas, const float
 
 typedef struct hd_roi_levels {
   int n_levels;                       /* 1..HD_MAX_LEVELS                                  */
-  const float* feat[HD_MAX_LEVELS];   /* device base pointer of each level's feature map   */
+  const void* feat[HD_MAX_LEVELS];    /* device base pointer of each level's feature map   */
   int h[HD_MAX_LEVELS], w[HD_MAX_LEVELS];
   float spatial_scale[HD_MAX_LEVELS]; /* 1/stride                                          */
   int64_t sb[HD_MAX_LEVELS], sc[HD_MAX_LEVELS], sh[HD_MAX_LEVELS], sw[HD_MAX_LEVELS];
@@ -157,6 +157,9 @@ typedef struct hd_roi_levels {
   int k_min;                          /* pyramid level number of feat[0] (e.g. 2 for P2)    */
   float canonical_scale;              /* 224                                               */
   int canonical_level;                /* 4                                                 */
+  int dtype;                          /* element type of feat[]: 0 = float32, 1 = bfloat16
+                                         (RoIAlign forward only; gradient maps and RoIPool
+                                         are float32)                                      */
 } hd_roi_levels;
 
 /* Level of a RoI (exact form of floor(k0 + log2(sqrt(area)/s0)), clamped):
@@ -166,20 +169,24 @@ hd_status hd_roi_level_map(const float* rois, int R, int k_min, int n_levels,
                            float canonical_scale, int canonical_level, int32_t* out_level,
                            hd_stream stream);
 
-/* Forward. out[r,c,ph,pw] with element strides (out_sr,out_sc,out_sh,out_sw).
+/* Forward. out[r,c,ph,pw] with element strides (out_sr,out_sc,out_sh,out_sw); out_dtype 0 = float32,
+ * 1 = bfloat16.  Features float32 or bfloat16 (levels->dtype), accumulation always float32.
  * Bilinear sampling as the public RoIAlign definition: bin grid sampling_ratio^2 points
  * (<=0: adaptive ceil(roi_size/P)); aligned!=0 shifts by -0.5 px and allows sub-pixel RoIs,
- * aligned==0 forces roi size >= 1; samples outside [-1, size] contribute 0. */
+ * aligned==0 forces roi size >= 1; samples outside [-1, size] contribute 0.
+ * Fast path: channels-last maps and output (sc == 1, out_sc == 1, 16-byte aligned rows),
+ * sampling_ratio 1 or 2, P <= 16; anything else runs the any-stride kernel. */
 hd_status hd_roi_align_fwd(const hd_roi_levels* levels, const float* rois, int R, int C, int P,
-                           int sampling_ratio, int aligned, float* out, int64_t out_sr,
+                           int sampling_ratio, int aligned, void* out, int out_dtype, int64_t out_sr,
                            int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream);
 
-/* Backward: scatter-adds grad_out into grad_feat (same struct, feat[] = grad buffers, which
- * the caller has zeroed).  Uses float atomics: summation order is not fixed. */
+/* Backward: scatter-adds grad_out (grad_dtype 0 = float32, 1 = bfloat16) into the float32 gradient
+ * maps grad_levels->feat[] (dtype must be 0), which the caller has zeroed.  Uses float atomics:
+ * summation order is not fixed. */
 hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, int R, int C,
-                           int P, int sampling_ratio, int aligned, const float* grad_out,
-                           int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw,
-                           hd_stream stream);
+                           int P, int sampling_ratio, int aligned, const void* grad_out,
+                           int grad_dtype, int64_t out_sr, int64_t out_sc, int64_t out_sh,
+                           int64_t out_sw, hd_stream stream);
 
 /* ---- RoI max-pooling over pyramid levels (README.md:73 "FasterRCNN-FPNP2-RoIPooling") ---- */
 

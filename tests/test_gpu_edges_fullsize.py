@@ -278,3 +278,129 @@ def test_newest_ops_shape_sweep(gpu, ops, seed):
     d1, c1 = ops.yolo_detect(views, H.YOLO_STRIDES, H.YOLO_ANCHORS, conf, 0.5, 4000, 64)
     d2, c2 = ops.yolo_nms(ops.yolo_decode(views, H.YOLO_STRIDES, H.YOLO_ANCHORS), conf, 0.5, 4000, 64)
     assert torch.equal(c1, c2) and torch.equal(d1, d2)
+
+
+# ------------------------------------------------------------------------------- BASELINE config 3 at full size
+def _cfg3_pyramid(gpu, dtype, fill=None):
+    """P2..P5 of an 832x832 bs16 batch, 256 channels, channels-last (FasterRCNN-R50-PAFPN, config 3)."""
+    g = torch.Generator(device=gpu).manual_seed(301)
+    feats = []
+    for s in (4, 8, 16, 32):
+        shape = (16, 256, 832 // s, 832 // s)
+        f = torch.randn(shape, device=gpu, generator=g) if fill is None else fill(shape, s)
+        feats.append(f.to(dtype).contiguous(memory_format=torch.channels_last))
+    return feats
+
+
+def _cfg3_rois(gpu, R_per_img=512, inside=False):
+    bx = H.boxes_batch(1, 16 * R_per_img, 832, 302, 16.0, 400.0)[0]
+    if inside:  # keep every sample strictly inside the maps: 40 px margin (> one stride-32 cell)
+        bx = bx.clamp(40.0, 792.0)
+        bx[:, 2:] = torch.maximum(bx[:, 2:], bx[:, :2] + 8.0)
+    bi = torch.arange(16).repeat_interleave(R_per_img)[:, None].float()
+    return torch.cat([bi, bx], 1).to(gpu)
+
+
+SCALES3 = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fullsize_roi_align_constant_and_ramp_identities(gpu, ops, dtype):
+    """R = 8192, C = 256, P = 7, sampling 2, 832^2 bs16 channels-last.  Bilinear sampling reproduces constants and
+    affine functions exactly (up to rounding) wherever no sample is clamped, so for RoIs inside the map:
+    constant map c -> every bin == c;  f(y, x) = a*y + b*x + c0 on a level -> bin == f at the bin centre."""
+    rois = _cfg3_rois(gpu, inside=True)
+    const = _cfg3_pyramid(gpu, dtype, fill=lambda shape, s: torch.full(shape, 1.5, device=gpu))
+    out = ops.roi_align(const, rois, 7, SCALES3, 2, True, 2, 224.0, 4, channels_last_out=True, out_dtype=torch.float32)
+    assert out.shape == (8192, 256, 7, 7)
+    assert float((out - 1.5).abs().max()) < 1e-5
+    del const, out
+
+    def ramp(shape, s):
+        B, C, Hh, Ww = shape
+        # a/16 and b/16 steps, exactly representable in bf16 over the map sizes used here (<= 208 cells: 13/16 steps)
+        y = torch.arange(Hh, device=gpu, dtype=torch.float32)[:, None] * 0.125
+        x = torch.arange(Ww, device=gpu, dtype=torch.float32)[None, :] * 0.0625
+        return (y + x)[None, None].expand(B, C, Hh, Ww)
+
+    feats = _cfg3_pyramid(gpu, dtype, fill=ramp)
+    out = ops.roi_align(feats, rois, 7, SCALES3, 2, True, 2, 224.0, 4, channels_last_out=True, out_dtype=torch.float32)
+    lvl = ops.roi_level_map(rois, 2, 4, 224.0, 4).long()
+    sc = torch.tensor(SCALES3, device=gpu)[lvl]
+    x1, y1, x2, y2 = [rois[:, i] * sc - 0.5 for i in (1, 2, 3, 4)]
+    k = (torch.arange(7, device=gpu, dtype=torch.float32) + 0.5) / 7.0
+    yc = y1[:, None] + (y2 - y1)[:, None] * k[None, :]        # bin centres in cell units
+    xc = x1[:, None] + (x2 - x1)[:, None] * k[None, :]
+    expect = yc[:, :, None] * 0.125 + xc[:, None, :] * 0.0625   # [R, 7, 7]
+    err = (out - expect[:, None]).abs().max()
+    # bf16 maps hold the ramp exactly only up to 8 significant bits: 26 * (2^-8) of headroom there
+    assert float(err) < (1e-3 if dtype == torch.float32 else 0.15), float(err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fullsize_roi_align_adjoint(gpu, ops, dtype):
+    """<fwd(x), g> == <x, bwd(g)> at config 3's full size (R = 8192 RoIs with borders and clamping included):
+    the backward kernel is exactly the transpose of the forward one.  x and g are non-negative, so both sides are
+    sums of non-negative terms and a relative tolerance is meaningful (with signed data the sums nearly cancel)."""
+    feats = [f.requires_grad_(True) for f in
+             _cfg3_pyramid(gpu, dtype, fill=lambda shape, s: torch.randn(shape, device=gpu, generator=torch.Generator(
+                 device=gpu).manual_seed(300 + s)).abs())]
+    rois = _cfg3_rois(gpu, inside=False)
+    out = ops.roi_align(feats, rois, 7, SCALES3, 2, True, 2, 224.0, 4, channels_last_out=True, out_dtype=torch.float32)
+    g = torch.randn(out.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(303)).abs()
+    g = g.contiguous(memory_format=torch.channels_last)
+    lhs = float((out.detach().double() * g.double()).sum())
+    out.backward(g)
+    rhs = sum(float((f.detach().double() * f.grad.double()).sum()) for f in feats)
+    # bf16: the returned gradients are rounded to bf16 once (2^-9 relative per element, random sign)
+    assert lhs > 1e6
+    assert abs(lhs - rhs) <= (2e-6 if dtype == torch.float32 else 1e-4) * lhs, (lhs, rhs)
+
+
+def test_fullsize_rpn_proposals_equal_topk_decode_nms(gpu, ops):
+    """hd_rpn_proposals at config 3's anchor set (832^2, 5 levels x 3 anchors, NA = 57 723 per image... x16 images,
+    pre 2000 / post 1000) == per-level top-k -> hd_box_decode -> hd_nms_batched(cls = level) composed by hand;
+    kept anchor indices compared exactly.  And NMS is idempotent on the result."""
+    strides = [4, 8, 16, 32, 64]
+    hw = [(math.ceil(832 / s), math.ceil(832 / s)) for s in strides]
+    base = torch.stack([ops.anchor_base([8.0 * s], [0.5, 1.0, 2.0]) for s in strides])
+    anchors = ops.anchor_grid(hw, strides, base, 0.5, gpu)
+    ls = [h * w * 3 for h, w in hw]
+    NA, B, pre, post = anchors.shape[0], 16, 2000, 1000
+    g = torch.Generator(device=gpu).manual_seed(304)
+    # distinct logits per image (ties would need the kernel's tie rule on the torch side too)
+    logits = torch.stack([torch.randperm(NA, device=gpu, generator=g).float() for _ in range(B)]) / NA * 8.0 - 4.0
+    deltas = torch.randn((B, NA, 4), device=gpu, generator=g) * 0.2
+    rois, sc, cnt, idx = ops.rpn_proposals(logits, deltas, anchors, ls, pre, post, 0.7, 2.0, 832.0, 832.0, return_index=True)
+    # by hand
+    cand_idx, cand_lvl, off = [], [], 0
+    for l, n in enumerate(ls):
+        k = min(n, pre)
+        top = torch.topk(logits[:, off:off + n], k, dim=1).indices + off
+        cand_idx.append(top)
+        cand_lvl.append(torch.full((B, k), l, dtype=torch.int32, device=gpu))
+        off += n
+    cand_idx, cand_lvl = torch.cat(cand_idx, 1), torch.cat(cand_lvl, 1)
+    K = cand_idx.shape[1]
+    a_sel = anchors[cand_idx.reshape(-1)]
+    d_sel = torch.gather(deltas, 1, cand_idx[..., None].expand(-1, -1, 4)).reshape(-1, 4)
+    boxes = ops.box_decode(a_sel.contiguous(), d_sel.contiguous(), 832.0, 832.0).view(B, K, 4)
+    lg = torch.gather(logits, 1, cand_idx)
+    ok = ((boxes[..., 2] - boxes[..., 0]) >= 2.0) & ((boxes[..., 3] - boxes[..., 1]) >= 2.0)
+    score = torch.where(ok, lg, torch.full_like(lg, float("-inf")))
+    keep, kc = ops.nms_batched(boxes.contiguous(), score.contiguous(), cand_lvl.contiguous(), None, float("-inf"), 0.7, 0, post)
+    assert torch.equal(kc, cnt)
+    kept_anchor = torch.where(keep >= 0, torch.gather(cand_idx, 1, keep.clamp(min=0).long()).to(torch.int32),
+                              torch.full_like(keep, -1))
+    assert torch.equal(kept_anchor, idx)
+    sel = torch.gather(boxes, 1, keep.clamp(min=0).long()[..., None].expand(-1, -1, 4))
+    sel = torch.where((keep >= 0)[..., None], sel, torch.zeros_like(sel))
+    assert torch.equal(sel, rois)
+    # idempotence: the survivors of one level never suppress each other
+    lv_of = torch.gather(cand_lvl, 1, keep.clamp(min=0).long())
+    sc_of = torch.gather(score, 1, keep.clamp(min=0).long())
+    nv = cnt.clone()
+    keep2, kc2 = ops.nms_batched(rois.contiguous(), sc_of.contiguous(), lv_of.contiguous(), nv, float("-inf"), 0.7, 0, post)
+    assert torch.equal(kc2, cnt)
+    ar = torch.arange(post, device=gpu, dtype=torch.int32)[None, :].expand(B, -1)
+    assert torch.equal(keep2, torch.where(ar < cnt[:, None], ar, torch.full_like(ar, -1)))

@@ -263,3 +263,29 @@ def test_other_yolov5_widths_train_and_detect(gpu, variant):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         det, cnt = model.forward_test(batch[0], conf_thr=0.01)
     assert det.shape == (2, 300, 6) and (cnt >= 0).all()
+
+
+def test_yolov5l_640_bs16_graph_replayed_steps(gpu):
+    """BASELINE config 4's per-GPU share: YOLOv5l 640x640 bs16 (80 classes), hipGraph-replayed train steps on one
+    fixed batch — finite, decreasing, and really replayed.  MIOpen's solver search is left off (the first step of a
+    640^2 `l` model would take minutes with it); the multi-GPU half of config 4 is covered by the gloo tests."""
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    was = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    try:
+        model = build_detector(dict(type="YOLOv5", variant="l", num_classes=80, img_size=640)).to(gpu)
+        model = model.to(memory_format=torch.channels_last).train()
+        assert sum(p.numel() for p in model.parameters()) > 40e6   # the `l` preset (46.5 M parameters), not `s`
+        tr = Trainer(model, lr=1e-3, total_steps=40, warmup_steps=2, device=gpu, use_graph=True, graph_warmup=2)
+        batch = _batch(16, 640, 80, 5, gpu, m_pad=40)
+        losses = [float(tr.step(*batch)[0]) for _ in range(12)]
+        assert tr._graph is not None, tr.graph_error
+        assert tr.graph_nodes > 500
+        assert np.isfinite(losses).all(), losses
+        replayed = losses[3:]                                      # >= 8 graph-replayed steps
+        assert len(replayed) >= 8 and replayed[-1] < replayed[0] and losses[-1] < losses[0], losses
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        torch.backends.cudnn.benchmark = was

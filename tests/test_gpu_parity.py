@@ -237,6 +237,62 @@ def test_roi_align_fwd_bwd(gpu, ops, layout, aligned, sr):
         assert H.rel_err(f.grad.cpu().numpy(), r) < TOL
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("sr", [1, 2])
+@pytest.mark.parametrize("in_dtype,out_dtype", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16"), ("f32", "bf16")])
+def test_roi_align_channels_last_fast_path(gpu, ops, sr, in_dtype, out_dtype):
+    """The separable channels-last kernels (float32 or bfloat16 maps, float32 accumulation): the oracle is fed the
+    same bf16-rounded features, so the float32-output cases hold the 1e-4 bar; a bf16 output adds its own rounding
+    (2^-9 relative).  C = 64 so both vector widths (4 x f32, 8 x bf16) tile the channels; RoIs span all levels,
+    touch the map borders and include sub-pixel and out-of-image boxes."""
+    strides = [4, 8, 16, 32]
+    feats, rois = _roi_case(53 + sr, 2, 64, 256, 90, strides)
+    extra = torch.tensor([[0, -20.0, -20.0, 30.0, 30.0], [1, 200.0, 180.0, 300.0, 290.0], [0, 10.2, 10.4, 10.9, 11.1],
+                          [1, 0.0, 0.0, 256.0, 256.0], [0, 255.0, 255.0, 256.0, 256.0], [1, -50.0, -50.0, -10.0, -10.0],
+                          [0, 3.0, 100.0, 250.0, 104.0], [1, 100.0, 3.0, 104.0, 250.0]])
+    rois = torch.cat([rois, extra])
+    scales = [1.0 / s for s in strides]
+    tin = torch.bfloat16 if in_dtype == "bf16" else torch.float32
+    tout = torch.bfloat16 if out_dtype == "bf16" else torch.float32
+    ref_feats = [_bf16_round(f) if in_dtype == "bf16" else f for f in feats]
+    fd = [dev(f, gpu).to(tin).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in ref_feats]
+    out = ops.roi_align(fd, dev(rois, gpu), 7, scales, sr, True, 2, 224.0 / 4, 4, channels_last_out=True, out_dtype=tout)
+    assert out.dtype == tout and out.is_contiguous(memory_format=torch.channels_last)
+    ref = co.roi_align_fwd([f.numpy() for f in ref_feats], rois.numpy(), 7, scales, sr, True, 2, 224.0 / 4, 4)
+    tol = TOL if out_dtype == "f32" else 6e-3
+    assert H.rel_err(out.detach().float().cpu().numpy(), ref) < tol
+    # element-wise too (a max-norm bound would hide a wrong small bin)
+    assert np.abs(out.detach().float().cpu().numpy() - ref).max() < tol * max(1.0, float(np.abs(ref).max()))
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(57))
+    go_ref = _bf16_round(go) if out_dtype == "bf16" else go
+    out.backward(dev(go_ref, gpu).to(tout).contiguous(memory_format=torch.channels_last))
+    rg = co.roi_align_bwd([tuple(f.shape) for f in feats], rois.numpy(), go_ref.numpy(), scales, sr, True, 2, 224.0 / 4, 4)
+    for f, r in zip(fd, rg):
+        assert f.grad.dtype == tin
+        assert H.rel_err(f.grad.float().cpu().numpy(), r) < (TOL if in_dtype == "f32" else 6e-3)
+
+
+def test_roi_align_fast_path_equals_generic_path(gpu, ops):
+    """Same inputs through the separable channels-last kernel and the any-stride kernel (NCHW maps): the two
+    summation orders agree to float32 rounding, forward and backward."""
+    strides = [4, 8, 16, 32]
+    feats, rois = _roi_case(58, 3, 32, 320, 200, strides)
+    scales = [1.0 / s for s in strides]
+    a = [dev(f, gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+    b = [dev(f, gpu).contiguous().requires_grad_(True) for f in feats]
+    oa = ops.roi_align(a, dev(rois, gpu), 7, scales, 2, True, 2, 224.0 / 4, 4, channels_last_out=True)
+    ob = ops.roi_align(b, dev(rois, gpu), 7, scales, 2, True, 2, 224.0 / 4, 4, channels_last_out=False)
+    assert H.rel_err(oa.detach().cpu().numpy(), ob.detach().cpu().numpy()) < 1e-5
+    go = torch.randn(oa.shape, generator=torch.Generator().manual_seed(59)).to(gpu)
+    oa.backward(go.contiguous(memory_format=torch.channels_last))
+    ob.backward(go)
+    for x, y in zip(a, b):
+        assert H.rel_err(x.grad.cpu().numpy(), y.grad.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 def test_roi_pool_fwd_bwd(gpu, ops, layout):
     """README.md:73 "-RoIPooling" variant: values and argmax bit-exact, backward = scatter to argmax."""
@@ -648,3 +704,41 @@ def test_mosaic_module_draws_on_device_and_feeds_the_assigner(gpu, ops):
     shapes = H.yolo_shapes(S, 13)
     cell, tbox, cls = ops.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, o_box, o_cls, o_cnt, 4.0)
     assert int((cell >= 0).sum()) > 0
+
+
+# ------------------------------------------------------------------------------- MaxIoUAssigner (host logic over hd_iou_assign)
+def test_max_iou_assigner_low_quality_match_is_deterministic(gpu, ops):
+    """padded gts used to be scattered onto box 0, colliding with a valid gt whose best box is box 0.
+    Reference here: the sequential per-gt loop of the public MaxIoUAssigner on the oracle's IoU matrix."""
+    from heltondetection_amd.assigners import MaxIoUAssigner
+    B, N, M = 3, 400, 12
+    a = H.boxes_batch(1, N, 256, 71)[0]
+    b = H.boxes_batch(B, M, 256, 72)
+    b[0, 0] = a[0]              # gt 0 of image 0 matches box 0 exactly -> its best box IS index 0
+    b[1, 3] = b[1, 2]           # two gts sharing one best box: the later gt wins the forced match
+    mv = torch.tensor([5, 12, 0], dtype=torch.int32)   # images with padded gts / none at all
+    asg = MaxIoUAssigner(0.7, 0.3, True)
+    outs = [asg(a.to(gpu), b.to(gpu), mv.to(gpu)) for _ in range(3)]
+    for o in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(o, outs[0]))
+    labels, matched, mx = [t.cpu().numpy() for t in outs[0]]
+    iou = co.pairwise_iou(np.broadcast_to(a.numpy(), (B, N, 4)).copy(), b.numpy())
+    for i in range(B):
+        m = int(mv[i])
+        if m == 0:
+            assert (labels[i] == -1).all() or (labels[i] <= 0).all()
+            continue
+        sub = iou[i, :, :m]
+        r_mx, r_am = sub.max(1), sub.argmax(1)
+        r_lab = np.full(N, -1, np.int32)
+        r_lab[r_mx < 0.3] = 0
+        r_lab[r_mx >= 0.7] = 1
+        r_match = r_am.astype(np.int32)
+        for j in range(m):                      # sequential: a later gt overwrites an earlier one
+            if sub[:, j].max() > 0:
+                n_best = int(sub[:, j].argmax())
+                r_lab[n_best] = 1
+                r_match[n_best] = j
+        assert np.array_equal(labels[i], r_lab), i
+        assert np.array_equal(matched[i], r_match), i
+    assert labels[0, 0] == 1 and matched[0, 0] == 0
