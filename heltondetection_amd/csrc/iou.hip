@@ -43,12 +43,15 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
   const int img = blockIdx.y;
   const int mv = m_valid ? min(m_valid[img], M) : M;
   const float4* bb = b + (int64_t)img * M;
+  int my_safe = 1;
   for (int m = threadIdx.x; m < M; m += kIouThreads) {
     float4 v = bb[m];
     s_box[m] = v;
     s_area[m] = hd_box_area(v);
+    my_safe &= (int)hd_box_div_safe_nn(v);
   }
-  __syncthreads();
+  // every b box of the image inside the exact range of the division-free quotient (hd_common.h)?
+  const bool b_safe = __syncthreads_and(my_safe) != 0;
   const int64_t T = (int64_t)N * M;
   const float4* aa = a + (int64_t)img * a_bstride4;
   float* o = out + (int64_t)img * T;
@@ -61,6 +64,8 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
     int m = (int)(e0 - (int64_t)n * M);
     float4 ab = aa[n];
     float aarea = hd_box_area(ab);
+    bool fast = b_safe && hd_box_div_safe_pos(ab);
+    uint32_t ones = 0u;
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -68,7 +73,11 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
         if (m < mv) {
           float4 gb = s_box[m];
           float garea = s_area[m];
-          r[k] = hd_iou_full(ab, aarea, gb, garea);
+          r[k] = fast ? hd_iou_fast(ab, aarea, gb, garea, &ones) : hd_iou_full(ab, aarea, gb, garea);
+          if (__builtin_expect(hd_ones_acc(ones), 0)) {  // all-ones denominator: the IEEE division decides
+            r[k] = hd_iou_full(ab, aarea, gb, garea);
+            ones = 0u;
+          }
         } else {
           r[k] = -1.0f;
         }
@@ -78,6 +87,7 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
           if (n < N) {
             ab = aa[n];
             aarea = hd_box_area(ab);
+            fast = b_safe && hd_box_div_safe_pos(ab);
           }
         }
       } else {
@@ -102,7 +112,6 @@ __global__ __launch_bounds__(kIouThreads) void pairwise_iou_kernel(
 // latency, no LDS access and no index arithmetic.  Measured (scratch micro-benchmark, B=2
 // N=409200 M=512): C=1 3.9 TB/s (VALU-bound on the IEEE division), C=4 5.6 TB/s, against 6.3 TB/s
 // for the same stores with no arithmetic and 6.5 TB/s for hipMemset.
-constexpr int kColRows = 128;  // rows per workgroup: 4 waves x 32 rows
 
 __device__ __forceinline__ float hd_readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -113,6 +122,8 @@ struct ColStore;
 template <>
 struct ColStore<4> {
   static __device__ __forceinline__ void st(float* p, const float* v) {
+    // plain stores: non-temporal ones were measured 20 % slower at M = 500, where the lines that straddle two
+    // rows are completed in L2 by the next row's store
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
@@ -136,40 +147,86 @@ template <int C, int NCH>
 __global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __restrict__ a, int64_t a_bstride4,
                                                                 const float4* __restrict__ b,
                                                                 const int32_t* __restrict__ m_valid, int N, int M,
-                                                                float* __restrict__ out) {
+                                                                int rpw, float* __restrict__ out) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mv = m_valid ? min(m_valid[img], M) : M;
   const float4* __restrict__ aa = a + (int64_t)img * a_bstride4;
   const float4* __restrict__ bb = b + (int64_t)img * M;
   float* __restrict__ o = out + (int64_t)img * N * M;
-  const int base = blockIdx.x * kColRows + wave * 32;
-  const int nr = max(0, min(32, N - base));
+  // rpw rows per wave (8, 16 or 32; the host picks fewer rows per wave when the grid would otherwise run as only a
+  // handful of rounds of resident waves: the last, partly filled round then costs a whole tile time)
+  const int base = (blockIdx.x * 4 + wave) * rpw;
+  const int nr = max(0, min(rpw, N - base));
   if (nr == 0) return;
   const float4 rb = lane < nr ? aa[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float ra = hd_box_area(rb);
+  const bool rows_unsafe = lane < nr && !hd_box_div_safe_pos(rb);
   constexpr int span = 64 * C;
   for (int s0 = 0; s0 < M; s0 += span * NCH) {
     float4 g[NCH][C];
     float ga[NCH][C];
     bool ok[NCH];
+    bool unsafe = rows_unsafe;
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
       const int m0 = s0 + h * span + lane * C;
       ok[h] = m0 < M;  // M % C == 0, so a lane's C columns are all inside or all outside
 #pragma unroll
+      for (int c = 0; c < C; ++c) g[h][c] = bb[ok[h] ? m0 + c : 0];  // unconditional: all NCH*C loads in flight at once
+    }
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+#pragma unroll
       for (int c = 0; c < C; ++c) {
-        g[h][c] = ok[h] ? bb[m0 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!ok[h]) g[h][c] = make_float4(0.f, 0.f, 0.f, 0.f);
         ga[h][c] = hd_box_area(g[h][c]);
+        unsafe |= !hd_box_div_safe_nn(g[h][c]);
       }
     }
+    // every box of this wave's tile inside the exact range of the division-free quotient (hd_common.h)?
+    const bool tile_fast = __ballot(unsafe) == 0ull;
     float* __restrict__ oc = o + (int64_t)base * M + s0 + lane * C;
     // the common case (full 32-row sub-tile, no padded columns in reach) runs without the two
     // per-output predicates: the kernel is VALU-bound, every instruction per output counts
-    const bool plain = (nr == 32) && (s0 + span * NCH <= mv || M == mv);
-    if (plain) {
+    const bool plain = (nr == rpw) && (s0 + span * NCH <= mv || M == mv);
+    if (plain && tile_fast) {
+      // the common case on real data: packed-f32 quotient, ~3 issue slots per output instead of ~13 for the IEEE
+      // division; same bits (tests/proofs/iou_div_proof.c).  A row whose outputs met an all-ones denominator
+      // (detector accumulated over the lane's outputs, one ballot per row) is recomputed with hd_iou_full.
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) {
+      for (int r = 0; r < rpw; ++r) {
+        const float4 ab = make_float4(hd_readlane_f(rb.x, r), hd_readlane_f(rb.y, r), hd_readlane_f(rb.z, r),
+                                      hd_readlane_f(rb.w, r));
+        const float aar = hd_readlane_f(ra, r);
+        float v[NCH][C];
+        uint32_t ones = 0u;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+          if (C >= 2) {
+#pragma unroll
+            for (int c = 0; c + 1 < C; c += 2) {
+              const hd_f2 q = hd_iou_fast2(ab, aar, g[h][c], ga[h][c], g[h][c + 1], ga[h][c + 1], &ones);
+              v[h][c] = q.x;
+              v[h][c + 1] = q.y;
+            }
+          } else {
+            v[h][0] = hd_iou_fast(ab, aar, g[h][0], ga[h][0], &ones);
+          }
+        }
+        if (__builtin_expect(__ballot(hd_ones_acc(ones)) != 0ull, 0)) {
+#pragma unroll
+          for (int h = 0; h < NCH; ++h)
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[h][c] = hd_iou_full(ab, aar, g[h][c], ga[h][c]);
+        }
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+          if (ok[h]) ColStore<C>::st(oc + (int64_t)r * M + h * span, v[h]);
+      }
+    } else if (plain) {
+#pragma unroll 8
+      for (int r = 0; r < rpw; ++r) {
         const float4 ab = make_float4(hd_readlane_f(rb.x, r), hd_readlane_f(rb.y, r), hd_readlane_f(rb.z, r),
                                       hd_readlane_f(rb.w, r));
         const float aar = hd_readlane_f(ra, r);
@@ -183,7 +240,7 @@ __global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __
       }
     } else {
 #pragma unroll 4
-      for (int r = 0; r < 32; ++r) {
+      for (int r = 0; r < rpw; ++r) {
         const float4 ab = make_float4(hd_readlane_f(rb.x, r), hd_readlane_f(rb.y, r), hd_readlane_f(rb.z, r),
                                       hd_readlane_f(rb.w, r));
         const float aar = hd_readlane_f(ra, r);
@@ -211,6 +268,17 @@ __device__ __forceinline__ unsigned long long pack_key(float iou, int n) {
   return ((unsigned long long)__float_as_uint(iou) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
 }
 
+// one pair for the assignment kernel (runs only for overlapping pairs): fast quotient when both boxes qualify,
+// IEEE division otherwise and for an all-ones denominator
+__device__ __forceinline__ float iou_pair(bool fast, const float4 a, float area_a, const float4 b, float area_b) {
+  if (fast) {
+    uint32_t ones = 0u;
+    const float v = hd_iou_fast(a, area_a, b, area_b, &ones);
+    if (__builtin_expect(!hd_ones_acc(ones), 1)) return v;
+  }
+  return hd_iou_full(a, area_a, b, area_b);
+}
+
 template <bool WITH_GT>
 __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
     const float4* __restrict__ a, int64_t a_bstride4, const float4* __restrict__ b,
@@ -230,17 +298,20 @@ __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
   const int m_end = min(mv, m_chunk0 + kAssignLdsMaxM);
   const int mc = max(m_end - m_chunk0, 0);
   const float4* bb = b + (int64_t)img * M + m_chunk0;
+  int my_safe = 1;
   for (int m = threadIdx.x; m < mc; m += kAssignThreads) {
     float4 v = bb[m];
     s_box[m] = v;
     s_area[m] = hd_box_area(v);
+    my_safe &= (int)hd_box_div_safe_nn(v);
     if (WITH_GT) s_key[m] = 0ull;
   }
-  __syncthreads();
+  const bool b_safe = __syncthreads_and(my_safe) != 0;  // division-free exact quotient allowed (hd_common.h)
   const float4* aa = a + (int64_t)img * a_bstride4;
   for (int n = blockIdx.x * kAssignThreads + threadIdx.x; n < N; n += gridDim.x * kAssignThreads) {
     const float4 ab = aa[n];
     const float aarea = hd_box_area(ab);
+    const bool fast = b_safe && hd_box_div_safe_pos(ab);
     float best;
     int bidx;
     if (m_chunk0 == 0) {
@@ -249,7 +320,7 @@ __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
       bidx = mv > 0 ? 0 : -1;
       if (mv > 0) {
         // exact value for m = 0 (may be > 0)
-        best = hd_iou_full(ab, aarea, s_box[0], s_area[0]);
+        best = iou_pair(fast, ab, aarea, s_box[0], s_area[0]);
         if (WITH_GT && best > 0.0f) {
           unsigned long long key = pack_key(best, n);
           if (key > s_key[0]) atomicMax(&s_key[0], key);
@@ -270,7 +341,7 @@ __global__ __launch_bounds__(kAssignThreads) void iou_assign_kernel(
       if (!(o0 || o1 || o2 || o3)) continue;
 #define HD_PAIR(OK, G, MM)                                                   \
   if (OK) {                                                                  \
-    const float v = hd_iou_full(ab, aarea, G, s_area[MM]);                   \
+    const float v = iou_pair(fast, ab, aarea, G, s_area[MM]);                \
     if (v > best) {                                                          \
       best = v;                                                              \
       bidx = m_chunk0 + (MM);                                                \
@@ -351,12 +422,16 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
     int C = 1;
     if (M % 4 == 0 && hd_aligned16(out) && util(4) >= 0.7) C = 4;
     else if (M % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && util(2) >= 0.7) C = 2;
-    dim3 cgrid((unsigned)((N + kColRows - 1) / kColRows), (unsigned)B);
+    // rows per wave: 32 when that still gives >= ~8 rounds of resident waves (16 per CU x 256 CUs), else 16 or 8
+    // (measured: 16 x 25200 x 512 runs 5.0 / 5.3 / 5.6 TB/s at 32 / 16 / 8 rows, 2 x 409200 x 500 prefers 16-32)
+    int rpw = 32;
+    while (rpw > 8 && (int64_t)B * ((N + rpw - 1) / rpw) < 8ll * 4096) rpw >>= 1;
+    dim3 cgrid((unsigned)((N + 4 * rpw - 1) / (4 * rpw)), (unsigned)B);
     const int spans = (M + 64 * C - 1) / (64 * C);
     const int nch = spans <= 3 ? spans : 1;  // rows-outer when the whole row fits in registers
 #define HD_LAUNCH_COLS(CC, NN)                                                                                      \
   hipLaunchKernelGGL((pairwise_iou_cols_kernel<CC, NN>), cgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, \
-                     M, out)
+                     M, rpw, out)
     if (C == 4) {
       if (nch == 1) HD_LAUNCH_COLS(4, 1);
       else if (nch == 2) HD_LAUNCH_COLS(4, 2);

@@ -742,3 +742,53 @@ def test_max_iou_assigner_low_quality_match_is_deterministic(gpu, ops):
         assert np.array_equal(labels[i], r_lab), i
         assert np.array_equal(matched[i], r_match), i
     assert labels[0, 0] == 1 and matched[0, 0] == 0
+
+
+# ------------------------------------------------------------------------------- division-free quotient, on the device
+def _adversarial_boxes(n, seed):
+    """Boxes that steer the IoU kernels through every branch of the fast/IEEE quotient selection: ordinary boxes,
+    the all-ones-denominator family (union = (2 - 2^-23) * 2^k with a power-of-two intersection, the one case the
+    fast sequence may miss by an ulp and must hand to the IEEE division), and boxes the range check must refuse
+    (-0.0, 1e-30, 1e30, inverted, zero-area)."""
+    g = torch.Generator().manual_seed(seed)
+    base = H.boxes_batch(1, n, 512, seed)[0]
+    special = []
+    eps = 2.0 ** -23
+    for k in (-8, -3, 0, 1, 5, 9):
+        s = 2.0 ** k
+        special += [[0.0, 0.0, s, s], [(1 - eps) * s, 0.0, (2 - eps) * s, s]]          # inter = 2^-23 s^2, union all-ones
+    special += [[-0.0, 0.0, 10.0, 10.0], [0.0, -0.0, 8.0, 12.0], [1e-30, 1e-30, 5.0, 5.0], [0.0, 0.0, 1e30, 1e30],
+                [7.0, 7.0, 3.0, 3.0], [4.0, 4.0, 4.0, 9.0], [0.0, 0.0, 0.0, 0.0], [2.0, 2.0, 6.0, 6.0],
+                [0.0, 0.0, float("inf"), 4.0]]
+    sp = torch.tensor(special, dtype=torch.float32)
+    idx = torch.randperm(n, generator=g)[: len(sp)]
+    base[idx] = sp
+    return base
+
+
+@pytest.mark.parametrize("M", [24, 64, 500])
+def test_iou_fast_quotient_paths_are_bit_exact(gpu, ops, M):
+    """M = 24: flat kernel; 64 / 500: lane-owns-columns kernel (C = 4 with one and two spans).  Every tile flavour:
+    all-safe tiles (packed fast quotient), tiles with an all-ones denominator (row recomputed), tiles with a
+    refused box (IEEE division).  Bit-exact against the oracle, which divides."""
+    B, N = 2, 1536
+    a = torch.stack([_adversarial_boxes(N, 81 + i) for i in range(B)])
+    b = torch.stack([_adversarial_boxes(M, 91 + i) for i in range(B)])
+    # rows 0..127 of image 0 and all of its columns stay ordinary, so fully "safe" tiles exist as well
+    a[0, :128] = H.boxes_batch(1, 128, 512, 97)[0]
+    b[0] = H.boxes_batch(1, M, 512, 98)[0]
+    # and a safe tile that contains ONLY the all-ones family in one row/column
+    eps = 2.0 ** -23
+    a[0, 5] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    b[0, 7] = torch.tensor([1 - eps, 0.0, 2 - eps, 1.0])
+    got = ops.pairwise_iou(a.to(gpu), b.to(gpu)).cpu().numpy()
+    ref = co.pairwise_iou(a.numpy(), b.numpy())
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert got[0, 5, 7] == np.float32(2.0 ** -23) / np.float32(2 - eps) and got[0, 5, 7] > 2.0 ** -24
+    mv = torch.tensor([M, max(M - 5, 1)], dtype=torch.int32)
+    for x, y in zip(ops.iou_assign(a.to(gpu), b.to(gpu), mv.to(gpu)), co.iou_assign(a.numpy(), b.numpy(), mv.numpy())):
+        assert np.array_equal(x.cpu().numpy(), y)
+    # shared anchors (a_bstride = 0)
+    got = ops.pairwise_iou(a[0].to(gpu), b.to(gpu)).cpu().numpy()
+    ref = co.pairwise_iou(np.broadcast_to(a[0].numpy(), (B, N, 4)).copy(), b.numpy())
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
