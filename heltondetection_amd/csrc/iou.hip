@@ -259,6 +259,78 @@ __global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __
   }
 }
 
+// Small-M variant (M / C <= 32): several ROWS share one wave instruction.  A lane owns C consecutive columns
+// (its C b boxes and their areas live in registers for the whole kernel) of row `lane / (M/C)` of the current
+// group of rpi = 64 / (M/C) rows, so a wave store still covers rpi*M*4 contiguous bytes (960 B at M = 40) and
+// there is no per-output index arithmetic, no LDS and no box that changes in the middle of a lane's vector —
+// the flat kernel spends ~30 instruction slots per output on exactly those, this one ~15.
+// A wave takes 64 rows at a time: their boxes are loaded once, coalesced, for the range check of the
+// division-free quotient; the per-group row loads that follow hit L1.
+constexpr int kRowsTile = 64;
+
+template <int C>
+__global__ __launch_bounds__(256) void pairwise_iou_rows_kernel(const float4* __restrict__ a, int64_t a_bstride4,
+                                                                const float4* __restrict__ b,
+                                                                const int32_t* __restrict__ m_valid, int N, int M,
+                                                                float* __restrict__ out) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = (blockIdx.x * 4 + wave) * kRowsTile;
+  if (base >= N) return;  // whole wave
+  const int mv = m_valid ? min(m_valid[img], M) : M;
+  const float4* __restrict__ aa = a + (int64_t)img * a_bstride4;
+  const float4* __restrict__ bb = b + (int64_t)img * M;
+  float* __restrict__ o = out + (int64_t)img * N * M;
+  const int cgn = M / C;     // column groups per row (<= 32)
+  const int rpi = 64 / cgn;  // rows per wave instruction (>= 2)
+  const int lrow = lane / cgn, lcg = lane - lrow * cgn;
+  const bool active = lrow < rpi;
+  float4 g[C];
+  float ga[C];
+  bool unsafe = false;
+#pragma unroll
+  for (int c = 0; c < C; ++c) g[c] = bb[lcg * C + c];  // lcg < cgn for every lane: always in range
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    ga[c] = hd_box_area(g[c]);
+    unsafe |= !hd_box_div_safe_nn(g[c]);
+  }
+  const int nr = min(kRowsTile, N - base);
+  const float4 tb = aa[base + min(lane, nr - 1)];
+  unsafe |= !hd_box_div_safe_pos(tb);
+  // fast: no padded column, every b box and every row box of this tile inside the exact range of the quotient
+  const bool fast = (mv == M) && __ballot(unsafe) == 0ull;
+  for (int r0 = 0; r0 < nr; r0 += rpi) {
+    const int rr = r0 + lrow;
+    const bool on = active && rr < nr;
+    const int n = base + (on ? rr : 0);
+    const float4 ab = aa[n];
+    const float aar = hd_box_area(ab);
+    float v[C];
+    if (fast) {
+      uint32_t ones = 0u;
+      if (C >= 2) {
+#pragma unroll
+        for (int c = 0; c + 1 < C; c += 2) {
+          const hd_f2 q = hd_iou_fast2(ab, aar, g[c], ga[c], g[c + 1], ga[c + 1], &ones);
+          v[c] = q.x;
+          v[c + 1] = q.y;
+        }
+      } else {
+        v[0] = hd_iou_fast(ab, aar, g[0], ga[0], &ones);
+      }
+      if (__builtin_expect(__ballot(hd_ones_acc(ones)) != 0ull, 0)) {  // all-ones denominator: IEEE division
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = hd_iou_full(ab, aar, g[c], ga[c]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c] = (lcg * C + c) < mv ? hd_iou_full(ab, aar, g[c], ga[c]) : -1.0f;
+    }
+    if (on) ColStore<C>::st(o + (int64_t)n * M + lcg * C, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 
 constexpr int kAssignThreads = 256;
@@ -416,6 +488,24 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
   hipStream_t s = (hipStream_t)stream;
   const float4* a4c = reinterpret_cast<const float4*>(a);
   const float4* b4c = reinterpret_cast<const float4*>(b);
+  // small M: several rows per wave instruction (M / C <= 32 column groups, C = 4 or 2 columns per lane)
+  {
+    int C = 0;
+    if (M % 4 == 0 && M / 4 <= 32 && hd_aligned16(out)) C = 4;
+    else if (M % 2 == 0 && M / 2 <= 32 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) C = 2;
+    if (C != 0) {
+      const int64_t gx = ((int64_t)N + 4 * kRowsTile - 1) / (4 * kRowsTile);
+      dim3 rgrid((unsigned)gx, (unsigned)B);
+      if (C == 4)
+        hipLaunchKernelGGL((pairwise_iou_rows_kernel<4>), rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
+                           out);
+      else
+        hipLaunchKernelGGL((pairwise_iou_rows_kernel<2>), rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
+                           out);
+      HD_RETURN_IF_LAUNCH_FAILED();
+      return HD_OK;
+    }
+  }
   if (M >= 48) {
     // columns per lane: the widest store whose last 64*C-column span is still >= 70 % occupied
     auto util = [&](int C) { const int span = 64 * C; return (double)M / (double)(((M + span - 1) / span) * span); };
