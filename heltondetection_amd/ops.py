@@ -873,10 +873,13 @@ def mosaic4(images: torch.Tensor, gt_boxes: torch.Tensor, gt_cls: torch.Tensor, 
     return out, ob, oc, cnt
 
 
-def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: int = 20, device=None):
+def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: int = 20, device=None,
+                        residual_after_act: bool = False):
     """Measurement helper for bench.py: the four fused-BN kernels on one channels-last tensor of `shape`
     ([B,C,H,W]), each launched `iters` times back to back on the current stream with a HIP event pair per launch
-    (saturated stream, so a pair spans the kernel only).  Returns {kernel: (median ms, algorithmic bytes)}."""
+    (saturated stream, so a pair spans the kernel only).  Returns {kernel: (median ms, algorithmic bytes)}.
+    residual_after_act: the apply kernel also reads a residual tensor (y = act(bn(x)) + r, the YOLOv5 shortcut;
+    the backward kernels are the plain ones in that mode)."""
     lib = _lib.load()
     device = torch.device(device or "cuda")
     x = torch.randn(shape, device=device).to(dtype).contiguous(memory_format=torch.channels_last)
@@ -891,6 +894,7 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
     b = torch.zeros(Cc, dtype=_F32, device=device)
     save = torch.zeros((2, Cc), dtype=_F32, device=device)
     y = torch.empty_like(x)
+    res = torch.randn_like(x) if residual_after_act else None
     dg = torch.empty((2, Cc), dtype=_F32, device=device)
     st = _stream(x)
     code = _ACT_CODE[act]
@@ -916,7 +920,7 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
     check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")
     out["bn_apply_kernel"] = (run(lambda: check(lib.hd_bn_act_apply(
         _ptr(x), dt, R, 0, Cc, _ptr(sums), _ptr(w), _ptr(b), 1e-3, 0.03, None, None, _ptr(save[0]), _ptr(save[1]), code,
-        None, 0, _ptr(y), st), "apply")), 2 * tb)
+        _ptr(res), 2 if res is not None else 0, _ptr(y), st), "apply")), (3 if res is not None else 2) * tb)
     out["bn_bwd_reduce_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_reduce(
         _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), st), "reduce")), 2 * tb)
     out["bn_bwd_dx_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_dx(
