@@ -207,6 +207,18 @@ def micro_kernels(device):
         ts = sorted(x.elapsed_time(y) for x, y in evs)
         return ts[len(ts) // 2]
 
+    def ktime(name, fn, iters=10, warm=3):
+        """Kernel-only HIP-event timing (the launch stamps its own event pair) of a single-kernel op."""
+        for _ in range(warm):
+            fn()
+        ops.enable_timing(name)
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        ts = sorted(ops.collect_timing()[name])
+        ops.disable_timing()
+        return ts[len(ts) // 2]
+
     def add(name, ms, nbytes, shape, bound="hbm"):
         print(f"[bench micro] {name} {shape}: {ms:.4f} ms", file=sys.stderr, flush=True)
         gbs = nbytes / ms / 1e6
@@ -219,7 +231,7 @@ def micro_kernels(device):
     a = torch.stack([syn.random_boxes(N, 1280.0, g, 8.0, 512.0) for _ in range(1)])[0].to(device)
     b = torch.stack([syn.random_boxes(M, 1280.0, g, 4.0, 64.0) for _ in range(B)]).to(device)
     out_holder = {}
-    ms = timeit(lambda: out_holder.__setitem__("o", ops.pairwise_iou(a, b)))
+    ms = ktime("pairwise_iou", lambda: out_holder.__setitem__("o", ops.pairwise_iou(a, b)))
     add("pairwise_iou_cols_kernel", ms, B * (16 * (N + M) + 4 * N * M), f"B={B} N={N} M={M}")
     out_holder.clear()
     ms = timeit(lambda: ops.iou_assign(a, b))
@@ -230,7 +242,7 @@ def micro_kernels(device):
     b2 = torch.stack([syn.random_boxes(M2, 640.0, g) for _ in range(B2)]).to(device)
     ms = timeit(lambda: ops.iou_assign(a2, b2))
     add("iou_assign_kernel(+finalize)", ms, B2 * (16 * (N2 + M2) + 8 * N2), f"B={B2} N={N2} M={M2}", "valu")
-    ms = timeit(lambda: out_holder.__setitem__("o", ops.pairwise_iou(a2, b2)))
+    ms = ktime("pairwise_iou", lambda: out_holder.__setitem__("o", ops.pairwise_iou(a2, b2)))
     add("pairwise_iou_rows_kernel (M / 4 <= 32)", ms, B2 * (16 * (N2 + M2) + 4 * N2 * M2), f"B={B2} N={N2} M={M2}")
     out_holder.clear()
     # YOLOv5 decode bs16 640^2 C=80
@@ -284,7 +296,7 @@ def micro_kernels(device):
             rb = syn.random_boxes(R, 832.0, g, 16.0, 400.0)
             rois = torch.cat([torch.arange(16).repeat_interleave(per_img)[:, None].float(), rb], 1).to(device)
             esz = 4 if dt == torch.float32 else 2
-            ms = timeit(lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
+            ms = ktime("roi_align_fwd", lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
             add(f"roi_align_fwd_cl_kernel<{dn}>", ms, R * 256 * 49 * esz + map_bytes,
                 f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the four maps once)")
             if per_img == 128:
@@ -368,8 +380,9 @@ def bn_family_roofline(model, batch, args, device):
                      {"bn_layers": len(recs), "launches_per_step": n_launch, "sum_launch_ms_per_step": round(tot_ms, 4),
                       "algorithmic_bytes_per_step": int(tot_bytes), "distinct_layer_shapes": len(cache),
                       "layer_bytes_min_max": [sizes[0], sizes[-1]] if sizes else None,
-                      "timed": "HIP event pair around each of 12 back-to-back launches per (kernel, layer shape) on the launch "
-                               "stream, right after the timed region; medians summed over the layers of one step",
+                      "timed": "every launch stamps its own HIP event pair with the kernel's begin / end (hipExtLaunchKernel through "
+                               "hd_debug_time_next_launch) on the launch stream, 12 launches per (kernel, layer shape), right after the timed "
+                               "region; medians summed over the layers of one step",
                       "per_kernel": {k: {"sum_ms": round(v[0], 4), "GB/s": round(v[1] / v[0] / 1e6, 1),
                                          "frac": round(v[1] / v[0] / 1e6 / HBM_PEAK_GBS, 4), "launches": v[2]}
                                      for k, v in per_kernel.items()}},
@@ -389,7 +402,7 @@ def yolo_dense_grad_roofline(model, batch, args):
     k_ms = sum(ms_list) / max(len(ms_list), 1)
     nbytes = loss_bwd_bytes(args.batch, args.size, args.classes + 5)
     return _hbm_entry("yolo_grad_dense_kernel (hd_yolo_loss_bwd_dense)", k_ms * len(ms_list), nbytes * len(ms_list), len(ms_list),
-                      {"timed": "HIP event pair around each of K back-to-back launches on this workload's head outputs"},
+                      {"timed": "every launch stamps its own HIP event pair (kernel begin / end) on this workload's head outputs"},
                       traffic=pmc_traffic("yolo_grad_dense_kernel", f"bs{args.batch} {args.size} no{args.classes + 5}"))
 
 
@@ -425,7 +438,7 @@ def roi_align_roofline(model, batch, args, device):
     shape = f"R={R} C={Cc} P={rh.P} s={rh.sr} {args.size} bs{args.batch} {str(fs[0].dtype).replace('torch.', '')}"
     main = _hbm_entry("roi_align_fwd_cl_kernel + roi_align_bwd_cl_kernel (hd_roi_align_fwd / _bwd), one launch each per step",
                       f_ms + b_ms, f_bytes + b_bytes, 2,
-                      {"shape": shape, "timed": "HIP event pair around each of 12 launches on the step's own pyramid and sampled RoIs",
+                      {"shape": shape, "timed": "every launch stamps its own HIP event pair (kernel begin / end) on the step's own pyramid and sampled RoIs",
                        "per_kernel": {"roi_align_fwd_cl_kernel": {"ms": round(f_ms, 4), "GB/s": round(f_bytes / f_ms / 1e6, 1),
                                                                   "frac": round(f_bytes / f_ms / 1e6 / HBM_PEAK_GBS, 4)},
                                       "roi_align_bwd_cl_kernel": {"ms": round(b_ms, 4), "GB/s": round(b_bytes / b_ms / 1e6, 1),

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "hd_abi_version": (C.c_int, []),
     "hd_status_str": (C.c_char_p, [_I]),
     "hd_device_count": (C.c_int, []),
+    "hd_debug_time_next_launch": (_I, [_P, _P]),
     "hd_anchor_base": (_I, [_P, _I, _P, _I, _P]),
     "hd_anchor_grid": (_I, [_I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "hd_pairwise_iou": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P]),

@@ -490,10 +490,10 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
   const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   if (dtype == 0)
-    hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,
+    (void)hd_launch(bn_stats_kernel<float>, dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,
                        reinterpret_cast<const float*>(x), nvec, C, sums);
   else
-    hipLaunchKernelGGL((bn_stats_kernel<__hip_bfloat16>), dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,
+    (void)hd_launch(bn_stats_kernel<__hip_bfloat16>, dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,
                        reinterpret_cast<const __hip_bfloat16*>(x), nvec, C, sums);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
@@ -521,7 +521,7 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
   const float unbias = RS > 1 ? (float)RS / (float)(RS - 1) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
 #define HD_APPLY_R(T, A, RS_, XT)                                                                                  \
-  hipLaunchKernelGGL((bn_apply_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
+  (void)hd_launch(bn_apply_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
                      reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(res), nvec, C, inv_R, unbias,    \
                      sums, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,         \
                      reinterpret_cast<XT*>(y))
@@ -551,7 +551,7 @@ extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C,
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   hipStream_t s = (hipStream_t)stream;
 #define HD_INFER(T, A, XT)                                                                                         \
-  hipLaunchKernelGGL((bn_infer_kernel<XT, A>), dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), \
+  (void)hd_launch(bn_infer_kernel<XT, A>, dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), \
                      nvec, C, gamma, beta, running_mean, running_var, eps, reinterpret_cast<XT*>(y))
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_INFER, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_INFER, __hip_bfloat16);
@@ -585,7 +585,7 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
 #define HD_RED_R(T, A, RS_, XT)                                                                                    \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), lds, s,                    \
+  (void)hd_launch(bn_bwd_reduce_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), lds, s,                    \
                      reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
                      (long long)ld, nvec, C, save_mean, save_invstd, gamma, beta, dsums)
 #define HD_RED(T, A, XT)                \
@@ -621,7 +621,7 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_
   const float inv_R = 1.0f / (float)(stat_rows > 0 ? stat_rows : R);
   hipStream_t s = (hipStream_t)stream;
 #define HD_DX_R(T, A, RS_, XT)                                                                                     \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<XT, A, RS_>), dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
+  (void)hd_launch(bn_bwd_dx_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
                      reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
                      reinterpret_cast<XT*>(dres), (long long)ld, nvec, C, inv_R, save_mean, save_invstd, gamma, beta, \
                      dsums, reinterpret_cast<XT*>(dx), dgamma, dbeta)

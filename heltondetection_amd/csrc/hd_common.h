@@ -186,6 +186,44 @@ __device__ __forceinline__ int hd_wave_sum_i(int v) {
 
 __device__ __forceinline__ int hd_lane() { return threadIdx.x & 63; }
 
+// ---- launches with optional kernel-only timing ----------------------------------------------------------
+// hd_launch() is hipLaunchKernel with the arguments converted to the kernel's exact parameter types.  When the
+// caller armed this thread with hd_debug_time_next_launch(start, stop) the launch goes through hipExtLaunchKernel
+// instead, which stamps the two events with the kernel's OWN begin / end (the dispatch packet's timestamps — the
+// interval rocprofv3 reports), so bench.py's rooflines are HIP-event measurements of the kernel alone, without
+// the host launch gap or the ~1.5 us boundary an event pair around the launch would include.
+#include <hip/hip_ext.h>
+
+#include <tuple>
+#include <utility>
+
+struct HdLaunchTiming {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+inline HdLaunchTiming& hd_launch_timing() {
+  static thread_local HdLaunchTiming t;
+  return t;
+}
+
+template <typename Tuple, size_t... I>
+inline hipError_t hd_launch_impl(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Tuple& args,
+                                 std::index_sequence<I...>) {
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(args))...};
+  HdLaunchTiming& t = hd_launch_timing();
+  if (t.stop != nullptr) {
+    const hipEvent_t a = t.start, b = t.stop;
+    t.start = t.stop = nullptr;  // one launch per arming
+    return hipExtLaunchKernel(fn, grid, block, ptrs, lds, s, a, b, 0);
+  }
+  return hipLaunchKernel(fn, grid, block, ptrs, lds, s);
+}
+template <typename... KArgs, typename... Args>
+inline hipError_t hd_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "hd_launch: argument count does not match the kernel");
+  std::tuple<KArgs...> held{static_cast<KArgs>(args)...};
+  return hd_launch_impl(reinterpret_cast<const void*>(kernel), grid, block, lds, s, held, std::index_sequence_for<KArgs...>{});
+}
+
 // Device-side fill (32-bit pattern).  Used instead of hipMemsetAsync: a memset becomes a memset
 // NODE when the caller captures the stream into a hipGraph, and on ROCm 7.2 those nodes were
 // observed not to stay ordered with the surrounding kernel nodes once eager launches are

@@ -497,10 +497,10 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
       const int64_t gx = ((int64_t)N + 4 * kRowsTile - 1) / (4 * kRowsTile);
       dim3 rgrid((unsigned)gx, (unsigned)B);
       if (C == 4)
-        hipLaunchKernelGGL((pairwise_iou_rows_kernel<4>), rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
+        (void)hd_launch(pairwise_iou_rows_kernel<4>, rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
                            out);
       else
-        hipLaunchKernelGGL((pairwise_iou_rows_kernel<2>), rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
+        (void)hd_launch(pairwise_iou_rows_kernel<2>, rgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, M,
                            out);
       HD_RETURN_IF_LAUNCH_FAILED();
       return HD_OK;
@@ -520,7 +520,7 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
     const int spans = (M + 64 * C - 1) / (64 * C);
     const int nch = spans <= 3 ? spans : 1;  // rows-outer when the whole row fits in registers
 #define HD_LAUNCH_COLS(CC, NN)                                                                                      \
-  hipLaunchKernelGGL((pairwise_iou_cols_kernel<CC, NN>), cgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, \
+  (void)hd_launch(pairwise_iou_cols_kernel<CC, NN>, cgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, \
                      M, rpw, out)
     if (C == 4) {
       if (nch == 1) HD_LAUNCH_COLS(4, 1);

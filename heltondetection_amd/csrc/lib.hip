@@ -1,7 +1,7 @@
 // lib.hip — library-level entry points (version, status text, device probe).
 #include "hd_common.h"
 
-extern "C" int hd_abi_version(void) { return 9; }
+extern "C" int hd_abi_version(void) { return 10; }
 
 extern "C" const char* hd_status_str(hd_status s) {
   switch (s) {
@@ -23,4 +23,15 @@ extern "C" int hd_device_count(void) {
     return 0;
   }
   return n;
+}
+
+// Arms the calling thread: the next kernel launched through hd_launch() (the fused BN kernels, the dense loss
+// gradient, RoIAlign, pairwise IoU) stamps `start` / `stop` (hipEvent_t created with timing enabled) with that
+// kernel's own begin and end.  NULL, NULL disarms.  Measurement aid of bench.py; no effect on results.
+extern "C" hd_status hd_debug_time_next_launch(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return HD_ERR_NULL;
+  HdLaunchTiming& t = hd_launch_timing();
+  t.start = reinterpret_cast<hipEvent_t>(start_event);
+  t.stop = reinterpret_cast<hipEvent_t>(stop_event);
+  return HD_OK;
 }

@@ -590,7 +590,7 @@ extern "C" hd_status hd_roi_align_fwd(const hd_roi_levels* levels, const float* 
     threads = threads < 64 ? 64 : (threads > 512 ? 512 : threads);
     const unsigned grid = (unsigned)((R + 7) / 8) * 8u;
 #define HD_ROI_FWD(TF, TO, SR)                                                                                       \
-  hipLaunchKernelGGL((roi_align_fwd_cl_kernel<TF, TO, SR>), dim3(grid), dim3(threads), 0, s, *levels, rois, R, C, P, \
+  (void)hd_launch(roi_align_fwd_cl_kernel<TF, TO, SR>, dim3(grid), dim3(threads), 0, s, *levels, rois, R, C, P, \
                      aligned, reinterpret_cast<TO*>(out), (long long)out_sr, (long long)out_sh, (long long)out_sw)
 #define HD_ROI_FWD_SR(TF, TO)              \
   do {                                     \
@@ -636,7 +636,7 @@ extern "C" hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const fl
     const int threads = C > 128 ? 256 : (C > 64 ? 128 : 64);
     const unsigned grid = (unsigned)((long long)R * P);
 #define HD_ROI_BWD(TG, SR)                                                                                     \
-  hipLaunchKernelGGL((roi_align_bwd_cl_kernel<TG, SR>), dim3(grid), dim3(threads), 0, s, *grad_levels, rois, C, P, \
+  (void)hd_launch(roi_align_bwd_cl_kernel<TG, SR>, dim3(grid), dim3(threads), 0, s, *grad_levels, rois, C, P, \
                      aligned, reinterpret_cast<const TG*>(grad_out), (long long)out_sr, (long long)out_sh,     \
                      (long long)out_sw)
     if (gbf) {

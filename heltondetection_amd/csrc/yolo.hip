@@ -896,7 +896,7 @@ extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_y
   float* part = grad_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes)
                           : nullptr;
   const unsigned gx = dense_grid_x(*lv, fl, ix);
-  hipLaunchKernelGGL(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
+  (void)hd_launch(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
                      B, *cfg, grad_scale, tobj, part);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;

@@ -19,8 +19,10 @@ class YOLOv5(nn.Module):
         self.backbone = BACKBONES.build(backbone or dict(type="CSPDarknet", variant=variant))
         self.neck = NECKS.build(neck or dict(type="YOLOv5PAFPN", depth=self.backbone.depth),
                                 in_channels=self.backbone.out_channels)
-        self.head = HEADS.build(head or dict(type="YOLOv5Head", num_classes=num_classes, img_size=img_size),
-                                in_channels=self.neck.out_channels)
+        head = dict(head) if head else dict(type="YOLOv5Head")
+        head.setdefault("num_classes", num_classes)  # a head config without its own class count takes the detector's
+        head.setdefault("img_size", img_size)
+        self.head = HEADS.build(head, in_channels=self.neck.out_channels)
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
                 # num_batches_tracked stays a buffer (checkpoints of stock torch BatchNorm2d modules load with
@@ -71,6 +73,8 @@ class FasterRCNN(nn.Module):
             roi_head = dict(type="RoIHead", in_channels=ch, num_classes=num_classes, decoupled=True)
             if p2_only:
                 roi_head.update(featmap_strides=(4,))
+        roi_head = dict(roi_head)
+        roi_head.setdefault("num_classes", num_classes)
         self.roi_head = HEADS.build(roi_head)
 
     def extract(self, images):

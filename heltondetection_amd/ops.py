@@ -62,6 +62,7 @@ def collect_timing() -> dict:
 
 
 class _timed:
+    """Event pair around a whole C-ABI call (ops that launch several kernels)."""
     __slots__ = ("name", "start")
 
     def __init__(self, name: str):
@@ -78,6 +79,35 @@ class _timed:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             _TIMED[self.name].append((self.start, end))
+        return False
+
+
+def _arm_kernel_timing():
+    """Arms libhd_ops so that the NEXT launch of an hd_launch() kernel stamps a fresh event pair with the kernel's own
+    begin / end (hd_debug_time_next_launch: the dispatch's timestamps, what a profiler reports).  Returns the pair."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()  # creates the hipEvent_t handles (torch creates them lazily at the first record)
+    b.record()
+    check(_lib.load().hd_debug_time_next_launch(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)), "hd_debug_time_next_launch")
+    return a, b
+
+
+class _ktimed:
+    """Kernel-only timing of a single-kernel C-ABI call: the event pair is stamped by the launch itself."""
+    __slots__ = ("name", "pair")
+
+    def __init__(self, name: str):
+        self.name = name if name in _TIMED else None
+
+    def __enter__(self):
+        if self.name is not None:
+            self.pair = _arm_kernel_timing()
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            _lib.load().hd_debug_time_next_launch(None, None)  # in case the call did not launch (empty input)
+            _TIMED[self.name].append(self.pair)
         return False
 
 
@@ -127,7 +157,7 @@ def pairwise_iou(a: torch.Tensor, b: torch.Tensor, m_valid: Optional[torch.Tenso
     if m_valid is not None:
         m_valid = _need(m_valid, _I32, "m_valid")
     out = torch.empty((B, N, M), dtype=_F32, device=b.device)
-    with _timed("pairwise_iou"):
+    with _ktimed("pairwise_iou"):
         check(lib.hd_pairwise_iou(_ptr(a), 0 if shared else N * 4, _ptr(b), _ptr(m_valid), B, N, M, _ptr(out),
                                   _stream(b)), "hd_pairwise_iou")
     return out
@@ -262,7 +292,7 @@ class _RoIAlignFn(torch.autograd.Function):
         R, Cc = rois.shape[0], feats[0].shape[1]
         out = torch.empty((R, Cc, P, P), dtype=out_dtype, device=rois.device,
                           memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
-        with _timed("roi_align_fwd"):
+        with _ktimed("roi_align_fwd"):
             check(lib.hd_roi_align_fwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
                                        _ptr(out), 0 if out_dtype == _F32 else 1, out.stride(0), out.stride(1),
                                        out.stride(2), out.stride(3), _stream(rois)), "hd_roi_align_fwd")
@@ -285,7 +315,7 @@ class _RoIAlignFn(torch.autograd.Function):
                  for shape, cl_fmt, _ in shapes]
         st = _roi_levels(grads, scales, k_min, cs, cl)
         R, Cc = rois.shape[0], shapes[0][0][1]
-        with _timed("roi_align_bwd"):
+        with _ktimed("roi_align_bwd"):
             check(lib.hd_roi_align_bwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
                                        _ptr(grad_out), 0 if grad_out.dtype == _F32 else 1, grad_out.stride(0),
                                        grad_out.stride(1), grad_out.stride(2), grad_out.stride(3), _stream(rois)),
@@ -505,9 +535,8 @@ def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, bo
 def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,
                              iters: int = 20) -> List[float]:
     """Measurement helper for bench.py: runs the loss forward once on `preds`, then launches
-    hd_yolo_loss_bwd_dense `iters` times back-to-back on the current stream with a HIP event pair around
-    every launch (the stream stays saturated, so an event pair spans the kernel and nothing else).
-    Returns the per-launch milliseconds after a device synchronise."""
+    hd_yolo_loss_bwd_dense `iters` times on the current stream, each launch stamping its own HIP event pair with
+    the kernel's begin / end (hd_debug_time_next_launch).  Returns the per-launch milliseconds."""
     lib = _lib.load()
     preds = [p.detach() for p in preds]
     st = _yolo_levels(preds, strides, anchors)
@@ -525,13 +554,11 @@ def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, sl
     gbias = torch.zeros((len(preds), st.na * st.no), dtype=_F32, device=dev)
     evs = []
     for i in range(iters + 3):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+        pair = _arm_kernel_timing()
         check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws),
                                          wsb, s), "hd_yolo_loss_bwd_dense")
-        b.record()
         if i >= 3:
-            evs.append((a, b))
+            evs.append(pair)
     torch.cuda.synchronize(dev)
     return [a.elapsed_time(b) for a, b in evs]
 
@@ -876,8 +903,9 @@ def mosaic4(images: torch.Tensor, gt_boxes: torch.Tensor, gt_cls: torch.Tensor, 
 def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: int = 20, device=None,
                         residual_after_act: bool = False):
     """Measurement helper for bench.py: the four fused-BN kernels on one channels-last tensor of `shape`
-    ([B,C,H,W]), each launched `iters` times back to back on the current stream with a HIP event pair per launch
-    (saturated stream, so a pair spans the kernel only).  Returns {kernel: (median ms, algorithmic bytes)}.
+    ([B,C,H,W]), each launched `iters` times on the current stream, every launch stamping its own HIP event pair
+    with the kernel's begin / end (hd_debug_time_next_launch), i.e. the kernel alone, without host launch gaps.
+    Returns {kernel: (median ms, algorithmic bytes)}.
     residual_after_act: the apply kernel also reads a residual tensor (y = act(bn(x)) + r, the YOLOv5 shortcut;
     the backward kernels are the plain ones in that mode)."""
     lib = _lib.load()
@@ -905,11 +933,8 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
             fn()
         evs = []
         for _ in range(iters):
-            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            evs.append(_arm_kernel_timing())  # the launch stamps the pair with the kernel's own begin / end
             fn()
-            e.record()
-            evs.append((a, e))
         torch.cuda.synchronize(device)
         ts = sorted(a.elapsed_time(e) for a, e in evs)
         return ts[len(ts) // 2]

@@ -59,6 +59,11 @@ int hd_abi_version(void);
 const char* hd_status_str(hd_status s);
 /* Number of visible HIP devices (0 on a CPU-only host); never throws. */
 int hd_device_count(void);
+/* Measurement aid: arms the calling thread so that the NEXT launch of one of the HBM-bound kernels (fused
+ * BN+act, hd_yolo_loss_bwd_dense, hd_roi_align_fwd/_bwd fast paths, hd_pairwise_iou) records the kernel's own
+ * begin / end into the two hipEvent_t (timing enabled) — the interval a profiler reports for the dispatch, free of
+ * host launch gaps.  NULL, NULL disarms.  Results are unaffected. */
+hd_status hd_debug_time_next_launch(void* start_event, void* stop_event);
 
 /* ---- anchors (FasterRCNN RPN, README.md:8) --------------------------------- */
 

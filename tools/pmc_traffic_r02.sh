@@ -56,6 +56,11 @@ for dn, esz in (("f32", 4), ("bf16", 2)):
             int(R * 256 * 49 * esz + maps * esz))
 one("roi_align_bwd_cl_kernel", "R=2048 C=256 P=7 s=2 (f32 and bf16 incoming gradient, mean), f32 gradient maps",
     int(2048 * 256 * 49 * 3 + 2 * maps * 4))
+f2, b2 = out.get("roi_align_fwd_cl_kernel<bf16> R=2048"), out.get("roi_align_bwd_cl_kernel")
+if f2 and b2:  # what bench.py --model frcnn reports as `roofline`: one forward + one backward launch of the train step
+    out["roi_align_step"] = {"shape": "R=2048 C=256 P=7 s=2 832 bs16 bfloat16", "traffic_bytes": f2["traffic_bytes"] + b2["traffic_bytes"],
+                             "algorithmic_bytes": f2["algorithmic_bytes"] + int(2048 * 256 * 49 * 2 + 2 * maps * 4),
+                             "note": "random maps and random RoIs of the same shapes as the step's (the step's own RoIs cluster around the ground truth)"}
 json.dump(out, open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r02_pmc_traffic.json", "w"), indent=1)
 for k, v in out.items():
     if k != "_note": print(k, {a: b for a, b in v.items() if a != "per_kernel"})

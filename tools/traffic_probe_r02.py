@@ -14,8 +14,10 @@ recs = []
 hooks = [m.register_forward_hook(lambda mod, inp, out: recs.append((tuple(out.shape), mod.act_name, len(inp) > 1 and inp[1] is not None)))
          for m in model.modules() if isinstance(m, ConvBNAct)]
 img = syn.make_images(16, 640, g).to(dev).contiguous(memory_format=torch.channels_last)
+ConvBNAct.fused = False   # shape collection only: keep this pass out of the counted bn_* launches
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
     model.extract(img)
+ConvBNAct.fused = True
 for h in hooks: h.remove()
 del model
 print("bn layers", len(recs))
