@@ -488,7 +488,7 @@ def main():
     lr = 1e-3 if args.model == "yolov5" else 2e-4
     trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
                       total_steps=args.steps + args.warmup + 8, warmup_steps=3, device=device,
-                      use_graph=not args.no_graph, graph_sync=False, graph_warmup=graph_warmup)
+                      use_graph=not args.no_graph, graph_warmup=graph_warmup)
     batches = make_batches(4 if args.model == "yolov5" else 2, args.batch, args.size, args.classes, 1234 + rank, device)
 
     log(f"{model_name(args)} + data ready on {torch.cuda.get_device_name(device)}; warm-up {args.warmup} steps "
@@ -592,6 +592,8 @@ def main():
             "final_loss": round(loss_val, 4),
         }
         out["config"]["hip_graph"] = trainer._graph is not None
+        if getattr(trainer, "_segments", None) is not None:
+            out["config"]["hip_graph_segments"] = len(trainer._segments)   # split replay: all-reduce k overlaps segment k + 1
         if slow_replay:
             out["config"]["hip_graph_slow_replay"] = True
             out["config"]["eager_ms_per_step_seen_in_warmup"] = round(min(eager_ms), 3)

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -113,6 +113,10 @@ SIGNATURES = {
     "hd_bn_act_bwd_reduce": (_I, [_P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "hd_bn_act_bwd_dx": (_I, [_P, _P, _L, _I, _L, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "hd_graph_replace_memsets": (_I, [_P, _P, _P]),
+    "hd_graph_mark": (_I, [_P, _I, _P]),
+    "hd_graph_split_instantiate": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "hd_graph_exec_launch": (_I, [_P, _P]),
+    "hd_graph_exec_destroy": (_I, [_P]),
     "hd_wbf_workspace_bytes": (_Z, [_I, _I]),
     "hd_wbf": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
 }

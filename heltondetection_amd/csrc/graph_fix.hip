@@ -7,6 +7,7 @@
 // point takes the raw hipGraph_t BEFORE instantiation (PyTorch: CUDAGraph(keep_graph=True) ->
 // raw_cuda_graph()), and for every memset node adds a fill-kernel node with the same
 // predecessors and successors, then destroys the memset node.  The caller instantiates afterwards.
+#include <algorithm>
 #include <vector>
 
 #include "hd_common.h"
@@ -100,4 +101,143 @@ extern "C" hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out,
   if (n_nodes_out) *n_nodes_out = (int)n;
   if (n_replaced_out) *n_replaced_out = replaced;
   return HD_OK;
+}
+
+// ---- splitting a captured step at bucket boundaries (multi-GPU overlap under hipGraph replay) -------------------
+// A train step replayed as ONE graph cannot overlap its gradient all-reduce with backward: a collective can only be
+// launched once the whole replay has been enqueued.  So the capture carries MARKERS — a one-lane kernel launched by
+// dist.GradReducer right after it packed a bucket — and hd_graph_split_instantiate() cuts the captured graph into
+// segments ending at the markers: segment k = every node that marker k depends on and that no earlier marker does,
+// the tail = the rest.  Each segment is a clone of the graph with the other nodes destroyed (the clone keeps kernel
+// parameters and the intra-segment edges; edges across segments disappear with the destroyed endpoints and are
+// re-established by launching the segments in order on one stream).  The host then replays segment k, launches
+// bucket k's RCCL all-reduce on RCCL's stream, replays segment k + 1 meanwhile, ... (train.Trainer._replay_split).
+namespace {
+
+__global__ void graph_mark_kernel(int32_t* __restrict__ slot, int32_t index) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *slot = index;
+}
+
+struct GraphExecs {
+  std::vector<hipGraphExec_t> execs;
+  std::vector<hipGraph_t> graphs;
+};
+
+}  // namespace
+
+extern "C" hd_status hd_graph_mark(int32_t* slot, int index, hd_stream stream) {
+  if (!slot) return HD_ERR_NULL;
+  hipLaunchKernelGGL(graph_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot, (int32_t)index);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_graph_split_instantiate(void* hip_graph, const int32_t* slot, int max_segments, void** out_execs,
+                                                int* marker_index_out, int* n_segments_out, int* n_nodes_out) {
+  if (!hip_graph || !slot || !out_execs || !marker_index_out || !n_segments_out) return HD_ERR_NULL;
+  if (max_segments < 1) return HD_ERR_SHAPE;
+  hipGraph_t g = reinterpret_cast<hipGraph_t>(hip_graph);
+  size_t n = 0;
+  if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return HD_ERR_LAUNCH;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return HD_ERR_LAUNCH;
+  // predecessor lists
+  std::vector<std::vector<int>> pred(n);
+  auto index_of = [&](hipGraphNode_t x) -> int {
+    for (size_t i = 0; i < n; ++i)
+      if (nodes[i] == x) return (int)i;
+    return -1;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    size_t nd = 0;
+    if (hipGraphNodeGetDependencies(nodes[i], nullptr, &nd) != hipSuccess) return HD_ERR_LAUNCH;
+    std::vector<hipGraphNode_t> deps(nd);
+    if (nd && hipGraphNodeGetDependencies(nodes[i], deps.data(), &nd) != hipSuccess) return HD_ERR_LAUNCH;
+    for (size_t d = 0; d < nd; ++d) {
+      const int j = index_of(deps[d]);
+      if (j < 0) return HD_ERR_LAUNCH;
+      pred[i].push_back(j);
+    }
+  }
+  // markers: kernel nodes of graph_mark_kernel writing to `slot`
+  struct Marker { int node, index; };
+  std::vector<Marker> markers;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType type;
+    if (hipGraphNodeGetType(nodes[i], &type) != hipSuccess) return HD_ERR_LAUNCH;
+    if (type != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams kp;
+    if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) return HD_ERR_LAUNCH;
+    if (kp.func != reinterpret_cast<void*>(graph_mark_kernel) || !kp.kernelParams) continue;
+    if (*reinterpret_cast<int32_t**>(kp.kernelParams[0]) != slot) continue;
+    markers.push_back({(int)i, (int)*reinterpret_cast<int32_t*>(kp.kernelParams[1])});
+  }
+  const int K = (int)markers.size();
+  if (K + 1 > max_segments) return HD_ERR_SHAPE;
+  // ancestors of every marker; markers are ordered by ancestry (captured from one stream: a chain)
+  std::vector<std::vector<char>> anc(K, std::vector<char>(n, 0));
+  for (int k = 0; k < K; ++k) {
+    std::vector<int> stack{markers[k].node};
+    anc[k][markers[k].node] = 1;
+    while (!stack.empty()) {
+      const int u = stack.back();
+      stack.pop_back();
+      for (int p : pred[u])
+        if (!anc[k][p]) {
+          anc[k][p] = 1;
+          stack.push_back(p);
+        }
+    }
+  }
+  std::vector<int> order(K);
+  for (int k = 0; k < K; ++k) order[k] = k;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {  // a before b iff a is an ancestor of b
+    if (anc[b][markers[a].node]) return true;
+    if (anc[a][markers[b].node]) return false;
+    return markers[a].index < markers[b].index;
+  });
+  std::vector<int> seg(n, K);  // K = tail
+  for (int r = K - 1; r >= 0; --r)  // later markers first, earlier ones overwrite: seg = first marker that needs the node
+    for (size_t i = 0; i < n; ++i)
+      if (anc[order[r]][i]) seg[i] = r;
+  GraphExecs made;
+  int produced = 0;
+  for (int s = 0; s <= K; ++s) {
+    size_t count = 0;
+    for (size_t i = 0; i < n; ++i) count += seg[i] == s;
+    if (count == 0) {
+      if (s < K) return HD_ERR_LAUNCH;  // a marker segment holds at least its marker
+      break;                            // empty tail
+    }
+    hipGraph_t c = nullptr;
+    if (hipGraphClone(&c, g) != hipSuccess) return HD_ERR_LAUNCH;
+    made.graphs.push_back(c);
+    for (size_t i = 0; i < n; ++i) {
+      if (seg[i] == s) continue;
+      hipGraphNode_t cn = nullptr;
+      if (hipGraphNodeFindInClone(&cn, nodes[i], c) != hipSuccess) return HD_ERR_LAUNCH;
+      if (hipGraphDestroyNode(cn) != hipSuccess) return HD_ERR_LAUNCH;
+    }
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, c, nullptr, nullptr, 0) != hipSuccess) return HD_ERR_LAUNCH;
+    made.execs.push_back(ex);
+    out_execs[produced] = reinterpret_cast<void*>(ex);
+    if (s < K) marker_index_out[produced] = markers[order[s]].index;
+    ++produced;
+  }
+  *n_segments_out = produced;
+  if (n_nodes_out) *n_nodes_out = (int)n;
+  // the pruned clones must outlive their executables only until instantiation on this stack
+  for (hipGraph_t c : made.graphs) (void)hipGraphDestroy(c);
+  return HD_OK;
+}
+
+extern "C" hd_status hd_graph_exec_launch(void* exec, hd_stream stream) {
+  if (!exec) return HD_ERR_NULL;
+  return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), (hipStream_t)stream) == hipSuccess ? HD_OK : HD_ERR_LAUNCH;
+}
+
+extern "C" hd_status hd_graph_exec_destroy(void* exec) {
+  if (!exec) return HD_OK;
+  return hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec)) == hipSuccess ? HD_OK : HD_ERR_LAUNCH;
 }

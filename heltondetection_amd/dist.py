@@ -93,6 +93,11 @@ class GradReducer:
                 self._bucket_of[p] = b
         self._avg_native = self.world > 1 and dist.get_backend(process_group) == "nccl"
         self._next = 0  # index of the next bucket whose collective may be launched (strict bucket order)
+        # hipGraph capture with split replay (train.Trainer): `_hold` keeps every collective back while the step is
+        # being captured, `_mark` is the int32 slot the bucket markers are written to (ops.graph_mark)
+        self._hold = False
+        self._mark = None
+        self._index_of = {id(b): i for i, b in enumerate(self.buckets)}
         self._hooks = []
         for p in params:
             src = self._src.get(p)
@@ -136,13 +141,18 @@ class GradReducer:
                 src.grad = None
         b.pending = 0
         b.packed = True
+        if self._mark is not None:
+            # bucket boundary of the captured step: the split replay launches this bucket's all-reduce right after
+            # the segment that ends here (one-lane marker kernel; found again by hd_graph_split_instantiate)
+            from . import ops
+            ops.graph_mark(self._mark, self._index_of[id(b)])
 
     def _flush(self, force: bool = False):
         """Launches the all-reduce of every packed bucket whose predecessors have been launched, strictly in
         bucket-index order: gradient-readiness order can differ between ranks (a bucket left incomplete on one
         rank is packed last there), and collectives issued in different orders on different ranks hang or mix
         up buffers on RCCL.  Deferred mode (hipGraph replay) launches nothing until finish() forces it."""
-        if self.world <= 1 or (self.defer and not force):
+        if self.world <= 1 or self._hold or (self.defer and not force):
             return
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         while self._next < len(self.buckets) and self.buckets[self._next].packed:
@@ -162,6 +172,18 @@ class GradReducer:
                 src = self._src.get(p)
                 if src is not None:
                     src.grad = None
+
+    def begin_split_replay(self):
+        """Split hipGraph replay: the segments repack the buckets on the device; nothing is packed or launched yet."""
+        self._next = 0
+        for b in self.buckets:
+            b.packed = False
+            b.work = None
+
+    def bucket_replayed(self, index: int):
+        """The replayed segment that packs bucket `index` has been enqueued: its all-reduce may go (in bucket order)."""
+        self.buckets[index].packed = True
+        self._flush(force=True)
 
     def pack_incomplete(self):
         """Call right after backward (inside the captured region in hipGraph mode, so the packing copies of

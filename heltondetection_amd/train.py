@@ -55,8 +55,8 @@ class Trainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
-                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: bool = False,
-                 lowp_weights: bool = True, augment=None):
+                 use_graph: bool = False, graph_warmup: int = 3, graph_sync: Optional[bool] = None,
+                 lowp_weights: bool = True, augment=None, graph_split: bool = True):
         self.model = model
         # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head
         # of every step (e.g. augment.Mosaic).  It is part of the captured region in hipGraph mode, so it must
@@ -68,17 +68,31 @@ class Trainer:
         from .layers import FusedBNAct
         if FusedBNAct.sync_group is not None:  # SyncBN all-reduces inside the layer: not capturable
             self.use_graph = False
-        self.graph_sync = bool(graph_sync)
         # bf16 weight shadows only make sense where autocast would otherwise cast per call
         self.shadows = None
         if lowp_weights and amp_dtype is not None and self.device.type == "cuda":
             self.shadows = LowpShadows(model, amp_dtype)
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, defer_collectives=self.use_graph,
+        import torch.distributed as tdist
+        world = tdist.get_world_size() if tdist.is_initialized() else 1
+        # Multi-rank hipGraph mode = SPLIT replay: the captured step is cut at the gradient-bucket boundaries
+        # (ops.GraphSegments) and bucket k's all-reduce is launched right after segment k has been enqueued, so it runs
+        # on RCCL's stream while segment k + 1 (the rest of backward) replays: the overlap north_star asks for, kept
+        # under hipGraph replay.  graph_split=False (or one rank) replays one graph and launches the collectives
+        # behind it (`defer`).
+        self.graph_split = bool(graph_split) and self.use_graph and world > 1
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes,
+                                   defer_collectives=self.use_graph and not self.graph_split,
                                    grad_sources=self.shadows.grad_sources() if self.shadows else None)
-        # With more than one rank the stream is drained after each replay, before the collectives are
-        # launched: an event recorded right after hipGraphLaunch is what the collective's stream waits on,
-        # and on this stack that event is observed seconds late on alternate replays.
-        self.graph_sync = self.graph_sync or self.reducer.world > 1
+        # graph_sync: drain the stream after every replayed graph / segment before the collectives are launched.
+        # Needed only for the gloo REHEARSAL backend (several ranks time-slicing one GPU): gloo's worker thread
+        # blocks on a host-side stream synchronise for its D2H staging copy, and with two processes sharing the
+        # device that wait was observed to return seconds late on alternate replays (DESIGN.md section 9,
+        # tools/graph_event_probe.py).  RCCL has no host-side wait on this path (its stream waits on an event
+        # device-side), so the default is off for it.
+        if graph_sync is None:
+            graph_sync = self.reducer.world > 1 and tdist.get_backend(self.reducer.group) != "nccl"
+        self.graph_sync = bool(graph_sync)
+        self._segments = None
         decay, no_decay = [], []
         for n, p in model.named_parameters():
             if not p.requires_grad:
@@ -124,20 +138,55 @@ class Trainer:
         self._static = [t.clone() for t in batch]
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):  # private-pool warm-up as torch.cuda.graphs prescribes
-            self._fwd_bwd(*self._static)
+        hold = self.reducer._hold
+        self.reducer._hold = True  # the warm-up pass computes gradients nobody uses: no collectives for it
+        try:
+            with torch.cuda.stream(side):  # private-pool warm-up as torch.cuda.graphs prescribes
+                self._fwd_bwd(*self._static)
+        finally:
+            self.reducer._hold = hold
         torch.cuda.current_stream(self.device).wait_stream(side)
         g = torch.cuda.CUDAGraph(keep_graph=True)
+        if self.graph_split:
+            # no collective may be launched while capturing; every packed bucket leaves a marker in the graph
+            self.reducer._hold = True
+            self._mark_slot = torch.zeros(1, dtype=torch.int32, device=self.device)
         # thread_local: only this thread's calls are policed during capture (RCCL's watchdog thread
         # queries events concurrently in multi-GPU runs)
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            out = self._fwd_bwd(*self._static)
+        try:
+            if self.graph_split:
+                self.reducer._mark = self._mark_slot
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._fwd_bwd(*self._static)
+        finally:
+            self.reducer._mark = None
+            self.reducer._hold = False
         # MIOpen's conv-backward solvers zero their accumulators with hipMemsetAsync, which the capture
         # turned into memset nodes; rewrite those into fill-kernel nodes before instantiating
         from . import ops
         self.graph_nodes, self.graph_memsets_replaced = ops.graph_replace_memsets(g.raw_cuda_graph())
-        g.instantiate()
+        if self.graph_split:
+            # `g` is never instantiated as a whole: it stays alive as the owner of the capture's memory pool
+            self._segments = ops.GraphSegments(g.raw_cuda_graph(), self._mark_slot, len(self.reducer.buckets) + 1)
+            marked = sorted(self._segments.marker_of[: len(self.reducer.buckets)])
+            if marked != list(range(len(self.reducer.buckets))):
+                raise RuntimeError(f"split capture: bucket markers {marked} do not cover the {len(self.reducer.buckets)} buckets")
+        else:
+            g.instantiate()
         self._graph, self._static_out = g, out
+
+    def _replay_split(self):
+        """Segment k, then bucket k's all-reduce on RCCL's stream while segment k + 1 is already being enqueued."""
+        seg, red = self._segments, self.reducer
+        red.begin_split_replay()
+        stream = torch.cuda.current_stream(self.device)
+        n_marked = len(red.buckets)
+        for k in range(len(seg)):
+            seg.launch(k, self._mark_slot)
+            if k < n_marked:
+                if self.graph_sync:  # gloo rehearsal only, see __init__
+                    stream.synchronize()
+                red.bucket_replayed(seg.marker_of[k])
 
     def step(self, images, gt_boxes, gt_cls, m_valid):
         batch = (images, gt_boxes, gt_cls, m_valid)
@@ -159,16 +208,17 @@ class Trainer:
                 self.graph_error = err
                 self.use_graph = False
                 self.reducer.defer = False
-                self._graph = self._static = self._static_out = None
+                self._graph = self._static = self._static_out = self._segments = None
                 torch.cuda.synchronize(self.device)
         if self._graph is not None:
             for dst, src in zip(self._static, batch):
                 dst.copy_(src, non_blocking=True)
-            self._graph.replay()
-            if self.graph_sync:
-                # single rank: off (not needed once the memset nodes are rewritten; 1500-step soak clean).
-                # multi rank: on, see __init__.
-                torch.cuda.current_stream(self.device).synchronize()
+            if self._segments is not None:
+                self._replay_split()
+            else:
+                self._graph.replay()
+                if self.graph_sync:  # gloo rehearsal only, see __init__
+                    torch.cuda.current_stream(self.device).synchronize()
             loss, parts = self._static_out
         else:
             loss, parts = self._fwd_bwd(*batch)

@@ -414,6 +414,22 @@ hd_status hd_mosaic4_boxes(const float* gt_boxes, const int32_t* gt_cls, const i
  * (DESIGN.md section 9).  n_nodes_out / n_replaced_out (host, may be NULL) receive the counts. */
 hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out, int* n_replaced_out);
 
+/* Multi-GPU overlap under hipGraph replay (reference README.md:29 DDP; north_star "all-reduce overlapped with the
+ * backward pass").  hd_graph_mark: a one-lane kernel that stores `index` into *slot — launched inside a stream
+ * capture right after gradient bucket `index` was packed, it marks that point of the captured graph.
+ * hd_graph_split_instantiate: cuts a captured, NOT instantiated hipGraph_t into segments that end at its markers
+ * (segment k = the nodes marker k depends on that no earlier marker needs; then the tail) and instantiates each
+ * (host call).  out_execs [max_segments] receives the hipGraphExec_t handles in replay order, marker_index_out[k] the
+ * index stored by the marker that closes segment k (only for the marker segments), n_segments_out their number
+ * (markers + 1, or markers when nothing follows the last one).  The original graph must stay alive (it owns the
+ * kernel parameters' memory pool on the framework side); launch the segments in order on one stream with
+ * hd_graph_exec_launch and destroy them with hd_graph_exec_destroy. */
+hd_status hd_graph_mark(int32_t* slot, int index, hd_stream stream);
+hd_status hd_graph_split_instantiate(void* hip_graph, const int32_t* slot, int max_segments, void** out_execs,
+                                     int* marker_index_out, int* n_segments_out, int* n_nodes_out);
+hd_status hd_graph_exec_launch(void* exec, hd_stream stream);
+hd_status hd_graph_exec_destroy(void* exec);
+
 #ifdef __cplusplus
 }
 #endif
