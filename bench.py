@@ -64,6 +64,9 @@ def parse():
                     help="run forward+backward eagerly instead of replaying a hipGraph (the graph has its memset "
                          "nodes rewritten into kernel nodes, DESIGN.md section 9, and is guarded: a non-finite or "
                          "eager-mismatching loss makes bench.py re-time eagerly)")
+    ap.add_argument("--graph-sync", choices=("auto", "on", "off"), default="auto",
+                    help="drain the stream after each replayed graph segment before its collective (auto: only for the gloo "
+                         "rehearsal backend, see train.Trainer)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="skip MIOpen's per-shape solver search (faster first step, ~20%% slower steady state)")
     args = ap.parse_args()
@@ -488,7 +491,8 @@ def main():
     lr = 1e-3 if args.model == "yolov5" else 2e-4
     trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
                       total_steps=args.steps + args.warmup + 8, warmup_steps=3, device=device,
-                      use_graph=not args.no_graph, graph_warmup=graph_warmup)
+                      use_graph=not args.no_graph, graph_warmup=graph_warmup,
+                      graph_sync={"auto": None, "on": True, "off": False}[args.graph_sync])
     batches = make_batches(4 if args.model == "yolov5" else 2, args.batch, args.size, args.classes, 1234 + rank, device)
 
     log(f"{model_name(args)} + data ready on {torch.cuda.get_device_name(device)}; warm-up {args.warmup} steps "

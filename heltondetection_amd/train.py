@@ -79,7 +79,8 @@ class Trainer:
         # on RCCL's stream while segment k + 1 (the rest of backward) replays: the overlap north_star asks for, kept
         # under hipGraph replay.  graph_split=False (or one rank) replays one graph and launches the collectives
         # behind it (`defer`).
-        self.graph_split = bool(graph_split) and self.use_graph and world > 1
+        # graph_split="force": split replay even on one rank (no collectives then; tests compare it with the one-graph replay)
+        self.graph_split = bool(graph_split) and self.use_graph and (world > 1 or graph_split == "force")
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes,
                                    defer_collectives=self.use_graph and not self.graph_split,
                                    grad_sources=self.shadows.grad_sources() if self.shadows else None)

@@ -39,7 +39,10 @@ def _worker(rank, world, port, tmp, use_graph):
     model = build_detector(dict(type="YOLOv5", variant="n", num_classes=8, img_size=128)).to(dev)
     model = model.to(memory_format=torch.channels_last).train()
     # 256 KiB buckets: the 1.8 M parameters of the `n` model spread over many buckets -> many segments
-    tr = Trainer(model, lr=1e-3, amp_dtype=None, total_steps=40, warmup_steps=2, bucket_bytes=1 << 20, device=dev,
+    # lr = 1e-7: AdamW moves every weight by ~lr per step whatever the gradient's size, so after 8 steps the two runs
+    # still sit at (numerically) the same point and their REDUCED GRADIENTS can be compared sharply; with a real
+    # learning rate Adam amplifies last-bit differences of near-zero gradients into sign flips of the update
+    tr = Trainer(model, lr=1e-7, amp_dtype=None, total_steps=40, warmup_steps=2, bucket_bytes=1 << 20, device=dev,
                  use_graph=use_graph, graph_warmup=2)
     assert len(tr.reducer.buckets) >= 3
     launches = []
@@ -74,7 +77,8 @@ def _worker(rank, world, port, tmp, use_graph):
             assert got == want, "split replay must launch the collectives in bucket order"
     info = {"graph": tr._graph is not None, "segments": None if tr._segments is None else len(tr._segments),
             "buckets": len(tr.reducer.buckets), "graph_error": tr.graph_error, "losses": losses, "times": times,
-            "graph_sync": tr.graph_sync, "params": [p.detach().float().cpu() for p in model.parameters()]}
+            "graph_sync": tr.graph_sync, "params": [p.detach().float().cpu() for p in model.parameters()],
+            "grads": [p.grad.detach().float().cpu().clone() for p in model.parameters()]}
     torch.save(info, os.path.join(tmp, f"{'g' if use_graph else 'e'}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -95,8 +99,13 @@ def test_two_rank_split_graph_replay_matches_eager(gpu, tmp_path):
         assert torch.equal(a, b)             # both ranks hold identical parameters after the split-replayed steps
     for a, b in zip(e0["params"], e1["params"]):
         assert torch.equal(a, b)
-    worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-6)) for a, b in zip(g0["params"], e0["params"]))
-    assert worst < 5e-3, worst               # fp32 step, float atomics reorder sums: not bit-equal, but the same training
-    assert all(abs(x - y) < 2e-2 * max(abs(y), 1.0) for x, y in zip(g0["losses"], e0["losses"]))
+    for a, b in zip(g0["grads"], g1["grads"]):
+        assert torch.equal(a, b)             # ... and the same averaged gradients
+    # split replay == eager hook-launched DDP: the averaged gradients of the last step (fp32 step; float atomics
+    # reorder sums, so not bit-equal)
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["grads"], e0["grads"]))
+    den = sum(float((b ** 2).sum()) for b in e0["grads"])
+    assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+    assert all(abs(x - y) < 1e-3 * max(abs(y), 1.0) for x, y in zip(g0["losses"], e0["losses"]))
     # no multi-second stall on any replayed step (second hazard)
     assert max(g0["times"][3:]) < 2.0 and max(g1["times"][3:]) < 2.0, (g0["times"], g1["times"])

@@ -4,8 +4,12 @@ GPU.  No torch.distributed here: each process replays a ~5 ms graph, records an 
 run one kernel, and then either the HOST waits for the side stream (what gloo's worker thread does before its D2H
 staging copy) or the main stream waits on it (what RCCL's stream hand-back does).
 
-    python tools/graph_event_probe.py single host|device [iters]
-    python tools/graph_event_probe.py pair   host|device [iters]     (two concurrent processes on GPU 0)
+    python tools/graph_event_probe.py single host|device|d2h [iters]
+    python tools/graph_event_probe.py pair   host|device|d2h [iters]     (two concurrent processes on GPU 0)
+
+d2h = gloo's CUDA all-reduce in miniature: the side stream waits on the event, copies 8 MB device -> PINNED host memory,
+a WORKER THREAD synchronises the side stream, "reduces" on the CPU, copies back host -> device on the side stream, and
+the main thread joins the worker before it lets the main stream continue (Work.wait()).
 """
 import os, subprocess, sys, time
 import torch
@@ -37,6 +41,9 @@ def worker(mode, iters, tag):
         out = body()
     side = torch.cuda.Stream(dev)
     z = torch.zeros((1 << 20,), device=dev)
+    big = torch.randn((1 << 21,), device=dev)          # 8 MB "gradient bucket"
+    pinned = torch.empty((1 << 21,), pin_memory=True)
+    import threading
     torch.cuda.synchronize()
     t_replay = time.perf_counter()
     g.replay(); torch.cuda.synchronize()
@@ -52,6 +59,20 @@ def worker(mode, iters, tag):
             z.add_(1.0)
         if mode == "host":
             side.synchronize()               # host thread blocks on the side stream
+        elif mode == "d2h":
+            with torch.cuda.stream(side):
+                pinned.copy_(big, non_blocking=True)
+
+            def work():
+                torch.cuda.set_device(dev)
+                side.synchronize()
+                pinned.mul_(0.5)
+                with torch.cuda.stream(side):
+                    big.copy_(pinned, non_blocking=True)
+                side.synchronize()
+            th = threading.Thread(target=work)
+            th.start()
+            th.join()
         else:
             torch.cuda.current_stream(dev).wait_stream(side)
         x.mul_(1.0)                           # the "optimizer" behind it on the main stream
