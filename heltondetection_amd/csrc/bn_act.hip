@@ -162,6 +162,23 @@ __device__ __forceinline__ float rep_sum(const float* __restrict__ p, int idx, i
   return v;
 }
 
+// Address of vector i of dy (or, for the forward kernels, of y).  dy may be a channel slice of a wider channels-last tensor (the gradient of
+// a torch.cat input: rows of C channels, row stride ld > C), which saves the .contiguous() copy autograd
+// would otherwise need in front of every such BatchNorm; ld == C is the dense case (no division).
+template <typename T>
+__device__ __forceinline__ const T* dy_at(const T* dy, long long i, int cg, int C, long long ld) {
+  constexpr int V = RowVec<T>::N;
+  if (ld == C) return dy + i * V;
+  const uint32_t r = (uint32_t)i / (uint32_t)cg;
+  const uint32_t g = (uint32_t)i - r * (uint32_t)cg;
+  return dy + (long long)r * ld + (long long)g * V;
+}
+
+template <typename T>
+__device__ __forceinline__ T* y_at(T* y, long long i, int cg, int C, long long ld) {
+  return const_cast<T*>(dy_at(const_cast<const T*>(y), i, cg, C, ld));
+}
+
 // ---- forward apply ------------------------------------------------------------------------------
 // RES: 0 no residual; 1 y = act(bn(x) + r) (ResNet bottleneck tail); 2 y = act(bn(x)) + r (YOLO bottleneck)
 template <typename T, int ACT, int RES>
@@ -172,7 +189,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta, float eps, float momentum,
                                                        float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_invstd, T* __restrict__ y) {
+                                                       float* __restrict__ save_invstd, T* __restrict__ y, long long ld_y) {
+  // ld_y: elements between consecutive rows of y; C = dense, > C = y is a channel slice of a wider channels-last
+  // tensor (the input slot of a following concatenation: the activation is written where torch.cat would copy it)
   constexpr int V = RowVec<T>::N;
   extern __shared__ float s_coef[];  // [2*C]: a_c, b_c — computed once per workgroup from the replicas
   const int cg = C / V;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
         for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
-        RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+        RowVec<T>::store(y_at(y, i + u * stride, cg, C, ld_y), v[u]);
       }
     } else {
       float rv[4][V];
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
           const float z = fmaf(a[k], v[u][k], b[k]);
           v[u][k] = RES == 1 ? act_fwd<ACT>(z + rv[u][k]) : act_fwd<ACT>(z) + rv[u][k];
         }
-        RowVec<T>::store(y + (i + u * stride) * V, v[u]);
+        RowVec<T>::store(y_at(y, i + u * stride, cg, C, ld_y), v[u]);
       }
     }
   }
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       const float z = fmaf(a[k], v[k], b[k]);
       v[k] = RES == 0 ? act_fwd<ACT>(z) : (RES == 1 ? act_fwd<ACT>(z + rv[k]) : act_fwd<ACT>(z) + rv[k]);
     }
-    RowVec<T>::store(y + i * V, v);
+    RowVec<T>::store(y_at(y, i, cg, C, ld_y), v);
   }
 }
 
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ running_mean,
                                                        const float* __restrict__ running_var, float eps,
-                                                       T* __restrict__ y) {
+                                                       T* __restrict__ y, long long ld_y) {
   constexpr int V = RowVec<T>::N;
   const int cg = C / V;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -267,20 +286,8 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
     RowVec<T>::load(x + i * V, v);
 #pragma unroll
     for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(fmaf(a[k], v[k], b[k]));
-    RowVec<T>::store(y + i * V, v);
+    RowVec<T>::store(y_at(y, i, cg, C, ld_y), v);
   }
-}
-
-// Address of vector i of dy.  dy may be a channel slice of a wider channels-last tensor (the gradient of
-// a torch.cat input: rows of C channels, row stride ld > C), which saves the .contiguous() copy autograd
-// would otherwise need in front of every such BatchNorm; ld == C is the dense case (no division).
-template <typename T>
-__device__ __forceinline__ const T* dy_at(const T* dy, long long i, int cg, int C, long long ld) {
-  constexpr int V = RowVec<T>::N;
-  if (ld == C) return dy + i * V;
-  const uint32_t r = (uint32_t)i / (uint32_t)cg;
-  const uint32_t g = (uint32_t)i - r * (uint32_t)cg;
-  return dy + (long long)r * ld + (long long)g * V;
 }
 
 // ---- backward reductions ------------------------------------------------------------------------
@@ -480,6 +487,14 @@ inline hd_status common_checks(int dtype, long long R, int C) {
 
 }  // namespace
 
+// dy_row_stride: elements between consecutive rows of dy (0 or C = dense; > C = channel slice of a wider tensor)
+static hd_status check_dy_stride(int64_t dy_row_stride, int C, int V, long long nvec, int64_t* ld) {
+  *ld = dy_row_stride == 0 ? C : dy_row_stride;
+  if (*ld < C || *ld % V != 0) return HD_ERR_SHAPE;
+  if (*ld != C && nvec >= (1ll << 31)) return HD_ERR_SHAPE;  // the strided path indexes with 32-bit row numbers
+  return HD_OK;
+}
+
 extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C, float* sums, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
@@ -504,7 +519,8 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
 extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows, int C, const float* sums,
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                                     int act, const void* res, int res_mode, void* y, hd_stream stream) {
+                                     int act, const void* res, int res_mode, void* y, int64_t y_row_stride,
+                                     hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !sums || !gamma || !beta || !save_mean || !save_invstd || !y) return HD_ERR_NULL;
@@ -516,6 +532,9 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
+  int64_t ld_y = 0;
+  st = check_dy_stride(y_row_stride, C, V, nvec, &ld_y);  // same rules as a strided dy: >= C, multiple of the vector
+  if (st != HD_OK) return st;
   const int64_t RS = stat_rows > 0 ? stat_rows : R;
   const float inv_R = 1.0f / (float)RS;
   const float unbias = RS > 1 ? (float)RS / (float)(RS - 1) : 1.0f;
@@ -524,7 +543,7 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
   (void)hd_launch(bn_apply_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
                      reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(res), nvec, C, inv_R, unbias,    \
                      sums, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,         \
-                     reinterpret_cast<XT*>(y))
+                     reinterpret_cast<XT*>(y), (long long)ld_y)
 #define HD_APPLY(T, A, XT)                     \
   do {                                         \
     if (res_mode == 0) HD_APPLY_R(T, A, 0, XT); \
@@ -541,30 +560,25 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
 
 extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                                      const float* beta, const float* running_mean, const float* running_var,
-                                     float eps, int act, void* y, hd_stream stream) {
+                                     float eps, int act, void* y, int64_t y_row_stride, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !gamma || !beta || !running_mean || !running_var || !y) return HD_ERR_NULL;
   if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
+  int64_t ld_y = 0;
+  st = check_dy_stride(y_row_stride, C, V, nvec, &ld_y);
+  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   hipStream_t s = (hipStream_t)stream;
 #define HD_INFER(T, A, XT)                                                                                         \
   (void)hd_launch(bn_infer_kernel<XT, A>, dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), \
-                     nvec, C, gamma, beta, running_mean, running_var, eps, reinterpret_cast<XT*>(y))
+                     nvec, C, gamma, beta, running_mean, running_var, eps, reinterpret_cast<XT*>(y), (long long)ld_y)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_INFER, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_INFER, __hip_bfloat16);
 #undef HD_INFER
   HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
-}
-
-// dy_row_stride: elements between consecutive rows of dy (0 or C = dense; > C = channel slice of a wider tensor)
-static hd_status check_dy_stride(int64_t dy_row_stride, int C, int V, long long nvec, int64_t* ld) {
-  *ld = dy_row_stride == 0 ? C : dy_row_stride;
-  if (*ld < C || *ld % V != 0) return HD_ERR_SHAPE;
-  if (*ld != C && nvec >= (1ll << 31)) return HD_ERR_SHAPE;  // the strided path indexes with 32-bit row numbers
   return HD_OK;
 }
 

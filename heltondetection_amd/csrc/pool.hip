@@ -54,8 +54,11 @@ struct Vec<__hip_bfloat16> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__ in, int B, int H, int W, int C,
-                                                           T* __restrict__ out, uint8_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__ in, long long ld_in, int B, int H, int W,
+                                                           int C, T* __restrict__ out, long long ld_out,
+                                                           uint8_t* __restrict__ idx) {
+  // ld_in / ld_out: elements between consecutive pixels of in / out (C = dense; > C = a channel slice of a wider
+  // channels-last tensor, e.g. a slot of SPPF's concatenation buffer); idx is always dense
   constexpr int V = Vec<T>::N;
   const int cv = C / V;
   const uint32_t total = (uint32_t)B * H * W * cv;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__
         const int xx = x + tx - 2;
         if (xx < 0 || xx >= W) continue;
         float v[V];
-        Vec<T>::load(in + (((size_t)b * H + yy) * W + xx) * C + c0, v);
+        Vec<T>::load(in + (((size_t)b * H + yy) * W + xx) * ld_in + c0, v);
 #pragma unroll
         for (int k = 0; k < V; ++k)
           if (v[k] > best[k] || v[k] != v[k]) {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__
       }
     }
     const size_t o = (((size_t)b * H + y) * W + x) * C + c0;
-    Vec<T>::store(out + o, best);
+    Vec<T>::store(out + (((size_t)b * H + y) * W + x) * ld_out + c0, best);
     if (V == 8) {
       *reinterpret_cast<uint2*>(idx + o) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
                                                       bi[4 % V] | (bi[5 % V] << 8) | (bi[6 % V] << 16) | (bi[7 % V] << 24));
@@ -101,8 +104,9 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx,
-                                                           int B, int H, int W, int C, T* __restrict__ gin) {
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__ gout, long long ld_gout,
+                                                           const uint8_t* __restrict__ idx, int B, int H, int W, int C,
+                                                           T* __restrict__ gin) {
   constexpr int V = Vec<T>::N;
   const int cv = C / V;
   const uint32_t total = (uint32_t)B * H * W * cv;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__
         for (int k = 0; k < V; ++k) any |= (taps[k] == want);
         if (!any) continue;
         float g[V];
-        Vec<T>::load(gout + q, g);
+        Vec<T>::load(gout + (((size_t)b * H + qy) * W + qx) * ld_gout + c0, g);
 #pragma unroll
         for (int k = 0; k < V; ++k)
           if (taps[k] == want) acc[k] += g[k];
@@ -171,34 +175,47 @@ inline hd_status pool_checks(const void* a, const void* b, const void* c, int dt
 
 }  // namespace
 
-extern "C" hd_status hd_maxpool5_fwd(const void* in, int dtype, int B, int H, int W, int C, void* out, uint8_t* idx,
-                                     hd_stream stream) {
+static hd_status pool_stride(int64_t given, int C, int V, int64_t* ld) {
+  *ld = given == 0 ? C : given;
+  return (*ld < C || *ld % V != 0) ? HD_ERR_SHAPE : HD_OK;
+}
+
+extern "C" hd_status hd_maxpool5_fwd(const void* in, int64_t in_row_stride, int dtype, int B, int H, int W, int C,
+                                     void* out, int64_t out_row_stride, uint8_t* idx, hd_stream stream) {
   hd_status st = pool_checks(in, out, idx, dtype, B, H, W, C);
   if (st != HD_OK) return st;
+  int64_t ld_in = 0, ld_out = 0;
+  if (pool_stride(in_row_stride, C, dtype == 0 ? 4 : 8, &ld_in) != HD_OK ||
+      pool_stride(out_row_stride, C, dtype == 0 ? 4 : 8, &ld_out) != HD_OK)
+    return HD_ERR_SHAPE;
   const long long items = (long long)B * H * W * (C / (dtype == 0 ? 4 : 8));
   if (dtype == 0)
     hipLaunchKernelGGL((maxpool5_fwd_kernel<float>), dim3(pool_grid(items)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float*>(in), B, H, W, C, reinterpret_cast<float*>(out), idx);
+                       reinterpret_cast<const float*>(in), (long long)ld_in, B, H, W, C, reinterpret_cast<float*>(out),
+                       (long long)ld_out, idx);
   else
     hipLaunchKernelGGL((maxpool5_fwd_kernel<__hip_bfloat16>), dim3(pool_grid(items)), dim3(256), 0,
-                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(in), B, H, W, C,
-                       reinterpret_cast<__hip_bfloat16*>(out), idx);
+                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(in), (long long)ld_in, B, H, W, C,
+                       reinterpret_cast<__hip_bfloat16*>(out), (long long)ld_out, idx);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
-extern "C" hd_status hd_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int B, int H, int W, int C,
-                                     void* grad_in, hd_stream stream) {
+extern "C" hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, const uint8_t* idx, int dtype,
+                                     int B, int H, int W, int C, void* grad_in, hd_stream stream) {
   hd_status st = pool_checks(grad_out, grad_in, idx, dtype, B, H, W, C);
   if (st != HD_OK) return st;
+  int64_t ld_g = 0;
+  if (pool_stride(grad_out_row_stride, C, dtype == 0 ? 4 : 8, &ld_g) != HD_OK) return HD_ERR_SHAPE;
   const long long items = (long long)B * H * W * (C / (dtype == 0 ? 4 : 8));
   if (dtype == 0)
     hipLaunchKernelGGL((maxpool5_bwd_kernel<float>), dim3(pool_grid(items)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float*>(grad_out), idx, B, H, W, C, reinterpret_cast<float*>(grad_in));
+                       reinterpret_cast<const float*>(grad_out), (long long)ld_g, idx, B, H, W, C,
+                       reinterpret_cast<float*>(grad_in));
   else
     hipLaunchKernelGGL((maxpool5_bwd_kernel<__hip_bfloat16>), dim3(pool_grid(items)), dim3(256), 0,
-                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(grad_out), idx, B, H, W, C,
-                       reinterpret_cast<__hip_bfloat16*>(grad_in));
+                       (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(grad_out), (long long)ld_g, idx, B, H, W,
+                       C, reinterpret_cast<__hip_bfloat16*>(grad_in));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

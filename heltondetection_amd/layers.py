@@ -40,6 +40,7 @@ class FusedBNAct:
     plain torch modules.  One statistics slot per BatchNorm2d module is kept in `_slots`."""
 
     enabled = True
+    cat_in_place = True  # producers of a concatenation write into its buffer (ops.CatBuffer) instead of torch.cat copying
     # SyncBN (SURVEY.md §8e, optional second exchange): set to a torch.distributed process group and every fused
     # BatchNorm takes its batch statistics over the shards of all ranks in the group.  Eager mode only: the
     # all-reduce sits between two kernels of the layer, so such a step is not captured into a hipGraph.
@@ -47,9 +48,11 @@ class FusedBNAct:
     _ACTS = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}
 
     @staticmethod
-    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False):
+    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False, out=None):
         """residual: added inside the fused kernel, before (`act(bn(x) + r)`) or after (`act(bn(x)) + r`) the
-        activation; the unfused fallback computes the same expression with torch ops."""
+        activation; the unfused fallback computes the same expression with torch ops.
+        out: a CatBuffer slot — the fused kernel writes its result there (the caller's CatBuffer.join then has nothing
+        to copy); the unfused fallback ignores it and returns an ordinary tensor (join copies it in, like torch.cat)."""
         # momentum=None (cumulative moving average) needs the step counter: that case stays on torch's BatchNorm
         if FusedBNAct.enabled and x.is_cuda and bn.momentum is not None:
             from . import ops
@@ -60,12 +63,36 @@ class FusedBNAct:
                     bn._hd_slot = slot
                 training = bn.training or bn.running_mean is None
                 return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, training, slot,
-                                  FusedBNAct.sync_group if training else None, residual, residual_after_act)
+                                  FusedBNAct.sync_group if training else None, residual, residual_after_act, out)
         if residual is None:
             return FusedBNAct._ACTS[act](bn(x))
         if residual_after_act:
             return FusedBNAct._ACTS[act](bn(x)) + residual
         return FusedBNAct._ACTS[act](bn(x) + residual)
+
+
+def cat_buffer(like: torch.Tensor, channels, hw=None):
+    """An ops.CatBuffer for a channel concatenation whose parts come out of fused BN+act kernels, or None when the
+    fused HIP path is not in play (CPU tensors, fusion switched off, layouts the kernels do not take): callers then
+    fall back to torch.cat.  `like` supplies batch size, dtype (autocast's under autocast) and device."""
+    if not (ConvBNAct.fused and FusedBNAct.enabled and like.is_cuda and FusedBNAct.cat_in_place):
+        return None
+    dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else like.dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        return None
+    vec = 4 if dtype == torch.float32 else 8
+    if any(int(c) % vec for c in channels) or any(int(c) // vec > 256 for c in channels):
+        return None
+    from . import ops
+    H, W = hw if hw is not None else like.shape[2:]
+    return ops.CatBuffer(_Like(like.shape[0], int(H), int(W), dtype, like.device), channels)
+
+
+class _Like:
+    """Shape / dtype / device carrier for ops.CatBuffer (which only reads .shape, .dtype, .device)."""
+
+    def __init__(self, B, H, W, dtype, device):
+        self.shape, self.dtype, self.device = (B, 0, H, W), dtype, device
 
 
 class ConvBNAct(nn.Module):
@@ -80,11 +107,12 @@ class ConvBNAct(nn.Module):
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act
 
-    def forward(self, x, residual=None):
-        """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut)."""
+    def forward(self, x, residual=None, out=None):
+        """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut).
+        out: a CatBuffer slot for the result (see FusedBNAct.apply)."""
         y = self.conv(x)
         if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
-            return FusedBNAct.apply(self.bn, y, self.act_name, residual, True)
+            return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out)
         y = self.act(self.bn(y))
         return y if residual is None else y + residual
 
@@ -97,9 +125,9 @@ class Bottleneck(nn.Module):
         self.cv2 = ConvBNAct(c_, c2, 3, 1)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         # the shortcut add rides in the second conv's fused BN+activation kernel
-        return self.cv2(self.cv1(x), x if self.add else None)
+        return self.cv2(self.cv1(x), x if self.add else None, out)
 
 
 class C3(nn.Module):
@@ -114,7 +142,14 @@ class C3(nn.Module):
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, e=1.0) for _ in range(n)))
 
     def forward(self, x):
-        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+        cb = cat_buffer(x, (self.cv1.conv.out_channels, self.cv2.conv.out_channels), x.shape[2:])
+        if cb is None:
+            return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+        # both branches end in a fused BN+act kernel: each writes straight into its half of the concatenation
+        y = self.cv1(x)
+        for k, blk in enumerate(self.m):
+            y = blk(y, cb.slot(0) if k == len(self.m) - 1 else None)
+        return self.cv3(cb.join((y, self.cv2(x, None, cb.slot(1)))))
 
 
 class C2f(nn.Module):
@@ -142,10 +177,23 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
     def forward(self, x):
+        c_ = self.cv1.conv.out_channels
+        cb = cat_buffer(x, (c_, c_, c_, c_), x.shape[2:]) if self.m.kernel_size == 5 else None
+        if cb is not None:
+            from . import ops  # HIP SPPF pool (arg-max tap forward, gather backward); see csrc/pool.hip
+            # cv1's activation and the three pools are written straight into their quarter of the concatenation
+            x = self.cv1(x, None, cb.slot(0))
+            if ops.maxpool5_supported(x):
+                y1 = ops.maxpool5(x, cb.slot(1))
+                y2 = ops.maxpool5(y1, cb.slot(2))
+                return self.cv2(cb.join((x, y1, y2, ops.maxpool5(y2, cb.slot(3)))))
+            y1 = self.m(x)
+            y2 = self.m(y1)
+            return self.cv2(cb.join((x, y1, y2, self.m(y2))))
         x = self.cv1(x)
         pool = self.m
         if self.m.kernel_size == 5 and x.is_cuda:
-            from . import ops  # HIP SPPF pool (arg-max tap forward, gather backward); see csrc/pool.hip
+            from . import ops
             if ops.maxpool5_supported(x):
                 pool = ops.maxpool5
         y1 = pool(x)

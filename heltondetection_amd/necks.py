@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import C2f, C3, ConvBNAct, ShadowConv2d, make_drop_block
+from .layers import C2f, C3, ConvBNAct, ShadowConv2d, cat_buffer, make_drop_block
 from .registry import NECKS
 
 
@@ -31,14 +31,23 @@ class YOLOv5PAFPN(nn.Module):
         self.bu5 = C3(2 * c4, c5, n, shortcut=False)
         self.out_channels = (c3, c4, c5)
 
+    @staticmethod
+    def _down_cat(down: ConvBNAct, x: torch.Tensor, lateral: torch.Tensor) -> torch.Tensor:
+        """cat(down(x), lateral): the strided conv's fused BN+act writes its half of the concatenation in place; the
+        lateral (which has other consumers) is copied in, as torch.cat would."""
+        cb = cat_buffer(x, (down.conv.out_channels, lateral.shape[1]), lateral.shape[2:])
+        if cb is None:
+            return torch.cat((down(x), lateral), 1)
+        return cb.join((down(x, None, cb.slot(0)), lateral))
+
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         p3, p4, p5 = feats
         l5 = self.lat5(p5)
         t4 = self.td4(torch.cat((F.interpolate(l5, scale_factor=2.0, mode="nearest"), p4), 1))
         l4 = self.lat4(t4)
         o3 = self.td3(torch.cat((F.interpolate(l4, scale_factor=2.0, mode="nearest"), p3), 1))
-        o4 = self.bu4(torch.cat((self.down3(o3), l4), 1))
-        o5 = self.bu5(torch.cat((self.down4(o4), l5), 1))
+        o4 = self.bu4(self._down_cat(self.down3, o3, l4))
+        o5 = self.bu5(self._down_cat(self.down4, o4, l5))
         return [self.drop(o3), self.drop(o4), self.drop(o5)]
 
 

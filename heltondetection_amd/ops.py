@@ -640,15 +640,87 @@ def wbf(boxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, model_w
 
 
 # ------------------------------------------------------------------------------- SPPF max-pool
+class _OutSlot:
+    """Non-tensor wrapper (so autograd ignores it) around the tensor a custom Function writes its result into."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+class CatBuffer:
+    """Destination of a channel concatenation whose inputs are written IN PLACE by the kernels that produce them
+    (fused BN+act, SPPF max-pool) instead of being copied there by torch.cat.
+
+        buf = ops.CatBuffer(like, [c0, c1, ...])      # one channels-last allocation [B, sum(c), H, W]
+        y0 = bn_act(..., out=buf.slot(0)); y1 = ...   # producers take the slot as `out`
+        z = buf.join([y0, y1, ...])                   # parts already in their slot cost nothing; others are copied in
+
+    slot(i) and join() hand out FRESH tensor objects over the buffer's storage (Tensor.set_ on the storage — not
+    views), so autograd sees ordinary independent tensors and no view / version-counter bookkeeping is involved; the
+    gradient of join() is the channel slices of the incoming gradient (views; the BN backward kernels read a strided
+    dy in place)."""
+
+    def __init__(self, like: torch.Tensor, channels: Sequence[int]):
+        B, _, H, W = like.shape
+        self.channels = [int(c) for c in channels]
+        self.offsets = [0]
+        for c in self.channels:
+            self.offsets.append(self.offsets[-1] + c)
+        self.buf = torch.empty((B, self.offsets[-1], H, W), dtype=like.dtype, device=like.device,
+                               memory_format=torch.channels_last)
+
+    def _alias(self, off: int, c: int) -> torch.Tensor:
+        b = self.buf
+        B, _, H, W = b.shape
+        t = torch.empty(0, dtype=b.dtype, device=b.device)
+        t.set_(b.untyped_storage(), b.storage_offset() + off, (B, c, H, W), b.stride())
+        return t
+
+    def slot(self, i: int) -> torch.Tensor:
+        return self._alias(self.offsets[i], self.channels[i])
+
+    def in_place(self, i: int, t: torch.Tensor) -> bool:
+        return (t.data_ptr() == self.buf.data_ptr() + self.offsets[i] * self.buf.element_size()
+                and t.shape[1] == self.channels[i] and t.stride() == self.buf.stride() and t.dtype == self.buf.dtype)
+
+    def join(self, parts: Sequence[torch.Tensor]) -> torch.Tensor:
+        if len(parts) != len(self.channels):
+            raise _lib.HdError("CatBuffer.join: one tensor per slot")
+        return _CatJoinFn.apply(self, *parts)
+
+
+class _CatJoinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cb: "CatBuffer", *parts):
+        for i, p in enumerate(parts):
+            if not cb.in_place(i, p):
+                cb.slot(i).copy_(p)  # a producer that could not write in place (or a foreign tensor): torch.cat's copy
+        ctx.offsets = cb.offsets
+        return cb._alias(0, cb.offsets[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        o = ctx.offsets
+        return (None,) + tuple(g[:, o[i]:o[i + 1]] for i in range(len(o) - 1))
+
+
 class _MaxPool5Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out_slot):
         lib = _lib.load()
         B, Cc, H, W = x.shape
         dt = {torch.float32: 0, torch.bfloat16: 1}[x.dtype]
-        out = torch.empty_like(x)  # keeps channels-last strides
+        vec = 4 if dt == 0 else 8
+        ld_in = _cl_row_stride(x, vec)
+        out = out_slot.t if out_slot is not None else torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device,
+                                                                  memory_format=torch.channels_last)
+        ld_out = _cl_row_stride(out, vec)
+        if ld_in is None or ld_out is None:
+            raise _lib.HdError("maxpool5: input / output must be (channel slices of) channels-last tensors")
         idx = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
-        check(lib.hd_maxpool5_fwd(_ptr(x), dt, B, H, W, Cc, _ptr(out), _ptr(idx), _stream(x)), "hd_maxpool5_fwd")
+        check(lib.hd_maxpool5_fwd(_ptr(x), int(ld_in), dt, B, H, W, Cc, _ptr(out), int(ld_out), _ptr(idx), _stream(x)),
+              "hd_maxpool5_fwd")
         ctx.save_for_backward(idx)
         ctx.meta = (dt, B, H, W, Cc)
         return out
@@ -658,24 +730,30 @@ class _MaxPool5Fn(torch.autograd.Function):
         lib = _lib.load()
         (idx,) = ctx.saved_tensors
         dt, B, H, W, Cc = ctx.meta
-        g = g.contiguous(memory_format=torch.channels_last)
-        gin = torch.empty_like(g)
-        check(lib.hd_maxpool5_bwd(_ptr(g), _ptr(idx), dt, B, H, W, Cc, _ptr(gin), _stream(g)), "hd_maxpool5_bwd")
-        return gin
+        ld = _cl_row_stride(g, 4 if dt == 0 else 8)
+        if ld is None or g.dtype != (torch.float32 if dt == 0 else torch.bfloat16):
+            g = g.to(torch.float32 if dt == 0 else torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            ld = Cc
+        gin = torch.empty((B, Cc, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        check(lib.hd_maxpool5_bwd(_ptr(g), int(ld), _ptr(idx), dt, B, H, W, Cc, _ptr(gin), _stream(g)), "hd_maxpool5_bwd")
+        return gin, None
 
 
 def maxpool5_supported(x: torch.Tensor) -> bool:
-    """HIP path: HIP tensor, dense channels-last, float32 (C % 4 == 0) or bfloat16 (C % 8 == 0)."""
-    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
-            and x.is_contiguous(memory_format=torch.channels_last)
-            and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0)
+    """HIP path: HIP tensor, channels-last (dense, or a channel slice of a wider channels-last tensor), float32
+    (C % 4 == 0) or bfloat16 (C % 8 == 0)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    vec = 4 if x.dtype == torch.float32 else 8
+    return x.shape[1] % vec == 0 and _cl_row_stride(x, vec) is not None
 
 
-def maxpool5(x: torch.Tensor) -> torch.Tensor:
-    """5x5 / stride 1 / pad 2 max-pool of a channels-last [B,C,H,W] tensor (SPPF)."""
+def maxpool5(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """5x5 / stride 1 / pad 2 max-pool on a channels-last HIP tensor (csrc/pool.hip): forward records the winning
+    tap, backward is a gather (no atomics).  out: a CatBuffer slot to write the result into."""
     if not maxpool5_supported(x):
-        raise _lib.HdError("maxpool5: needs a dense channels-last float32/bfloat16 HIP tensor")
-    return _MaxPool5Fn.apply(x)
+        raise _lib.HdError("maxpool5: needs a channels-last float32/bfloat16 HIP tensor")
+    return _MaxPool5Fn.apply(x, _OutSlot(out) if out is not None else None)
 
 
 # ------------------------------------------------------------------------------- fused BN + act
@@ -760,7 +838,7 @@ def _cl_row_stride(t: torch.Tensor, vec: int):
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None, res=None,
-                res_mode=0):
+                res_mode=0, out_slot=None):
         lib = _lib.load()
         if res is not None:
             if res.shape != x.shape or res.dtype != x.dtype or res.stride() != x.stride():
@@ -776,7 +854,10 @@ class _BNActFn(torch.autograd.Function):
         if slot.fwd_gen == arena.gen:   # second forward since the last arena reset: clear our own slot
             sums.zero_()
         slot.fwd_gen = arena.gen
-        y = torch.empty_like(x)
+        y = out_slot.t if out_slot is not None else torch.empty_like(x)
+        ld_y = _cl_row_stride(y, 4 if dt == 0 else 8)
+        if ld_y is None or y.shape != x.shape or y.dtype != x.dtype:
+            raise _lib.HdError("bn_act: `out` must be a channels-last tensor (or channel slice) of x's shape and dtype")
         save = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
@@ -790,7 +871,7 @@ class _BNActFn(torch.autograd.Function):
             stat_rows = R * dist.get_world_size(sync_group)
         check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
                                   _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
-                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), st), "hd_bn_act_apply")
+                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y), st), "hd_bn_act_apply")
         # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
         keep_res = res if (res is not None and int(res_mode) == 1) else None
         ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
@@ -833,8 +914,8 @@ class _BNActFn(torch.autograd.Function):
         # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
         gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
         if local is not None:
-            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None
-        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None
+            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None, None
+        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None, None
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:
@@ -844,12 +925,13 @@ def bn_act_slot(device, channels: int) -> _StatSlot:
 
 def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: float, act: str, training: bool,
            slot: Optional[_StatSlot] = None, sync_group=None, residual: Optional[torch.Tensor] = None,
-           residual_after_act: bool = False) -> torch.Tensor:
+           residual_after_act: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip).
     sync_group: a torch.distributed process group -> statistics (and the backward sums) are taken over the
     batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable.
     residual: a tensor shaped like x that is added inside the apply kernel — before the activation
-    (`act(bn(x) + r)`, the ResNet bottleneck tail) or after it (`act(bn(x)) + r`, the YOLOv5 shortcut)."""
+    (`act(bn(x) + r)`, the ResNet bottleneck tail) or after it (`act(bn(x)) + r`, the YOLOv5 shortcut).
+    out: a tensor to write the result into, e.g. a CatBuffer slot (a channel slice of a channels-last buffer)."""
     if not bn_act_supported(x):
         raise _lib.HdError("bn_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0")
     code = _ACT_CODE[act]
@@ -857,18 +939,26 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
         if slot is None:
             slot = bn_act_slot(x.device, x.shape[1])
         return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot, sync_group, residual,
-                              (2 if residual_after_act else 1) if residual is not None else 0)
+                              (2 if residual_after_act else 1) if residual is not None else 0,
+                              _OutSlot(out) if out is not None else None)
     lib = _lib.load()
     B, Cc, H, W = x.shape
-    y = torch.empty_like(x)
+    direct = out is not None and residual is None  # inference with a residual finishes with torch ops below
+    y = out if direct else torch.empty_like(x)
+    ld_y = _cl_row_stride(y, 4 if x.dtype == torch.float32 else 8)
+    if ld_y is None:
+        raise _lib.HdError("bn_act: `out` must be a channels-last tensor or channel slice")
     fused_act = code if (residual is None or residual_after_act) else 0
     check(lib.hd_bn_act_infer(_ptr(x), 0 if x.dtype == torch.float32 else 1, B * H * W, Cc, _ptr(weight.detach().float()),
                               _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), fused_act,
-                              _ptr(y), _stream(x)), "hd_bn_act_infer")
+                              _ptr(y), int(ld_y), _stream(x)), "hd_bn_act_infer")
     if residual is not None:  # inference: the add (and a pre-add activation) stay plain torch ops
         y = y + residual
         if not residual_after_act:
             y = {1: torch.nn.functional.silu, 2: torch.relu, 0: (lambda t: t)}[code](y)
+        if out is not None:
+            out.copy_(y)
+            y = out
     return y
 
 
@@ -945,7 +1035,7 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
     check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")
     out["bn_apply_kernel"] = (run(lambda: check(lib.hd_bn_act_apply(
         _ptr(x), dt, R, 0, Cc, _ptr(sums), _ptr(w), _ptr(b), 1e-3, 0.03, None, None, _ptr(save[0]), _ptr(save[1]), code,
-        _ptr(res), 2 if res is not None else 0, _ptr(y), st), "apply")), (3 if res is not None else 2) * tb)
+        _ptr(res), 2 if res is not None else 0, _ptr(y), 0, st), "apply")), (3 if res is not None else 2) * tb)
     out["bn_bwd_reduce_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_reduce(
         _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), st), "reduce")), 2 * tb)
     out["bn_bwd_dx_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_dx(

@@ -347,10 +347,13 @@ hd_status hd_wbf(const float* boxes, const float* scores, const int32_t* labels,
  * C % 4 == 0; 1 = bfloat16, C % 8 == 0).  idx [B,H,W,C] uint8 receives the winning tap
  * (ty*5+tx; first tap in scan order wins ties).  Backward is the gather form over idx (no
  * atomics, deterministic): grad_in[p] = sum of grad_out[q] over outputs q whose tap points at p. */
-hd_status hd_maxpool5_fwd(const void* in, int dtype, int B, int H, int W, int C, void* out,
-                          uint8_t* idx, hd_stream stream);
-hd_status hd_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int B, int H, int W,
-                          int C, void* grad_in, hd_stream stream);
+/* in_row_stride / out_row_stride / grad_out_row_stride: elements between consecutive pixels (0 or C = dense;
+ * > C, multiple of the vector width = the tensor is a channel slice of a wider channels-last tensor, e.g. a slot of
+ * the concatenation buffer SPPF's four branches are written into).  idx and grad_in are always dense. */
+hd_status hd_maxpool5_fwd(const void* in, int64_t in_row_stride, int dtype, int B, int H, int W, int C,
+                          void* out, int64_t out_row_stride, uint8_t* idx, hd_stream stream);
+hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, const uint8_t* idx, int dtype,
+                          int B, int H, int W, int C, void* grad_in, hd_stream stream);
 
 /* Fused BatchNorm2d (batch statistics) + activation on a dense channels-last tensor seen as rows
  * [R = B*H*W, C]; dtype 0 = float32 (C % 4 == 0), 1 = bfloat16 (C % 8 == 0); C/vec <= 256.
@@ -370,14 +373,17 @@ hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean,
                           float* save_invstd, int act, const void* res, int res_mode, void* y,
-                          hd_stream stream);
+                          int64_t y_row_stride, hd_stream stream);
+/* y_row_stride (apply, infer): elements between consecutive rows of y; 0 (or C) = dense, > C = y is a channel slice of a
+ * wider channels-last tensor — the slot of a following concatenation, so the activation is written where torch.cat
+ * would otherwise copy it (multiple of the vector width). */
 /* Residual input (same dtype/shape as x, dense rows): res_mode 0 = none (res NULL); 1 = y = act(bn(x) + res), the
  * ResNet bottleneck tail; 2 = y = act(bn(x)) + res, the YOLOv5 bottleneck shortcut.  Backward: only mode 1 needs the
  * kernels' help — pass the same `res` to _bwd_reduce and _bwd_dx (act' is taken at bn(x) + res) and _bwd_dx also
  * writes d(res) = dz into dres; for mode 2 d(res) is dy itself and the backward entry points are called with NULL. */
 hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var,
-                          float eps, int act, void* y, hd_stream stream);
+                          float eps, int act, void* y, int64_t y_row_stride, hd_stream stream);
 /* dy_row_stride: elements between consecutive rows of dy; 0 (or C) = dense rows, > C = dy is a channel slice
  * of a wider channels-last tensor (the gradient of a concatenation input), multiple of the vector width. */
 hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,

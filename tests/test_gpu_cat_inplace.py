@@ -1,0 +1,96 @@
+"""Concatenations whose inputs are produced in place (ops.CatBuffer): the fused BN+act apply kernel and the SPPF
+max-pool write straight into their channel slice of the concatenation buffer, and the backward kernels read the
+matching slice of the gradient — instead of torch.cat's copy kernels (VERDICT r01 #7 / DESIGN.md open item).
+Checked against the torch.cat path of the same modules: same values, same gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_and_pool_write_into_cat_slots(gpu, dtype):
+    from heltondetection_amd import ops
+    torch.manual_seed(0)
+    B, H, W = 4, 20, 20
+    ca, cb_ = 32, 64
+    xa = _cl(torch.randn((B, ca, H, W), device=gpu).to(dtype)).requires_grad_(True)
+    xb = _cl(torch.randn((B, cb_, H, W), device=gpu).to(dtype)).requires_grad_(True)
+    wa, ba = torch.rand(ca, device=gpu, requires_grad=True), torch.randn(ca, device=gpu, requires_grad=True)
+    wb, bb = torch.rand(cb_, device=gpu, requires_grad=True), torch.randn(cb_, device=gpu, requires_grad=True)
+    g = _cl(torch.randn((B, ca + cb_ + cb_, H, W), device=gpu).to(dtype))
+
+    def run(in_place):
+        for t in (xa, xb, wa, ba, wb, bb):
+            t.grad = None
+        ops.bn_arena_reset(gpu)
+        if in_place:
+            buf = ops.CatBuffer(xa, [ca, cb_, cb_])
+            ya = ops.bn_act(xa, wa, ba, None, None, 1e-3, 0.03, "silu", True, out=buf.slot(0))
+            yb = ops.bn_act(xb, wb, bb, None, None, 1e-3, 0.03, "silu", True, out=buf.slot(1))
+            assert buf.in_place(0, ya) and buf.in_place(1, yb)
+            yp = ops.maxpool5(yb, out=buf.slot(2))          # strided input (slot 1) -> strided output (slot 2)
+            z = buf.join([ya, yb, yp])
+            assert z.data_ptr() == buf.buf.data_ptr() and z.is_contiguous(memory_format=torch.channels_last)
+        else:
+            ya = ops.bn_act(xa, wa, ba, None, None, 1e-3, 0.03, "silu", True)
+            yb = ops.bn_act(xb, wb, bb, None, None, 1e-3, 0.03, "silu", True)
+            z = torch.cat((ya, yb, ops.maxpool5(yb)), 1)
+        z.backward(g)
+        return z.detach().float().cpu(), [t.grad.detach().float().cpu() for t in (xa, xb, wa, ba, wb, bb)]
+
+    z0, g0 = run(False)
+    z1, g1 = run(True)
+    assert torch.equal(z0, z1)                      # same kernels, same arithmetic: identical activations
+    tol = 1e-5 if dtype == torch.float32 else 2e-2  # gradients: float atomics reorder the per-channel sums
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    # a foreign tensor (not produced in place) is copied into its slot by join, like torch.cat
+    buf = ops.CatBuffer(xa, [ca, ca])
+    other = _cl(torch.randn((B, ca, H, W), device=gpu).to(dtype))
+    ya = ops.bn_act(xa, wa, ba, None, None, 1e-3, 0.03, "silu", True, out=buf.slot(0))
+    z = buf.join([ya, other])
+    assert torch.equal(z[:, ca:], other) and torch.equal(z[:, :ca], ya)
+
+
+def test_yolov5_step_with_in_place_concatenation_matches_torch_cat(gpu):
+    """Whole model, forward + loss + backward, fp32: the in-place concatenation path (C3, SPPF, PAFPN bottom-up) and
+    the torch.cat path produce the same loss and the same gradients."""
+    from heltondetection_amd import ops, synthetic as syn
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.layers import FusedBNAct
+    torch.manual_seed(0)
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160)).to(gpu)
+    model = model.to(memory_format=torch.channels_last).train()
+    g = syn.make_generator(5)
+    img = _cl(syn.make_images(4, 160, g).to(gpu))
+    gtb, gtc, mv = [t.to(gpu) for t in syn.make_targets(4, 160, g, "coco", 8, 8)]
+    out = {}
+    for flag in (False, True):
+        FusedBNAct.cat_in_place = flag
+        try:
+            model.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(gpu)
+            loss, _ = model.forward_train(img, gtb, gtc, mv)
+            loss.backward()
+            out[flag] = (float(loss), [p.grad.detach().float().cpu().clone() for p in model.parameters()])
+        finally:
+            FusedBNAct.cat_in_place = True
+    assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0])
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(out[True][1], out[False][1]))
+    den = sum(float((b ** 2).sum()) for b in out[False][1])
+    assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
+    # eval mode goes through hd_bn_act_infer with the same slots
+    model.eval()
+    with torch.no_grad():
+        FusedBNAct.cat_in_place = False
+        ref = [f.float().cpu() for f in model.extract(img)]
+        FusedBNAct.cat_in_place = True
+        got = [f.float().cpu() for f in model.extract(img)]
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
