@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the roofline legs (profiling runs: keeps the kernel trace to the train steps alone)")
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
     ap.add_argument("--no-graph", action="store_true",
                     help="run forward+backward eagerly instead of replaying a hipGraph (the graph has its memset "
@@ -299,9 +301,10 @@ def micro_kernels(device):
             rb = syn.random_boxes(R, 832.0, g, 16.0, 400.0)
             rois = torch.cat([torch.arange(16).repeat_interleave(per_img)[:, None].float(), rb], 1).to(device)
             esz = 4 if dt == torch.float32 else 2
+            touched = roi_touched_elements(rois, feats, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, 4)
             ms = ktime("roi_align_fwd", lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
-            add(f"roi_align_fwd_cl_kernel<{dn}>", ms, R * 256 * 49 * esz + map_bytes,
-                f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the four maps once)")
+            add(f"roi_align_fwd_cl_kernel<{dn}>", ms, R * 256 * 49 * esz + touched * esz,
+                f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the {touched * esz / 1e6:.0f} MB of feature bytes under the RoIs, once)")
             if per_img == 128:
                 fr = [f.detach().requires_grad_(True) for f in feats]
                 out = ops.roi_align(fr, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True)
@@ -312,8 +315,8 @@ def micro_kernels(device):
                 torch.cuda.synchronize()
                 tb = sorted(ops.collect_timing()["roi_align_bwd"])
                 ops.disable_timing()
-                add("roi_align_bwd_cl_kernel", tb[len(tb) // 2], R * 256 * 49 * esz + 2 * sum(f.numel() * 4 for f in feats),
-                    f"R={R} C=256 P=7 s=2 grad {dn} -> f32 maps (kernel only; float atomics, bytes = grad in + maps read-modify-write)",
+                add("roi_align_bwd_cl_kernel", tb[len(tb) // 2], R * 256 * 49 * esz + 2 * touched * 4,
+                    f"R={R} C=256 P=7 s=2 grad {dn} -> f32 maps (kernel only; float atomics; bytes = grad in + touched f32 cells read-modify-write)",
                     "atomic")
                 del fr, out, go
         del feats
@@ -409,9 +412,39 @@ def yolo_dense_grad_roofline(model, batch, args):
                       traffic=pmc_traffic("yolo_grad_dense_kernel", f"bs{args.batch} {args.size} no{args.classes + 5}"))
 
 
+def roi_touched_elements(rois5, feats, scales, k_min, n_levels):
+    """Feature pixels x channels under at least one RoI's sampling window, summed over levels: what a perfect gather
+    would have to read once (forward) or read-modify-write once (backward).  2-D difference array per level, on the
+    device: +1 / -1 at the window corners, two prefix sums, count of cells > 0."""
+    from heltondetection_amd import ops
+    lvl = ops.roi_level_map(rois5, k_min, n_levels, 224.0, 4).long()
+    total = 0
+    for l, f in enumerate(feats[:n_levels]):
+        B, C, H, W = f.shape
+        sel = lvl == l
+        if not bool(sel.any()):
+            continue
+        r = rois5[sel]
+        b = r[:, 0].long()
+        x0 = (r[:, 1] * scales[l] - 0.5).floor().clamp(0, W - 1).long()
+        y0 = (r[:, 2] * scales[l] - 0.5).floor().clamp(0, H - 1).long()
+        x1 = ((r[:, 3] * scales[l] - 0.5).floor() + 1).clamp(0, W - 1).long()
+        y1 = ((r[:, 4] * scales[l] - 0.5).floor() + 1).clamp(0, H - 1).long()
+        d = torch.zeros((B, H + 1, W + 1), dtype=torch.int32, device=f.device)
+        one = torch.ones_like(b, dtype=torch.int32)
+        d.index_put_((b, y0, x0), one, accumulate=True)
+        d.index_put_((b, y0, x1 + 1), -one, accumulate=True)
+        d.index_put_((b, y1 + 1, x0), -one, accumulate=True)
+        d.index_put_((b, y1 + 1, x1 + 1), one, accumulate=True)
+        cover = d.cumsum(1).cumsum(2)[:, :H, :W] > 0
+        total += int(cover.sum()) * C
+    return total
+
+
 def roi_align_roofline(model, batch, args, device):
     """FasterRCNN (config 3): hd_roi_align_fwd / _bwd on the step's own pyramid (bf16 under autocast) and sampled RoIs.
-    Algorithmic bytes: fwd = RoI features out + the pyramid maps once; bwd = incoming gradient + the float32 gradient
+    Algorithmic bytes ("R*C*P^2*4 out + touched feature bytes"): fwd = RoI features out + every
+    feature byte under at least one RoI window once; bwd = incoming gradient + the same cells of the float32 gradient
     maps read-modify-written once (what a perfect scatter would move; the kernel itself is float-atomic bound)."""
     from heltondetection_amd import ops
     images, gt_boxes, gt_cls, m_valid = batch
@@ -435,13 +468,14 @@ def roi_align_roofline(model, batch, args, device):
     f_ms, b_ms = med(t["roi_align_fwd"]), med(t["roi_align_bwd"])
     R, Cc = rois5.shape[0], fs[0].shape[1]
     esz = fs[0].element_size()
-    map_elems = sum(f.numel() for f in fs)
-    f_bytes = R * Cc * rh.P * rh.P * esz + map_elems * esz
-    b_bytes = R * Cc * rh.P * rh.P * esz + 2 * map_elems * 4
+    touched = roi_touched_elements(rois5, fs, rh.scales, rh.k_min, len(fs))
+    f_bytes = R * Cc * rh.P * rh.P * esz + touched * esz
+    b_bytes = R * Cc * rh.P * rh.P * esz + 2 * touched * 4
     shape = f"R={R} C={Cc} P={rh.P} s={rh.sr} {args.size} bs{args.batch} {str(fs[0].dtype).replace('torch.', '')}"
     main = _hbm_entry("roi_align_fwd_cl_kernel + roi_align_bwd_cl_kernel (hd_roi_align_fwd / _bwd), one launch each per step",
                       f_ms + b_ms, f_bytes + b_bytes, 2,
-                      {"shape": shape, "timed": "every launch stamps its own HIP event pair (kernel begin / end) on the step's own pyramid and sampled RoIs",
+                      {"shape": shape, "touched_feature_elements": int(touched), "pyramid_elements": int(sum(f.numel() for f in fs)),
+                       "timed": "every launch stamps its own HIP event pair (kernel begin / end) on the step's own pyramid and sampled RoIs",
                        "per_kernel": {"roi_align_fwd_cl_kernel": {"ms": round(f_ms, 4), "GB/s": round(f_bytes / f_ms / 1e6, 1),
                                                                   "frac": round(f_bytes / f_ms / 1e6 / HBM_PEAK_GBS, 4)},
                                       "roi_align_bwd_cl_kernel": {"ms": round(b_ms, 4), "GB/s": round(b_bytes / b_ms / 1e6, 1),
@@ -609,7 +643,9 @@ def main():
         # Rooflines are measured live, with HIP events on the launch stream, on this workload's own shapes, right
         # after the timed region (inside it the launches sit in a replayed hipGraph, where no event can be recorded).
         try:
-            if args.model == "yolov5":
+            if args.no_roofline:
+                out["roofline"] = None
+            elif args.model == "yolov5":
                 out["roofline"] = bn_family_roofline(model, batches[0], args, device)
                 out["roofline_secondary"] = [yolo_dense_grad_roofline(model, batches[0], args)]
             else:

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -32,6 +32,11 @@ class RoiLevels(C.Structure):
         ("canonical_level", C.c_int),
         ("dtype", C.c_int),
     ]
+
+
+class Rows2(C.Structure):
+    """hd_rows2: optional second place of a [R, C] operand of the fused BN kernels."""
+    _fields_ = [("p2", C.c_void_p), ("ld2", C.c_int64), ("split", C.c_int)]
 
 
 class YoloLevels(C.Structure):
@@ -104,14 +109,14 @@ SIGNATURES = {
     "hd_maxpool5_bwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_bn_act_replicas": (C.c_int, []),
     "hd_bn_act_stats": (_I, [_P, _I, _L, _I, _P, _P]),
-    "hd_bn_act_apply": (_I, [_P, _I, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
-    "hd_bn_act_infer": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _I, _P, _L, _P]),
+    "hd_bn_act_apply": (_I, [_P, _I, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P, _P]),
+    "hd_bn_act_infer": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _I, _P, _L, _P, _P]),
     "hd_yolo_detect_workspace_bytes": (_Z, [_P, _I, _I, _I]),
     "hd_yolo_detect": (_I, [_P, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "hd_mosaic4": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, C.c_float, _P, _L, _L, _L, _L, _P]),
     "hd_mosaic4_boxes": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
-    "hd_bn_act_bwd_reduce": (_I, [_P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "hd_bn_act_bwd_dx": (_I, [_P, _P, _L, _I, _L, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "hd_bn_act_bwd_reduce": (_I, [_P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "hd_bn_act_bwd_dx": (_I, [_P, _P, _L, _I, _L, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hd_graph_replace_memsets": (_I, [_P, _P, _P]),
     "hd_graph_mark": (_I, [_P, _I, _P]),
     "hd_graph_split_instantiate": (_I, [_P, _P, _I, _P, _P, _P, _P]),

@@ -19,6 +19,8 @@
 // channel per workgroup (<= 512 workgroups, so same-address serialisation stays < 3 us).
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "hd_common.h"
 #include "hd_vec.h"
 
@@ -162,22 +164,26 @@ __device__ __forceinline__ float rep_sum(const float* __restrict__ p, int idx, i
   return v;
 }
 
-// Address of vector i of dy (or, for the forward kernels, of y).  dy may be a channel slice of a wider channels-last tensor (the gradient of
-// a torch.cat input: rows of C channels, row stride ld > C), which saves the .contiguous() copy autograd
-// would otherwise need in front of every such BatchNorm; ld == C is the dense case (no division).
+// A [R, C] channels-last operand that may live in TWO places: channel groups [0, split) in rows of stride ld at p,
+// groups [split, cg) in rows of stride ld2 at p2.  One place, dense (ld == C, split == cg) is the fast case with no
+// division.  A strided single place is a channel slice of a wider channels-last tensor (the gradient of a torch.cat
+// input / the slot of a concatenation buffer); two places serve the merged C3 branch convolutions, whose first half
+// feeds the bottleneck stack as a dense tensor while the second half goes straight into the concatenation.
 template <typename T>
-__device__ __forceinline__ const T* dy_at(const T* dy, long long i, int cg, int C, long long ld) {
-  constexpr int V = RowVec<T>::N;
-  if (ld == C) return dy + i * V;
-  const uint32_t r = (uint32_t)i / (uint32_t)cg;
-  const uint32_t g = (uint32_t)i - r * (uint32_t)cg;
-  return dy + (long long)r * ld + (long long)g * V;
-}
-
-template <typename T>
-__device__ __forceinline__ T* y_at(T* y, long long i, int cg, int C, long long ld) {
-  return const_cast<T*>(dy_at(const_cast<const T*>(y), i, cg, C, ld));
-}
+struct Rows {
+  T* p;
+  long long ld;
+  T* p2;
+  long long ld2;
+  int split;  // in vector groups
+  __device__ __forceinline__ T* at(long long i, int cg, int C) const {
+    constexpr int V = RowVec<typename std::remove_const<T>::type>::N;
+    if (ld == C && split == cg) return p + i * V;
+    const uint32_t r = (uint32_t)i / (uint32_t)cg;
+    const uint32_t g = (uint32_t)i - r * (uint32_t)cg;
+    return (int)g < split ? p + (long long)r * ld + (long long)g * V : p2 + (long long)r * ld2 + (long long)((int)g - split) * V;
+  }
+};
 
 // ---- forward apply ------------------------------------------------------------------------------
 // RES: 0 no residual; 1 y = act(bn(x) + r) (ResNet bottleneck tail); 2 y = act(bn(x)) + r (YOLO bottleneck)
@@ -189,9 +195,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta, float eps, float momentum,
                                                        float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_invstd, T* __restrict__ y, long long ld_y) {
-  // ld_y: elements between consecutive rows of y; C = dense, > C = y is a channel slice of a wider channels-last
-  // tensor (the input slot of a following concatenation: the activation is written where torch.cat would copy it)
+                                                       float* __restrict__ save_invstd, const Rows<T> y) {
   constexpr int V = RowVec<T>::N;
   extern __shared__ float s_coef[];  // [2*C]: a_c, b_c — computed once per workgroup from the replicas
   const int cg = C / V;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
         for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
-        RowVec<T>::store(y_at(y, i + u * stride, cg, C, ld_y), v[u]);
+        RowVec<T>::store(y.at(i + u * stride, cg, C), v[u]);
       }
     } else {
       float rv[4][V];
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
           const float z = fmaf(a[k], v[u][k], b[k]);
           v[u][k] = RES == 1 ? act_fwd<ACT>(z + rv[u][k]) : act_fwd<ACT>(z) + rv[u][k];
         }
-        RowVec<T>::store(y_at(y, i + u * stride, cg, C, ld_y), v[u]);
+        RowVec<T>::store(y.at(i + u * stride, cg, C), v[u]);
       }
     }
   }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       const float z = fmaf(a[k], v[k], b[k]);
       v[k] = RES == 0 ? act_fwd<ACT>(z) : (RES == 1 ? act_fwd<ACT>(z + rv[k]) : act_fwd<ACT>(z) + rv[k]);
     }
-    RowVec<T>::store(y_at(y, i, cg, C, ld_y), v);
+    RowVec<T>::store(y.at(i, cg, C), v);
   }
 }
 
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ running_mean,
                                                        const float* __restrict__ running_var, float eps,
-                                                       T* __restrict__ y, long long ld_y) {
+                                                       const Rows<T> y) {
   constexpr int V = RowVec<T>::N;
   const int cg = C / V;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -286,15 +290,15 @@ __global__ __launch_bounds__(256) void bn_infer_kernel(const T* __restrict__ x, 
     RowVec<T>::load(x + i * V, v);
 #pragma unroll
     for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(fmaf(a[k], v[k], b[k]));
-    RowVec<T>::store(y_at(y, i, cg, C, ld_y), v);
+    RowVec<T>::store(y.at(i, cg, C), v);
   }
 }
 
 // ---- backward reductions ------------------------------------------------------------------------
 // RES (backward kernels): 0, or 1 = the forward added `res` before the activation, so act' is taken at bn(x) + res
 template <typename T, int ACT, int RES>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            const T* __restrict__ res, long long ld_dy, long long nvec,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const Rows<const T> dy,
+                                                            const T* __restrict__ res, long long nvec,
                                                             int C,
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_invstd,
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       rx[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
-      rg[u] = *reinterpret_cast<const uint4*>(dy_at(dy, i + u * stride, cg, C, ld_dy));
+      rg[u] = *reinterpret_cast<const uint4*>(dy.at(i + u * stride, cg, C));
       if (RES) rr[u] = *reinterpret_cast<const uint4*>(res + (i + u * stride) * V);
     }
 #pragma unroll
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (; i < nvec; i += stride) {
     float xv[V], gv[V], rv[V];
     RowVec<T>::load(x + i * V, xv);
-    RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
+    RowVec<T>::load(dy.at(i, cg, C), gv);
     if (RES) RowVec<T>::load(res + i * V, rv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -370,9 +374,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 template <typename T, int ACT, int RES>
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, const Rows<const T> dy,
                                                         const T* __restrict__ res, T* __restrict__ dres,
-                                                        long long ld_dy, long long nvec, int C, float inv_R,
+                                                        long long nvec, int C, float inv_R,
                                                         const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd,
                                                         const float* __restrict__ gamma,
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       RowVec<T>::load(x + (i + u * stride) * V, xv[u]);
-      RowVec<T>::load(dy_at(dy, i + u * stride, cg, C, ld_dy), gv[u]);
+      RowVec<T>::load(dy.at(i + u * stride, cg, C), gv[u]);
       if (RES) RowVec<T>::load(res + (i + u * stride) * V, rv[u]);
     }
 #pragma unroll
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
   for (; i < nvec; i += stride) {
     float xv[V], gv[V], rv[V];
     RowVec<T>::load(x + i * V, xv);
-    RowVec<T>::load(dy_at(dy, i, cg, C, ld_dy), gv);
+    RowVec<T>::load(dy.at(i, cg, C), gv);
     if (RES) RowVec<T>::load(res + i * V, rv);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -487,6 +491,35 @@ inline hd_status common_checks(int dtype, long long R, int C) {
 
 }  // namespace
 
+// Host side of Rows<T>: primary pointer + row stride (0 or C = dense) and the optional second place (hd_rows2).
+template <typename XT>
+static hd_status make_rows(XT* p, int64_t row_stride, const hd_rows2* tail, int C, int V, long long nvec, Rows<XT>* out) {
+  int64_t ld = row_stride == 0 ? C : row_stride;
+  int split = C;
+  XT* p2 = nullptr;
+  int64_t ld2 = 0;
+  if (tail && tail->p2) {
+    split = tail->split;
+    if (split <= 0 || split >= C || split % V != 0) return HD_ERR_SHAPE;
+    p2 = reinterpret_cast<XT*>(const_cast<void*>(static_cast<const void*>(tail->p2)));
+    ld2 = tail->ld2 == 0 ? (C - split) : tail->ld2;
+    if (ld2 < C - split || ld2 % V != 0) return HD_ERR_SHAPE;
+    if (!hd_aligned16(p2)) return HD_ERR_ALIGN;
+    if (row_stride == 0) ld = split;  // a dense first place holds only its own channels
+    if (ld < split) return HD_ERR_SHAPE;
+  } else if (ld < C) {
+    return HD_ERR_SHAPE;
+  }
+  if (ld % V != 0) return HD_ERR_SHAPE;
+  if ((ld != C || split != C) && nvec >= (1ll << 31)) return HD_ERR_SHAPE;  // the strided path indexes with 32-bit rows
+  out->p = p;
+  out->ld = ld;
+  out->p2 = p2;
+  out->ld2 = ld2;
+  out->split = split / V;
+  return HD_OK;
+}
+
 // dy_row_stride: elements between consecutive rows of dy (0 or C = dense; > C = channel slice of a wider tensor)
 static hd_status check_dy_stride(int64_t dy_row_stride, int C, int V, long long nvec, int64_t* ld) {
   *ld = dy_row_stride == 0 ? C : dy_row_stride;
@@ -520,7 +553,7 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                      int act, const void* res, int res_mode, void* y, int64_t y_row_stride,
-                                     hd_stream stream) {
+                                     const hd_rows2* y_tail, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !sums || !gamma || !beta || !save_mean || !save_invstd || !y) return HD_ERR_NULL;
@@ -532,18 +565,19 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
-  int64_t ld_y = 0;
-  st = check_dy_stride(y_row_stride, C, V, nvec, &ld_y);  // same rules as a strided dy: >= C, multiple of the vector
-  if (st != HD_OK) return st;
   const int64_t RS = stat_rows > 0 ? stat_rows : R;
   const float inv_R = 1.0f / (float)RS;
   const float unbias = RS > 1 ? (float)RS / (float)(RS - 1) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
 #define HD_APPLY_R(T, A, RS_, XT)                                                                                  \
-  (void)hd_launch(bn_apply_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
-                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(res), nvec, C, inv_R, unbias,    \
-                     sums, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,         \
-                     reinterpret_cast<XT*>(y), (long long)ld_y)
+  do {                                                                                                             \
+    Rows<XT> yr;                                                                                                   \
+    st = make_rows<XT>(reinterpret_cast<XT*>(y), y_row_stride, y_tail, C, V, nvec, &yr);                          \
+    if (st != HD_OK) return st;                                                                                    \
+    (void)hd_launch(bn_apply_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s,    \
+                    reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(res), nvec, C, inv_R, unbias,      \
+                    sums, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, yr);      \
+  } while (0)
 #define HD_APPLY(T, A, XT)                     \
   do {                                         \
     if (res_mode == 0) HD_APPLY_R(T, A, 0, XT); \
@@ -560,21 +594,24 @@ extern "C" hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_
 
 extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                                      const float* beta, const float* running_mean, const float* running_var,
-                                     float eps, int act, void* y, int64_t y_row_stride, hd_stream stream) {
+                                     float eps, int act, void* y, int64_t y_row_stride, const hd_rows2* y_tail,
+                                     hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !gamma || !beta || !running_mean || !running_var || !y) return HD_ERR_NULL;
   if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  int64_t ld_y = 0;
-  st = check_dy_stride(y_row_stride, C, V, nvec, &ld_y);
-  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   hipStream_t s = (hipStream_t)stream;
 #define HD_INFER(T, A, XT)                                                                                         \
-  (void)hd_launch(bn_infer_kernel<XT, A>, dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), \
-                     nvec, C, gamma, beta, running_mean, running_var, eps, reinterpret_cast<XT*>(y), (long long)ld_y)
+  do {                                                                                                             \
+    Rows<XT> yr;                                                                                                   \
+    st = make_rows<XT>(reinterpret_cast<XT*>(y), y_row_stride, y_tail, C, V, nvec, &yr);                          \
+    if (st != HD_OK) return st;                                                                                    \
+    (void)hd_launch(bn_infer_kernel<XT, A>, dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x),     \
+                    nvec, C, gamma, beta, running_mean, running_var, eps, yr);                                     \
+  } while (0)
   if (dtype == 0) HD_ACT_DISPATCH(float, HD_INFER, float);
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_INFER, __hip_bfloat16);
 #undef HD_INFER
@@ -585,23 +622,25 @@ extern "C" hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C,
 extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                                           int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                           const float* beta, int act, const void* res, float* dsums,
-                                          hd_stream stream) {
+                                          const hd_rows2* dy_tail, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !dy || !save_mean || !save_invstd || !gamma || !beta || !dsums) return HD_ERR_NULL;
   if (!hd_aligned16(x) || !hd_aligned16(dy) || (res && !hd_aligned16(res))) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  int64_t ld = 0;
-  st = check_dy_stride(dy_row_stride, C, V, nvec, &ld);
-  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
 #define HD_RED_R(T, A, RS_, XT)                                                                                    \
-  (void)hd_launch(bn_bwd_reduce_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), lds, s,                    \
-                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
-                     (long long)ld, nvec, C, save_mean, save_invstd, gamma, beta, dsums)
+  do {                                                                                                             \
+    Rows<const XT> dr;                                                                                             \
+    st = make_rows<const XT>(reinterpret_cast<const XT*>(dy), dy_row_stride, dy_tail, C, V, nvec, &dr);           \
+    if (st != HD_OK) return st;                                                                                    \
+    (void)hd_launch(bn_bwd_reduce_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), lds, s,                         \
+                    reinterpret_cast<const XT*>(x), dr, reinterpret_cast<const XT*>(res), nvec, C, save_mean,      \
+                    save_invstd, gamma, beta, dsums);                                                              \
+  } while (0)
 #define HD_RED(T, A, XT)                \
   do {                                  \
     if (res) HD_RED_R(T, A, 1, XT);     \
@@ -618,7 +657,7 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t
 extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                                       int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                       const float* beta, int act, const void* res, const float* dsums, void* dx,
-                                      void* dres, float* dgamma, float* dbeta, hd_stream stream) {
+                                      void* dres, float* dgamma, float* dbeta, const hd_rows2* dy_tail, hd_stream stream) {
   hd_status st = common_checks(dtype, R, C);
   if (st != HD_OK) return st;
   if (!x || !dy || !save_mean || !save_invstd || !gamma || !beta || !dsums || !dx || !dgamma || !dbeta)
@@ -628,17 +667,19 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_
     return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  int64_t ld = 0;
-  st = check_dy_stride(dy_row_stride, C, V, nvec, &ld);
-  if (st != HD_OK) return st;
   const Launch l = plan(nvec / 4 + 1, C / V, 2048);  // >= 4 vectors per lane: the per-workgroup prologue is not free
   const float inv_R = 1.0f / (float)(stat_rows > 0 ? stat_rows : R);
   hipStream_t s = (hipStream_t)stream;
 #define HD_DX_R(T, A, RS_, XT)                                                                                     \
-  (void)hd_launch(bn_bwd_dx_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s, \
-                     reinterpret_cast<const XT*>(x), reinterpret_cast<const XT*>(dy), reinterpret_cast<const XT*>(res), \
-                     reinterpret_cast<XT*>(dres), (long long)ld, nvec, C, inv_R, save_mean, save_invstd, gamma, beta, \
-                     dsums, reinterpret_cast<XT*>(dx), dgamma, dbeta)
+  do {                                                                                                             \
+    Rows<const XT> dr;                                                                                             \
+    st = make_rows<const XT>(reinterpret_cast<const XT*>(dy), dy_row_stride, dy_tail, C, V, nvec, &dr);           \
+    if (st != HD_OK) return st;                                                                                    \
+    (void)hd_launch(bn_bwd_dx_kernel<XT, A, RS_>, dim3(l.grid), dim3(l.block), 2 * (size_t)C * sizeof(float), s,   \
+                    reinterpret_cast<const XT*>(x), dr, reinterpret_cast<const XT*>(res), reinterpret_cast<XT*>(dres), \
+                    nvec, C, inv_R, save_mean, save_invstd, gamma, beta, dsums, reinterpret_cast<XT*>(dx), dgamma, \
+                    dbeta);                                                                                        \
+  } while (0)
 #define HD_DX(T, A, XT)               \
   do {                                \
     if (res) HD_DX_R(T, A, 1, XT);    \

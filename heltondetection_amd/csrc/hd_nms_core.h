@@ -18,7 +18,14 @@
 //      Per 64-box chunk wave 0 resolves the chunk against its diagonal word with scalar
 //      bit-ops, then all lanes OR the kept rows' words (independent loads).  Stops at max_out.
 //
-// The result is bit-identical to the serial algorithm in oracle/hd_oracle.c: nms_one().
+// Steps 2 and 3 run in WINDOWS over the score-sorted candidates (first 1024, then up to 4096, 16384, 65536): the
+// scan stops as soon as max_out boxes are kept, and everything a later window would have computed — the bulk of the
+// N^2/2 pair tests when max_out is a few hundred — is never launched into (the kernels of the remaining windows find
+// the image's `done` flag set and exit).  A window's mask kernel computes the tiles whose COLUMN tile lies in the
+// window (all rows above the diagonal); its scan first folds the rows kept in earlier windows into the new columns'
+// removed-words, then continues the greedy resolve.  State between windows (kept count, kept bits per chunk, done
+// flag) lives in the workspace.  Greedy NMS evaluated lazily is still greedy NMS:
+// the result is bit-identical to the serial algorithm in oracle/hd_oracle.c: nms_one().
 #pragma once
 #include <atomic>
 
@@ -134,6 +141,9 @@ struct CoreWs {
   int32_t* scls;    // [B, cap] sorted classes
   int32_t* sidx;    // [B, cap] sorted candidate indices
   u64* mask;        // [B, cap, words]
+  u64* kept;        // [B, words] window state: kept bits of every resolved chunk
+  int32_t* st_count;  // [B] kept so far
+  int32_t* st_done;   // [B] 1 once the image is finished (max_out reached or every candidate resolved)
   int key_cap, cap, words;
   size_t bytes;
 };
@@ -160,6 +170,9 @@ inline CoreWs core_layout(void* base, int B, int n_keys_max, int max_candidates)
   w.scls = reinterpret_cast<int32_t*>(take((size_t)B * cap * sizeof(int32_t)));
   w.sidx = reinterpret_cast<int32_t*>(take((size_t)B * cap * sizeof(int32_t)));
   w.mask = reinterpret_cast<u64*>(take((size_t)B * cap * w.words * sizeof(u64)));
+  w.kept = reinterpret_cast<u64*>(take((size_t)B * w.words * sizeof(u64)));
+  w.st_count = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
+  w.st_done = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
   w.bytes = off;
   return w;
 }
@@ -180,7 +193,11 @@ static __global__ __launch_bounds__(kSortThreads) void nms_sort_gather_kernel(Co
   __syncthreads();
   block_sort_desc(keys, n_pow2, s_tile, w.key_cap < kSortTile ? w.key_cap : kSortTile);
   const int nc = n < w.cap ? n : w.cap;
-  if (threadIdx.x == 0) w.nc[b] = nc;
+  if (threadIdx.x == 0) {
+    w.nc[b] = nc;
+    w.st_count[b] = 0;  // window state of steps 2 and 3
+    w.st_done[b] = 0;
+  }
   for (int r = threadIdx.x; r < nc; r += blockDim.x) {
     const uint32_t idx = key_index(keys[r]);
     w.sbox[(size_t)b * w.cap + r] = cand_box[(long long)b * cand_stride + idx];
@@ -201,26 +218,27 @@ static __global__ __launch_bounds__(kSortThreads) void nms_sort_gather_kernel(Co
 // boxes is one v_cmp whose 64-bit result IS the mask word (the wavefront ballot).
 constexpr int kMaskBlocks = 512;  // x 4 waves per image
 
-static __global__ __launch_bounds__(256) void nms_mask_kernel(CoreWs w, float iou_thr) {
+static __global__ __launch_bounds__(256) void nms_mask_kernel(CoreWs w, float iou_thr, int ct_lo, int ct_hi) {
   __shared__ float4 s_row[4][64];
   __shared__ float s_rarea[4][64];
   __shared__ int32_t s_rcls[4][64];
   const int b = blockIdx.y;
+  if (w.st_done[b]) return;  // an earlier window already kept max_out boxes (or resolved every candidate)
   const int nc = w.nc[b];
   const int T = (nc + 63) >> 6;
-  const long long P = (long long)T * (T + 1) / 2;
+  const int hi = ct_hi < T ? ct_hi : T;
+  if (ct_lo >= hi) return;
+  // tile pairs (rt <= ct) with ct in [ct_lo, hi), enumerated column by column: q = ct (ct + 1) / 2 + rt
+  const long long q0 = (long long)ct_lo * (ct_lo + 1) / 2, q1 = (long long)hi * (hi + 1) / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* sbox = w.sbox + (size_t)b * w.cap;
   const int32_t* scls = w.scls + (size_t)b * w.cap;
   const long long n_waves = (long long)gridDim.x * 4;
-  for (long long p = (long long)blockIdx.x * 4 + wv; p < P; p += n_waves) {
-    // p = rt*T - rt*(rt-1)/2 + (ct - rt), 0 <= rt <= ct < T
-    int rt = (int)(((double)(2 * T + 1) - sqrt((double)(2 * T + 1) * (double)(2 * T + 1) - 8.0 * (double)p)) * 0.5);
-    if (rt < 0) rt = 0;
-    if (rt > T - 1) rt = T - 1;
-    while (rt > 0 && (long long)rt * T - (long long)rt * (rt - 1) / 2 > p) --rt;
-    while ((long long)(rt + 1) * T - (long long)(rt + 1) * rt / 2 <= p) ++rt;
-    const int ct = rt + (int)(p - ((long long)rt * T - (long long)rt * (rt - 1) / 2));
+  for (long long q = q0 + (long long)blockIdx.x * 4 + wv; q < q1; q += n_waves) {
+    int ct = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((long long)ct * (ct + 1) / 2 > q) --ct;
+    while ((long long)(ct + 1) * (ct + 2) / 2 <= q) ++ct;
+    const int rt = (int)(q - (long long)ct * (ct + 1) / 2);
     const int row0 = rt * 64;
     {
       const int r = row0 + lane;
@@ -272,20 +290,46 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(CoreWs w, float io
 // ---- step 3 ---------------------------------------------------------------------------------
 // keep_out[b, 0:count] = candidate indices in kept order; tail = -1.
 static __global__ __launch_bounds__(1024) void nms_scan_kernel(CoreWs w, int max_out, int32_t* __restrict__ keep_out,
-                                                        int32_t* __restrict__ keep_count) {
+                                                        int32_t* __restrict__ keep_count, int c_lo, int c_hi) {
   __shared__ u64 s_cur;
   __shared__ u64 s_kept;
   __shared__ int s_count;
   const int b = blockIdx.x;
+  if (w.st_done[b]) return;
   const int nc = w.nc[b];
   const int words = (nc + 63) / 64;
   const int t = threadIdx.x;
   const u64* mask = w.mask + (size_t)b * w.cap * w.words;
   const int32_t* sidx = w.sidx + (size_t)b * w.cap;
   int32_t* keep = keep_out + (size_t)b * max_out;
+  u64* st_kept = w.kept + (size_t)b * w.words;
+  const int hi = c_hi < words ? c_hi : words;
   u64 removed = 0ull;
-  int count = 0;
-  for (int c = 0; c < words && count < max_out; ++c) {
+  int count = c_lo == 0 ? 0 : w.st_count[b];
+  // OR the mask words of the rows `kept` of chunk c into this lane's removed-word (column tile t), 8 independent loads
+  // at a time (a plain one-load-per-iteration loop waits out a full memory latency per kept box)
+  auto fold = [&](int c, u64 kept) {
+    const u64* col = mask + (size_t)c * 64 * w.words + t;
+    while (kept) {
+      int j[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        j[k] = kept ? __ffsll((long long)kept) - 1 : -1;
+        kept &= kept - 1;  // 0 & anything stays 0
+      }
+      u64 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = j[k] >= 0 ? col[(size_t)j[k] * w.words] : 0ull;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) removed |= v[k];
+    }
+  };
+  if (c_lo > 0 && t >= c_lo && t < hi) {
+    // columns new in this window: the rows kept in earlier windows have not been applied to them yet
+    for (int c = 0; c < c_lo; ++c) fold(c, st_kept[c]);
+  }
+  int c = c_lo;
+  for (; c < hi && count < max_out; ++c) {
     if (t == c) s_cur = removed;
     __syncthreads();
     if (t < 64) {
@@ -316,35 +360,30 @@ static __global__ __launch_bounds__(1024) void nms_scan_kernel(CoreWs w, int max
       if (t == 0) {
         s_kept = kept;
         s_count = count + __popcll(kept);
+        st_kept[c] = kept;
       }
     }
     __syncthreads();
-    u64 kept = s_kept;
+    const u64 kept = s_kept;
     count = s_count;
-    if (count >= max_out) break;
-    if (t > c && t < words) {
-      // OR the kept rows' words into this lane's removed-word, 8 independent loads at a time (a plain
-      // one-load-per-iteration loop waits out a full memory latency per kept box)
-      const u64* col = mask + (size_t)c * 64 * w.words + t;
-      while (kept) {
-        int j[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          j[k] = kept ? __ffsll((long long)kept) - 1 : -1;
-          kept &= kept - 1;  // 0 & anything stays 0
-        }
-        u64 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = j[k] >= 0 ? col[(size_t)j[k] * w.words] : 0ull;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) removed |= v[k];
-      }
+    if (count >= max_out) {
+      ++c;
+      break;
     }
+    if (t > c && t < hi) fold(c, kept);  // columns beyond this window are brought up to date when their window opens
     __syncthreads();  // s_cur / s_kept are rewritten next iteration
   }
-  if (count > max_out) count = max_out;
-  if (t == 0) keep_count[b] = count;
-  for (int i = count + t; i < max_out; i += blockDim.x) keep[i] = -1;
+  if (count >= max_out || c >= words) {
+    // finished: max_out reached, or every candidate resolved
+    if (count > max_out) count = max_out;
+    if (t == 0) {
+      keep_count[b] = count;
+      w.st_done[b] = 1;
+    }
+    for (int i = count + t; i < max_out; i += blockDim.x) keep[i] = -1;
+  } else if (t == 0) {
+    w.st_count[b] = count;
+  }
 }
 
 // Runs steps 1-3.  The caller has zeroed w.n_keys before its prepare kernel ran.
@@ -368,14 +407,27 @@ inline hd_status run_core(const CoreWs& w, int B, const float4* cand_box, const 
   hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(B), dim3(kSortThreads), sort_lds, s, w, cand_box, cand_cls,
                      cand_stride);
   HD_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskBlocks, (unsigned)B), dim3(256), 0, s, w, iou_thr);
-  HD_RETURN_IF_LAUNCH_FAILED();
   // one lane per 64-candidate mask word; fewer waves make the three barriers per chunk cheaper
   int scan_threads = ((w.words + 63) / 64) * 64;
   if (scan_threads < 64) scan_threads = 64;
   if (scan_threads > 1024) scan_threads = 1024;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(scan_threads), 0, s, w, max_out, keep_out, keep_count);
-  HD_RETURN_IF_LAUNCH_FAILED();
+  // windows over the sorted candidates, in 64-candidate chunks: [0,16) [16,64) [64,256) [256,1024); how many of them an
+  // image needs is decided on the device (st_done), the host only bounds them by the workspace capacity
+  const int window_end[4] = {16, 64, 256, 1024};
+  int lo = 0;
+  for (int k = 0; k < 4 && lo < w.words; ++k) {
+    const int hi = window_end[k];
+    // the first window's tile pairs (<= 136) fit a few workgroups per image; later ones use the persistent grid
+    const long long pairs = (long long)(hi < w.words ? hi : w.words) * ((hi < w.words ? hi : w.words) + 1) / 2 - (long long)lo * (lo + 1) / 2;
+    long long blocks = (pairs + 3) / 4;
+    if (blocks > kMaskBlocks) blocks = kMaskBlocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, s, w, iou_thr, lo, hi);
+    HD_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(scan_threads), 0, s, w, max_out, keep_out, keep_count, lo, hi);
+    HD_RETURN_IF_LAUNCH_FAILED();
+    lo = hi;
+  }
   return HD_OK;
 }
 

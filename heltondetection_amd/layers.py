@@ -131,25 +131,68 @@ class Bottleneck(nn.Module):
 
 
 class C3(nn.Module):
-    """CSP bottleneck with 3 convolutions (YOLOv5 v6.x)."""
+    """CSP bottleneck with 3 convolutions (YOLOv5 v6.x).
+
+    The two branch convolutions cv1 and cv2 (both 1x1, same input, same width c_, each followed by its own
+    BatchNorm + SiLU) are held as ONE convolution to 2*c_ channels with ONE BatchNorm (`cv12`): BatchNorm statistics
+    and affine parameters are per channel, so this is the same function of the same number of parameters with the
+    same initialisation — but one MIOpen convolution forward, one data-gradient and one weight-gradient kernel
+    instead of two each, four fused-BN launches instead of eight, and no gradient-sum kernel for the shared input.
+    Channels [0, c_) are the cv1 branch (into the bottleneck stack), [c_, 2c_) the cv2 branch, which the fused BN
+    kernel writes straight into its half of the block's concatenation (ops.CatBuffer; hd_rows2 second place).
+    `split_state_dict` / `merge_state_dict` translate to and from the cv1 / cv2 naming of the public v6.x weights."""
 
     def __init__(self, c1, c2, n=1, shortcut=True, e=0.5):
         super().__init__()
         c_ = int(c2 * e)
-        self.cv1 = ConvBNAct(c1, c_, 1, 1)
-        self.cv2 = ConvBNAct(c1, c_, 1, 1)
+        self.c_ = c_
+        self.cv12 = ConvBNAct(c1, 2 * c_, 1, 1)
         self.cv3 = ConvBNAct(2 * c_, c2, 1, 1)
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, e=1.0) for _ in range(n)))
 
     def forward(self, x):
-        cb = cat_buffer(x, (self.cv1.conv.out_channels, self.cv2.conv.out_channels), x.shape[2:])
+        c_ = self.c_
+        cb = cat_buffer(x, (c_, c_), x.shape[2:])
         if cb is None:
-            return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
-        # both branches end in a fused BN+act kernel: each writes straight into its half of the concatenation
-        y = self.cv1(x)
+            y = self.cv12(x)
+            return self.cv3(torch.cat((self.m(y[:, :c_]), y[:, c_:]), 1))
+        # first half: a dense tensor for the bottleneck stack; second half: straight into the concatenation
+        y1 = torch.empty((x.shape[0], c_, x.shape[2], x.shape[3]), dtype=cb.buf.dtype, device=x.device,
+                         memory_format=torch.channels_last)
+        y = self.cv12(x, None, (y1, cb.slot(1)))
+        if isinstance(y, tuple):
+            y, y2 = y
+        else:  # the unfused fallback returned one tensor
+            y, y2 = y[:, :c_], y[:, c_:]
         for k, blk in enumerate(self.m):
             y = blk(y, cb.slot(0) if k == len(self.m) - 1 else None)
-        return self.cv3(cb.join((y, self.cv2(x, None, cb.slot(1)))))
+        return self.cv3(cb.join((y, y2)))
+
+    @staticmethod
+    def split_state_dict(sd: dict, prefix: str) -> dict:
+        """`prefix`cv12.* -> `prefix`cv1.* + `prefix`cv2.* (the two halves along the output-channel axis)."""
+        out = dict(sd)
+        for k in [k for k in sd if k.startswith(prefix + "cv12.")]:
+            v = out.pop(k)
+            rest = k[len(prefix) + 5:]
+            if v.dim() == 0:  # num_batches_tracked
+                out[prefix + "cv1." + rest] = v.clone()
+                out[prefix + "cv2." + rest] = v.clone()
+            else:
+                h = v.shape[0] // 2
+                out[prefix + "cv1." + rest] = v[:h].clone()
+                out[prefix + "cv2." + rest] = v[h:].clone()
+        return out
+
+    @staticmethod
+    def merge_state_dict(sd: dict, prefix: str) -> dict:
+        """The inverse: `prefix`cv1.* + `prefix`cv2.* -> `prefix`cv12.*."""
+        out = dict(sd)
+        for k in [k for k in sd if k.startswith(prefix + "cv1.")]:
+            rest = k[len(prefix) + 4:]
+            a, b = out.pop(k), out.pop(prefix + "cv2." + rest)
+            out[prefix + "cv12." + rest] = a.clone() if a.dim() == 0 else torch.cat((a, b), 0)
+        return out
 
 
 class C2f(nn.Module):

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import RoiLevels, YoloLevels, YoloLossCfg, check
+from ._lib import RoiLevels, Rows2, YoloLevels, YoloLossCfg, check
 
 _F32, _I32 = torch.float32, torch.int32
 
@@ -854,10 +854,23 @@ class _BNActFn(torch.autograd.Function):
         if slot.fwd_gen == arena.gen:   # second forward since the last arena reset: clear our own slot
             sums.zero_()
         slot.fwd_gen = arena.gen
-        y = out_slot.t if out_slot is not None else torch.empty_like(x)
-        ld_y = _cl_row_stride(y, 4 if dt == 0 else 8)
-        if ld_y is None or y.shape != x.shape or y.dtype != x.dtype:
-            raise _lib.HdError("bn_act: `out` must be a channels-last tensor (or channel slice) of x's shape and dtype")
+        vec = 4 if dt == 0 else 8
+        split = 0
+        y2, tail = None, None
+        if out_slot is not None and isinstance(out_slot.t, tuple):
+            # two destinations (merged C3 branch convolutions): channels [0, split) -> y, [split, C) -> y2
+            y, y2 = out_slot.t
+            split = y.shape[1]
+            ld_y, ld_y2 = _cl_row_stride(y, vec), _cl_row_stride(y2, vec)
+            if (ld_y is None or ld_y2 is None or y.shape[1] + y2.shape[1] != Cc or y.dtype != x.dtype or y2.dtype != x.dtype
+                    or split % vec or y.shape[0] != B or y.shape[2:] != x.shape[2:] or y2.shape[2:] != x.shape[2:]):
+                raise _lib.HdError("bn_act: split outputs must be channels-last tensors / channel slices covering x's channels")
+            tail = Rows2(y2.data_ptr(), int(ld_y2), int(split))
+        else:
+            y = out_slot.t if out_slot is not None else torch.empty_like(x)
+            ld_y = _cl_row_stride(y, vec)
+            if ld_y is None or y.shape != x.shape or y.dtype != x.dtype:
+                raise _lib.HdError("bn_act: `out` must be a channels-last tensor (or channel slice) of x's shape and dtype")
         save = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
@@ -871,25 +884,43 @@ class _BNActFn(torch.autograd.Function):
             stat_rows = R * dist.get_world_size(sync_group)
         check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
                                   _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
-                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y), st), "hd_bn_act_apply")
+                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y),
+                                  C.byref(tail) if tail is not None else None, st), "hd_bn_act_apply")
         # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
         keep_res = res if (res is not None and int(res_mode) == 1) else None
         ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
-        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows, 0 if res is None else int(res_mode))
-        return y
+        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows, 0 if res is None else int(res_mode), split)
+        return y if y2 is None else (y, y2)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         lib = _lib.load()
         x, w, b, save, *rest = ctx.saved_tensors
-        dt, R, Cc, act, slot, sync_group, stat_rows, res_mode = ctx.meta
+        dt, R, Cc, act, slot, sync_group, stat_rows, res_mode, split = ctx.meta
         res = rest[0] if rest else None
-        if dy.dtype != x.dtype:
-            dy = dy.to(x.dtype)
-        ld = _cl_row_stride(dy, 4 if dt == 0 else 8)
-        if ld is None:  # not (a channel slice of) a channels-last tensor: one copy
-            dy = dy.contiguous(memory_format=torch.channels_last)
-            ld = Cc
+        vec = 4 if dt == 0 else 8
+
+        def prep(g, channels):
+            """-> (tensor kept alive, row stride): a (channel slice of a) channels-last tensor, copied once otherwise."""
+            if g is None:  # an unused half: zero gradient
+                g = torch.zeros((x.shape[0], channels, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
+                                memory_format=torch.channels_last)
+            if g.dtype != x.dtype:
+                g = g.to(x.dtype)
+            ld_ = _cl_row_stride(g, vec)
+            if ld_ is None:
+                g = g.contiguous(memory_format=torch.channels_last)
+                ld_ = channels
+            return g, ld_
+
+        tail = None
+        if split:
+            dy, ld = prep(dy, split)
+            dy2, ld2 = prep(dy2, Cc - split)
+            tail = Rows2(dy2.data_ptr(), int(ld2), int(split))
+        else:
+            dy, ld = prep(dy, Cc)
+        tail_ref = C.byref(tail) if tail is not None else None
         rep = lib.hd_bn_act_replicas()
         dsums = slot.buf[rep * 2 * Cc: rep * 4 * Cc]
         if slot.bwd_gen == slot.arena.gen:
@@ -900,7 +931,7 @@ class _BNActFn(torch.autograd.Function):
         st = _stream(x)
         dres = torch.empty_like(x) if res is not None else None
         check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
-                                       act, _ptr(res), _ptr(dsums), st), "hd_bn_act_bwd_reduce")
+                                       act, _ptr(res), _ptr(dsums), tail_ref, st), "hd_bn_act_bwd_reduce")
         local = None
         if sync_group is not None:
             # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
@@ -909,8 +940,8 @@ class _BNActFn(torch.autograd.Function):
             local = dsums.view(rep, 2, Cc).sum(0)
             dist.all_reduce(dsums, group=sync_group)
         check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
-                                   _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), st),
-              "hd_bn_act_bwd_dx")
+                                   _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), tail_ref,
+                                   st), "hd_bn_act_bwd_dx")
         # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
         gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
         if local is not None:
@@ -931,7 +962,8 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
     batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable.
     residual: a tensor shaped like x that is added inside the apply kernel — before the activation
     (`act(bn(x) + r)`, the ResNet bottleneck tail) or after it (`act(bn(x)) + r`, the YOLOv5 shortcut).
-    out: a tensor to write the result into, e.g. a CatBuffer slot (a channel slice of a channels-last buffer)."""
+    out: a tensor to write the result into, e.g. a CatBuffer slot (a channel slice of a channels-last buffer); or a
+    pair (y_first, y_second) of such tensors that split the channels between them (returns the pair)."""
     if not bn_act_supported(x):
         raise _lib.HdError("bn_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0")
     code = _ACT_CODE[act]
@@ -943,15 +975,28 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
                               _OutSlot(out) if out is not None else None)
     lib = _lib.load()
     B, Cc, H, W = x.shape
-    direct = out is not None and residual is None  # inference with a residual finishes with torch ops below
-    y = out if direct else torch.empty_like(x)
-    ld_y = _cl_row_stride(y, 4 if x.dtype == torch.float32 else 8)
-    if ld_y is None:
-        raise _lib.HdError("bn_act: `out` must be a channels-last tensor or channel slice")
+    vec = 4 if x.dtype == torch.float32 else 8
+    tail, y2 = None, None
+    if isinstance(out, tuple):  # two destinations (merged C3 branch convolutions); no residual in that layer
+        if residual is not None:
+            raise _lib.HdError("bn_act: split outputs and a residual are not combined")
+        y, y2 = out
+        ld_y, ld_y2 = _cl_row_stride(y, vec), _cl_row_stride(y2, vec)
+        if ld_y is None or ld_y2 is None or y.shape[1] + y2.shape[1] != Cc or y.shape[1] % vec:
+            raise _lib.HdError("bn_act: split outputs must be channels-last tensors / channel slices covering x's channels")
+        tail = Rows2(y2.data_ptr(), int(ld_y2), int(y.shape[1]))
+    else:
+        direct = out is not None and residual is None  # inference with a residual finishes with torch ops below
+        y = out if direct else torch.empty_like(x)
+        ld_y = _cl_row_stride(y, vec)
+        if ld_y is None:
+            raise _lib.HdError("bn_act: `out` must be a channels-last tensor or channel slice")
     fused_act = code if (residual is None or residual_after_act) else 0
     check(lib.hd_bn_act_infer(_ptr(x), 0 if x.dtype == torch.float32 else 1, B * H * W, Cc, _ptr(weight.detach().float()),
                               _ptr(bias.detach().float()), _ptr(running_mean), _ptr(running_var), float(eps), fused_act,
-                              _ptr(y), int(ld_y), _stream(x)), "hd_bn_act_infer")
+                              _ptr(y), int(ld_y), C.byref(tail) if tail is not None else None, _stream(x)), "hd_bn_act_infer")
+    if y2 is not None:
+        return y, y2
     if residual is not None:  # inference: the add (and a pre-add activation) stay plain torch ops
         y = y + residual
         if not residual_after_act:
@@ -1035,12 +1080,12 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
     check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "stats")
     out["bn_apply_kernel"] = (run(lambda: check(lib.hd_bn_act_apply(
         _ptr(x), dt, R, 0, Cc, _ptr(sums), _ptr(w), _ptr(b), 1e-3, 0.03, None, None, _ptr(save[0]), _ptr(save[1]), code,
-        _ptr(res), 2 if res is not None else 0, _ptr(y), 0, st), "apply")), (3 if res is not None else 2) * tb)
+        _ptr(res), 2 if res is not None else 0, _ptr(y), 0, None, st), "apply")), (3 if res is not None else 2) * tb)
     out["bn_bwd_reduce_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_reduce(
-        _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), st), "reduce")), 2 * tb)
+        _ptr(x), _ptr(dy), 0, dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), None, st), "reduce")), 2 * tb)
     out["bn_bwd_dx_kernel"] = (run(lambda: check(lib.hd_bn_act_bwd_dx(
         _ptr(x), _ptr(dy), 0, dt, R, 0, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b), code, None, _ptr(dsums), _ptr(y),
-        None, _ptr(dg[0]), _ptr(dg[1]), st), "dx")), 3 * tb)
+        None, _ptr(dg[0]), _ptr(dg[1]), None, st), "dx")), 3 * tb)
     return out
 
 

@@ -366,6 +366,18 @@ hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, con
  *   backward: _bwd_reduce accumulates (sum dz, sum dz*xhat) into dsums (ZEROED BY THE CALLER),
  *             dz = dy*act'(z) with z recomputed from x; _bwd_dx writes dx and dgamma/dbeta. */
 int hd_bn_act_replicas(void);
+/* Optional SECOND PLACE of a [R, C] operand of the fused BN kernels (y of _apply / _infer, dy of the backward pair):
+ * channels [0, split) live at the primary pointer (row stride given beside it; 0 = dense over `split` channels),
+ * channels [split, C) at p2 with row stride ld2 (0 = dense over C - split).  NULL (or p2 == NULL) = one place.
+ * Serves the merged branch convolutions of a C3 block (cv1 | cv2 as ONE convolution + ONE BatchNorm): the first half
+ * of the activation is a dense tensor for the bottleneck stack, the second half is written straight into the slot of
+ * the block's concatenation; backward reads the two incoming gradients from where they are.  split, ld2: multiples of
+ * the vector width (4 f32 / 8 bf16); p2 16-byte aligned. */
+typedef struct hd_rows2 {
+  const void* p2;
+  int64_t ld2;
+  int split;
+} hd_rows2;
 hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C, float* sums, hd_stream stream);
 /* stat_rows (apply, bwd_dx): rows the (d)sums cover; 0 = R.  > R when the caller all-reduced the sums across
  * ranks between the two launches (synchronised BatchNorm over a data-parallel group). */
@@ -373,7 +385,7 @@ hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean,
                           float* save_invstd, int act, const void* res, int res_mode, void* y,
-                          int64_t y_row_stride, hd_stream stream);
+                          int64_t y_row_stride, const hd_rows2* y_tail, hd_stream stream);
 /* y_row_stride (apply, infer): elements between consecutive rows of y; 0 (or C) = dense, > C = y is a channel slice of a
  * wider channels-last tensor — the slot of a following concatenation, so the activation is written where torch.cat
  * would otherwise copy it (multiple of the vector width). */
@@ -383,16 +395,18 @@ hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows
  * writes d(res) = dz into dres; for mode 2 d(res) is dy itself and the backward entry points are called with NULL. */
 hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var,
-                          float eps, int act, void* y, int64_t y_row_stride, hd_stream stream);
+                          float eps, int act, void* y, int64_t y_row_stride, const hd_rows2* y_tail,
+                          hd_stream stream);
 /* dy_row_stride: elements between consecutive rows of dy; 0 (or C) = dense rows, > C = dy is a channel slice
  * of a wider channels-last tensor (the gradient of a concatenation input), multiple of the vector width. */
 hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R, int C,
                                const float* save_mean, const float* save_invstd, const float* gamma,
-                               const float* beta, int act, const void* res, float* dsums, hd_stream stream);
+                               const float* beta, int act, const void* res, float* dsums, const hd_rows2* dy_tail,
+                               hd_stream stream);
 hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride, int dtype, int64_t R,
                            int64_t stat_rows, int C, const float* save_mean, const float* save_invstd, const float* gamma,
                            const float* beta, int act, const void* res, const float* dsums, void* dx,
-                           void* dres, float* dgamma, float* dbeta, hd_stream stream);
+                           void* dres, float* dgamma, float* dbeta, const hd_rows2* dy_tail, hd_stream stream);
 
 /* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
 

@@ -94,3 +94,61 @@ def test_yolov5_step_with_in_place_concatenation_matches_torch_cat(gpu):
         got = [f.float().cpu() for f in model.extract(img)]
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_two_place_output_and_gradient(gpu, dtype):
+    """hd_rows2: the fused BN writes channels [0, split) to a dense tensor and [split, C) into a concatenation slot
+    (the merged cv1 | cv2 convolution of a C3 block), and its backward reads the two incoming gradients in place.
+    Reference: the same kernels with one dense output, sliced by torch."""
+    from heltondetection_amd import ops
+    torch.manual_seed(1)
+    B, H, W, C1, C2 = 3, 12, 20, 32, 32
+    x = _cl(torch.randn((B, C1 + C2, H, W), device=gpu).to(dtype)).requires_grad_(True)
+    w = torch.rand(C1 + C2, device=gpu, requires_grad=True)
+    b = torch.randn(C1 + C2, device=gpu, requires_grad=True)
+    ga = _cl(torch.randn((B, C1, H, W), device=gpu).to(dtype))
+    gcat = _cl(torch.randn((B, 48 + C2, H, W), device=gpu).to(dtype))     # gradient of a [48 | C2] concatenation
+
+    def run(split):
+        for t in (x, w, b):
+            t.grad = None
+        ops.bn_arena_reset(gpu)
+        if split:
+            buf = ops.CatBuffer(x, [48, C2])
+            y1 = torch.empty((B, C1, H, W), dtype=dtype, device=gpu, memory_format=torch.channels_last)
+            a, c = ops.bn_act(x, w, b, None, None, 1e-3, 0.03, "silu", True, out=(y1, buf.slot(1)))
+            assert a.data_ptr() == y1.data_ptr() and buf.in_place(1, c)
+            torch.autograd.backward([a, c], [ga, gcat[:, 48:]])
+        else:
+            y = ops.bn_act(x, w, b, None, None, 1e-3, 0.03, "silu", True)
+            a, c = y[:, :C1], y[:, C1:]
+            torch.autograd.backward([a, c], [ga, gcat[:, 48:]])
+        return a.detach().float().cpu(), c.detach().float().cpu(), [t.grad.detach().float().cpu() for t in (x, w, b)]
+
+    a0, c0, g0 = run(False)
+    a1, c1, g1 = run(True)
+    assert torch.equal(a0, a1) and torch.equal(c0, c1)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for p, q in zip(g0, g1):
+        assert float((p - q).abs().max()) <= tol * max(1.0, float(q.abs().max()))
+    # inference (running statistics) with the same two places
+    rm, rv = torch.randn(C1 + C2, device=gpu), torch.rand(C1 + C2, device=gpu) + 0.5
+    with torch.no_grad():
+        ref = ops.bn_act(x, w, b, rm, rv, 1e-3, 0.03, "silu", False)
+        buf = ops.CatBuffer(x, [48, C2])
+        y1 = torch.empty((B, C1, H, W), dtype=dtype, device=gpu, memory_format=torch.channels_last)
+        a, c = ops.bn_act(x, w, b, rm, rv, 1e-3, 0.03, "silu", False, out=(y1, buf.slot(1)))
+    assert torch.equal(a, ref[:, :C1]) and torch.equal(c, ref[:, C1:])
+
+
+def test_c3_state_dict_round_trip_to_public_naming():
+    from heltondetection_amd.layers import C3
+    blk = C3(32, 64, n=2)
+    sd = blk.state_dict()
+    pub = C3.split_state_dict(sd, "")
+    assert "cv1.conv.weight" in pub and "cv2.bn.running_var" in pub and not any(k.startswith("cv12.") for k in pub)
+    assert pub["cv1.conv.weight"].shape == (32, 32, 1, 1)
+    back = C3.merge_state_dict(pub, "")
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    blk.load_state_dict(back, strict=True)

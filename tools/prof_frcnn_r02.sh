@@ -9,7 +9,7 @@ WARM=${WARM:-6}
 (cd $R && timeout -k 10 820 python3 bench.py --model frcnn --steps $STEPS --warmup $WARM --no-micro > gpurun_out/r02_frcnn_bench.log 2> gpurun_out/r02_frcnn_bench.err)
 echo "bench rc=$?"; tail -2 $R/gpurun_out/r02_frcnn_bench.err | cut -c1-300
 rm -rf /tmp/pfr2
-(cd $R && timeout -k 10 330 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfr2 -- python3 bench.py --model frcnn --steps $STEPS --warmup $WARM --no-micro > gpurun_out/r02_frcnn_bench_profiled.log 2> gpurun_out/r02_frcnn_bench_profiled.err)
+(cd $R && timeout -k 10 330 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfr2 -- python3 bench.py --model frcnn --steps $STEPS --warmup $WARM --no-micro --no-roofline --no-cpu-baseline > gpurun_out/r02_frcnn_bench_profiled.log 2> gpurun_out/r02_frcnn_bench_profiled.err)
 echo "profiled rc=$?"
 f=$(ls /tmp/pfr2/*/*kernel_stats.csv | head -1)
 cp $f $R/gpurun_out/r02_frcnn_kernel_stats.csv
