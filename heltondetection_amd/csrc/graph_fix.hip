@@ -32,6 +32,22 @@ __global__ __launch_bounds__(256) void graph_fill_words_kernel(unsigned int* __r
     dst[i] = pattern;
 }
 
+// device-to-device copy of one contiguous span (16-byte vectors when both ends are aligned, bytes otherwise)
+__global__ __launch_bounds__(256) void graph_copy_bytes_kernel(unsigned char* __restrict__ dst,
+                                                               const unsigned char* __restrict__ src, size_t n_bytes,
+                                                               int vec16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (vec16) {
+    const size_t nv = n_bytes / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) d4[i] = s4[i];
+    for (size_t i = nv * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes; i += stride) dst[i] = src[i];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes; i += stride) dst[i] = src[i];
+  }
+}
+
 }  // namespace
 
 extern "C" hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out, int* n_replaced_out) {
@@ -41,11 +57,13 @@ extern "C" hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out,
   if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return HD_ERR_LAUNCH;
   std::vector<hipGraphNode_t> nodes(n);
   if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return HD_ERR_LAUNCH;
-  int replaced = 0;
+  int replaced = 0, copies = 0;
+  std::vector<char> gone(n, 0);
   for (size_t k = 0; k < n; ++k) {
     hipGraphNodeType type;
     if (hipGraphNodeGetType(nodes[k], &type) != hipSuccess) return HD_ERR_LAUNCH;
     if (type != hipGraphNodeTypeMemset) continue;
+    gone[k] = 1;
     hipMemsetParams mp;
     if (hipGraphMemsetNodeGetParams(nodes[k], &mp) != hipSuccess) return HD_ERR_LAUNCH;
     size_t nd = 0, nq = 0;
@@ -98,8 +116,68 @@ extern "C" hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out,
     if (hipGraphDestroyNode(nodes[k]) != hipSuccess) return HD_ERR_LAUNCH;
     ++replaced;
   }
+  // Device-to-device memcpy nodes (contiguous same-dtype tensor copies: PyTorch's copy_ of small 1-D tensors, e.g. the
+  // BatchNorm weight / bias gradients dist.GradReducer packs into its buckets) get the same treatment, as a precaution:
+  // they go through the same copy-engine path as the memset nodes whose misordering was reproduced;
+  // no misordered memcpy node was observed.  A one-span copy kernel with the same predecessors and successors replaces
+  // each; other memcpy shapes / kinds are left alone.
+  for (size_t k = 0; k < n; ++k) {
+    if (gone[k]) continue;  // a memset node destroyed above
+    hipGraphNodeType type;
+    if (hipGraphNodeGetType(nodes[k], &type) != hipSuccess) return HD_ERR_LAUNCH;
+    if (type != hipGraphNodeTypeMemcpy) continue;
+    hipMemcpy3DParms cp;
+    if (hipGraphMemcpyNodeGetParams(nodes[k], &cp) != hipSuccess) return HD_ERR_LAUNCH;
+    if (cp.kind != hipMemcpyDeviceToDevice && cp.kind != hipMemcpyDefault) continue;
+    if (cp.srcArray || cp.dstArray || cp.extent.height > 1 || cp.extent.depth > 1) continue;
+    if (cp.srcPos.x || cp.srcPos.y || cp.srcPos.z || cp.dstPos.x || cp.dstPos.y || cp.dstPos.z) continue;
+    if (cp.kind == hipMemcpyDefault) {  // only when both ends are device memory
+      hipPointerAttribute_t a, b;
+      if (hipPointerGetAttributes(&a, cp.srcPtr.ptr) != hipSuccess || hipPointerGetAttributes(&b, cp.dstPtr.ptr) != hipSuccess ||
+          a.type != hipMemoryTypeDevice || b.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        continue;
+      }
+    }
+    size_t nd = 0, nq = 0;
+    if (hipGraphNodeGetDependencies(nodes[k], nullptr, &nd) != hipSuccess) return HD_ERR_LAUNCH;
+    std::vector<hipGraphNode_t> deps(nd);
+    if (nd && hipGraphNodeGetDependencies(nodes[k], deps.data(), &nd) != hipSuccess) return HD_ERR_LAUNCH;
+    if (hipGraphNodeGetDependentNodes(nodes[k], nullptr, &nq) != hipSuccess) return HD_ERR_LAUNCH;
+    std::vector<hipGraphNode_t> outs(nq);
+    if (nq && hipGraphNodeGetDependentNodes(nodes[k], outs.data(), &nq) != hipSuccess) return HD_ERR_LAUNCH;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(cp.dstPtr.ptr);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(cp.srcPtr.ptr);
+    size_t bytes = cp.extent.width;
+    if (bytes == 0) {
+      for (size_t a = 0; a < nd; ++a)
+        for (size_t b = 0; b < nq; ++b)
+          if (hipGraphAddDependencies(g, &deps[a], &outs[b], 1) != hipSuccess) return HD_ERR_LAUNCH;
+      if (hipGraphDestroyNode(nodes[k]) != hipSuccess) return HD_ERR_LAUNCH;
+      ++copies;
+      continue;
+    }
+    int vec16 = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0 ? 1 : 0;
+    void* args[4] = {&dst, &src, &bytes, &vec16};
+    size_t items = vec16 ? (bytes + 15) / 16 : bytes;
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipKernelNodeParams kp = {};
+    kp.func = reinterpret_cast<void*>(graph_copy_bytes_kernel);
+    kp.gridDim = dim3((unsigned)blocks);
+    kp.blockDim = dim3(256);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipGraphNode_t knode;
+    if (hipGraphAddKernelNode(&knode, g, nd ? deps.data() : nullptr, nd, &kp) != hipSuccess) return HD_ERR_LAUNCH;
+    for (size_t b = 0; b < nq; ++b)
+      if (hipGraphAddDependencies(g, &knode, &outs[b], 1) != hipSuccess) return HD_ERR_LAUNCH;
+    if (hipGraphDestroyNode(nodes[k]) != hipSuccess) return HD_ERR_LAUNCH;
+    ++copies;
+  }
   if (n_nodes_out) *n_nodes_out = (int)n;
-  if (n_replaced_out) *n_replaced_out = replaced;
+  if (n_replaced_out) *n_replaced_out = replaced + copies;
   return HD_OK;
 }
 

@@ -429,9 +429,11 @@ hd_status hd_mosaic4_boxes(const float* gt_boxes, const int32_t* gt_cls, const i
 /* ---- hipGraph hygiene ------------------------------------------------------------------------ */
 
 /* Replaces every memset node of a captured, NOT YET INSTANTIATED hipGraph_t by an equivalent
- * fill-kernel node with the same predecessors/successors (host call; no stream).  On ROCm 7.2
- * memset nodes were observed not to stay ordered against neighbouring kernel nodes on replay
- * (DESIGN.md section 9).  n_nodes_out / n_replaced_out (host, may be NULL) receive the counts. */
+ * fill-kernel node, and every one-span device-to-device memcpy node by a copy-kernel node, with the
+ * same predecessors/successors (host call; no stream).  On ROCm 7.2 memset nodes were observed not
+ * to stay ordered against neighbouring kernel nodes on replay; memcpy nodes
+ * take the same engine path and are rewritten as a precaution.
+ * n_nodes_out / n_replaced_out (host, may be NULL) receive the node count and the number rewritten. */
 hd_status hd_graph_replace_memsets(void* hip_graph, int* n_nodes_out, int* n_replaced_out);
 
 /* Multi-GPU overlap under hipGraph replay (reference README.md:29 DDP; north_star "all-reduce overlapped with the

@@ -39,10 +39,13 @@ def _worker(rank, world, port, tmp, use_graph):
     model = build_detector(dict(type="YOLOv5", variant="n", num_classes=8, img_size=128)).to(dev)
     model = model.to(memory_format=torch.channels_last).train()
     # 256 KiB buckets: the 1.8 M parameters of the `n` model spread over many buckets -> many segments
-    # lr = 1e-7: AdamW moves every weight by ~lr per step whatever the gradient's size, so after 8 steps the two runs
-    # still sit at (numerically) the same point and their REDUCED GRADIENTS can be compared sharply; with a real
-    # learning rate Adam amplifies last-bit differences of near-zero gradients into sign flips of the update
-    tr = Trainer(model, lr=1e-7, amp_dtype=None, total_steps=40, warmup_steps=2, bucket_bytes=1 << 20, device=dev,
+    # lr = 0: the parameters never move, so every step of both runs evaluates the SAME function and the reduced
+    # gradients can be compared sharply at any step.  (With any positive learning rate, however tiny, AdamW moves each
+    # weight by ~lr per step in the direction of a possibly noise-level gradient sign; the YOLO box loss has kinks —
+    # CIoU's enclosing-box min/max — and on a 4-image batch a single matched cell crossing one changes a level's
+    # gradient by >10 %: two correct runs then differ discretely from some step on.  Seen and pinned down with
+    # scratch probes this round: eager runs differ from each other the same way.)
+    tr = Trainer(model, lr=0.0, amp_dtype=None, total_steps=40, warmup_steps=2, bucket_bytes=1 << 20, device=dev,
                  use_graph=use_graph, graph_warmup=2)
     assert len(tr.reducer.buckets) >= 3
     launches = []
@@ -105,7 +108,9 @@ def test_two_rank_split_graph_replay_matches_eager(gpu, tmp_path):
     # reorder sums, so not bit-equal)
     num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["grads"], e0["grads"]))
     den = sum(float((b ** 2).sum()) for b in e0["grads"])
-    assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+    worst = sorted(((float(((a - b) ** 2).sum() / ((b ** 2).sum() + 1e-30)) ** 0.5, i, tuple(b.shape))
+                    for i, (a, b) in enumerate(zip(g0["grads"], e0["grads"]))), reverse=True)[:6]
+    assert den > 0 and (num / den) ** 0.5 < 1e-3, ((num / den) ** 0.5, worst, g0["losses"], e0["losses"])
     assert all(abs(x - y) < 1e-3 * max(abs(y), 1.0) for x, y in zip(g0["losses"], e0["losses"]))
     # no multi-second stall on any replayed step (second hazard)
     assert max(g0["times"][3:]) < 2.0 and max(g1["times"][3:]) < 2.0, (g0["times"], g1["times"])

@@ -278,14 +278,16 @@ def test_yolov5l_640_bs16_graph_replayed_steps(gpu):
         model = build_detector(dict(type="YOLOv5", variant="l", num_classes=80, img_size=640)).to(gpu)
         model = model.to(memory_format=torch.channels_last).train()
         assert sum(p.numel() for p in model.parameters()) > 40e6   # the `l` preset (46.5 M parameters), not `s`
-        tr = Trainer(model, lr=1e-3, total_steps=40, warmup_steps=2, device=gpu, use_graph=True, graph_warmup=2)
+        tr = Trainer(model, lr=1e-3, total_steps=60, warmup_steps=2, device=gpu, use_graph=True, graph_warmup=2)
         batch = _batch(16, 640, 80, 5, gpu, m_pad=40)
-        losses = [float(tr.step(*batch)[0]) for _ in range(12)]
+        losses = [float(tr.step(*batch)[0]) for _ in range(24)]
         assert tr._graph is not None, tr.graph_error
         assert tr.graph_nodes > 500
         assert np.isfinite(losses).all(), losses
         replayed = losses[3:]                                      # >= 8 graph-replayed steps
-        assert len(replayed) >= 8 and replayed[-1] < replayed[0] and losses[-1] < losses[0], losses
+        # the first dozen AdamW steps of a random-init `l` model at lr 1e-3 plateau (eager and replayed alike,
+        # scratch/graph_probe3.py); "decreasing" is judged on window means over 21 replayed steps
+        assert len(replayed) >= 8 and np.mean(replayed[-4:]) < np.mean(replayed[:4]) and losses[-1] < losses[0], losses
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     finally:
         torch.backends.cudnn.benchmark = was
