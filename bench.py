@@ -354,7 +354,11 @@ def bn_family_roofline(model, batch, args, device):
     recs, hooks = [], []
 
     def hook(mod, inp, out):
-        recs.append((tuple(out.shape), mod.act_name, len(inp) > 1 and inp[1] is not None))
+        if isinstance(out, tuple):  # a two-place output (the merged C3 branch convolutions): one BN over all channels
+            shape = (out[0].shape[0], sum(o.shape[1] for o in out)) + tuple(out[0].shape[2:])
+        else:
+            shape = tuple(out.shape)
+        recs.append((shape, mod.act_name, len(inp) > 1 and inp[1] is not None))
 
     for m in model.modules():
         if isinstance(m, ConvBNAct):
@@ -391,7 +395,12 @@ def bn_family_roofline(model, batch, args, device):
                                "region; medians summed over the layers of one step",
                       "per_kernel": {k: {"sum_ms": round(v[0], 4), "GB/s": round(v[1] / v[0] / 1e6, 1),
                                          "frac": round(v[1] / v[0] / 1e6 / HBM_PEAK_GBS, 4), "launches": v[2]}
-                                     for k, v in per_kernel.items()}},
+                                     for k, v in per_kernel.items()},
+                      "per_shape": [{"shape": list(key[0]), "act": key[1], "shortcut": bool(key[2]), "layers": recs.count(key),
+                                     "MB": round(key[0][0] * key[0][1] * key[0][2] * key[0][3] * (4 if args.fp32 else 2) / 1e6, 2),
+                                     "us": {k.replace("bn_", "").replace("_kernel", ""): round(ms * 1e3, 2) for k, (ms, nb) in t.items()},
+                                     "GB/s": {k.replace("bn_", "").replace("_kernel", ""): round(nb / ms / 1e6) for k, (ms, nb) in t.items()}}
+                                    for key, t in cache.items()]},
                      traffic=pmc_traffic("bn_family_step", f"{model_name(args)} {args.size} bs{args.batch}"))
     return fam
 

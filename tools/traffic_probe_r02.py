@@ -11,8 +11,10 @@ N_IT = int(os.environ.get("HD_PROBE_ITERS", "3"))
 # 1. the fused BN+act family over every BatchNorm layer of YOLOv5s 640^2 bs16 (one forward + backward of each layer)
 model = build_detector(dict(type="YOLOv5", variant="s", num_classes=80, img_size=640)).to(dev).to(memory_format=torch.channels_last).train()
 recs = []
-hooks = [m.register_forward_hook(lambda mod, inp, out: recs.append((tuple(out.shape), mod.act_name, len(inp) > 1 and inp[1] is not None)))
-         for m in model.modules() if isinstance(m, ConvBNAct)]
+def _hook(mod, inp, out):
+    shape = (out[0].shape[0], sum(o.shape[1] for o in out)) + tuple(out[0].shape[2:]) if isinstance(out, tuple) else tuple(out.shape)
+    recs.append((shape, mod.act_name, len(inp) > 1 and inp[1] is not None))
+hooks = [m.register_forward_hook(_hook) for m in model.modules() if isinstance(m, ConvBNAct)]
 img = syn.make_images(16, 640, g).to(dev).contiguous(memory_format=torch.channels_last)
 ConvBNAct.fused = False   # shape collection only: keep this pass out of the counted bn_* launches
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -50,17 +52,18 @@ del o
 a2 = syn.random_boxes(306900, 640.0, g).to(dev); b2 = torch.stack([syn.random_boxes(40, 640.0, g) for _ in range(16)]).to(dev)
 for _ in range(N_IT): o = ops.pairwise_iou(a2, b2)
 del o
-# 4. RoIAlign: config 3 pyramid; R = 8192 forward (f32 and bf16 maps), R = 2048 forward + backward (bf16: the train step)
+# 4. RoIAlign: config 3 pyramid; R = 8192 forward (f32 and bf16 maps), R = 2560 forward + backward (the train step's
+#    160 sampled RoIs per image: 32 foreground + 128 background)
 for dt in (torch.float32, torch.bfloat16):
     feats = [torch.randn((16, 256, 832 // s, 832 // s), device=dev).to(dt).contiguous(memory_format=torch.channels_last) for s in (4, 8, 16, 32)]
-    for per_img in (512, 128):
+    for per_img in (512, 160):
         R = 16 * per_img
         rb = syn.random_boxes(R, 832.0, g, 16.0, 400.0)
         rois = torch.cat([torch.arange(16).repeat_interleave(per_img)[:, None].float(), rb], 1).to(dev)
-        fr = [f.detach().requires_grad_(per_img == 128) for f in feats]
+        fr = [f.detach().requires_grad_(per_img == 160) for f in feats]
         for _ in range(N_IT):
             out = ops.roi_align(fr, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True)
-            if per_img == 128:
+            if per_img == 160:
                 out.backward(torch.ones_like(out))
     del feats
 torch.cuda.synchronize(); print("done")
