@@ -346,9 +346,11 @@ def _hbm_entry(kernel, ms, nbytes, launches, extra=None, traffic=None):
 
 
 def bn_family_roofline(model, batch, args, device):
-    """Step-weighted roofline of the fused BN+act kernels: every BatchNorm layer of the model (shape, activation,
-    shortcut variant recorded by forward hooks on a real forward pass of this workload), the four kernels of each
-    timed with HIP events on the launch stream; achieved = sum of algorithmic bytes / sum of launch times."""
+    """Step-weighted roofline of the fused BN+act kernels, measured IN the train step: three eager forward + loss +
+    backward passes of this workload with every fused-BN launch stamping its own HIP event pair (kernel begin / end,
+    hd_debug_time_next_launch), so each kernel is timed on its real tensors in its real cache state (x fresh from the
+    convolution for stats / apply, x cold and dy fresh for the backward pair) — what a profiler reports for the same
+    launches inside the replayed graph.  achieved = algorithmic bytes of all launches of a step / their summed time."""
     from heltondetection_amd import ops
     from heltondetection_amd.layers import ConvBNAct
     recs, hooks = [], []
@@ -363,44 +365,68 @@ def bn_family_roofline(model, batch, args, device):
     for m in model.modules():
         if isinstance(m, ConvBNAct):
             hooks.append(m.register_forward_hook(hook))
+    names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
+    passes, per_pass = 3, []
     try:
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
-            model.extract(batch[0])
+        for it in range(passes + 1):  # the first pass warms up and fills `recs`
+            if it == 1:
+                for h in hooks:
+                    h.remove()
+                hooks = []
+            model.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(device)
+            if it >= 1:
+                ops.enable_timing(*names)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+                loss, _ = model.forward_train(*batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            if it >= 1:
+                per_pass.append({k: v for k, v in ops.collect_timing().items()})
+                ops.disable_timing()
     finally:
+        ops.disable_timing()
         for h in hooks:
             h.remove()
-    dtype = torch.float32 if args.fp32 else torch.bfloat16
-    cache, per_kernel = {}, {}
-    tot_ms = tot_bytes = 0.0
-    for key in recs:
-        if key not in cache:
-            shape, act, res = key
-            cache[key] = ops.time_bn_act_kernels(shape, dtype, act, iters=12, device=device, residual_after_act=res)
-        for k, (ms, nb) in cache[key].items():
-            a = per_kernel.setdefault(k, [0.0, 0.0, 0])
-            a[0] += ms
-            a[1] += nb
-            a[2] += 1
-            tot_ms += ms
-            tot_bytes += nb
-    n_launch = 4 * len(recs)
-    sizes = sorted({int(s[0] * s[1] * s[2] * s[3] * (4 if args.fp32 else 2)) for s, _, _ in recs})
+        model.zero_grad(set_to_none=True)
+    esz = 4 if args.fp32 else 2
+    tb = [s[0] * s[1] * s[2] * s[3] * esz for s, _, _ in recs]
+    # algorithmic tensor passes: stats 1, apply 2 (+1 with a fused shortcut read), bwd_reduce 2, bwd_dx 3
+    bytes_k = {"bn_stats_kernel": sum(tb), "bn_apply_kernel": sum((3 if r[2] else 2) * t for r, t in zip(recs, tb)),
+               "bn_bwd_reduce_kernel": 2 * sum(tb), "bn_bwd_dx_kernel": 3 * sum(tb)}
+    med = lambda v: sorted(v)[len(v) // 2]
+    ms_k = {k: med([sum(p[k]) for p in per_pass]) for k in names}
+    n_k = {k: len(per_pass[0][k]) for k in names}
+    tot_ms, tot_bytes, n_launch = sum(ms_k.values()), sum(bytes_k.values()), sum(n_k.values())
+    sizes = sorted(set(tb))
+    # per layer shape (forward order of the first occurrence): the launch times of the middle pass
+    mid = per_pass[len(per_pass) // 2]
+    by_shape = {}
+    for i, key in enumerate(recs):
+        e = by_shape.setdefault(key, {"layers": 0, "us": {k: 0.0 for k in names}})
+        e["layers"] += 1
+        e["us"]["bn_stats_kernel"] += mid["bn_stats_kernel"][i] * 1e3
+        e["us"]["bn_apply_kernel"] += mid["bn_apply_kernel"][i] * 1e3
+        j = len(recs) - 1 - i  # backward visits the layers in reverse order
+        e["us"]["bn_bwd_reduce_kernel"] += mid["bn_bwd_reduce_kernel"][j] * 1e3 if j < len(mid["bn_bwd_reduce_kernel"]) else 0.0
+        e["us"]["bn_bwd_dx_kernel"] += mid["bn_bwd_dx_kernel"][j] * 1e3 if j < len(mid["bn_bwd_dx_kernel"]) else 0.0
     fam = _hbm_entry("fused BN+act family (bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_dx), step-weighted over the "
                      f"model's {len(recs)} BatchNorm layers", tot_ms, tot_bytes, n_launch,
                      {"bn_layers": len(recs), "launches_per_step": n_launch, "sum_launch_ms_per_step": round(tot_ms, 4),
-                      "algorithmic_bytes_per_step": int(tot_bytes), "distinct_layer_shapes": len(cache),
-                      "layer_bytes_min_max": [sizes[0], sizes[-1]] if sizes else None,
-                      "timed": "every launch stamps its own HIP event pair with the kernel's begin / end (hipExtLaunchKernel through "
-                               "hd_debug_time_next_launch) on the launch stream, 12 launches per (kernel, layer shape), right after the timed "
-                               "region; medians summed over the layers of one step",
-                      "per_kernel": {k: {"sum_ms": round(v[0], 4), "GB/s": round(v[1] / v[0] / 1e6, 1),
-                                         "frac": round(v[1] / v[0] / 1e6 / HBM_PEAK_GBS, 4), "launches": v[2]}
-                                     for k, v in per_kernel.items()},
-                      "per_shape": [{"shape": list(key[0]), "act": key[1], "shortcut": bool(key[2]), "layers": recs.count(key),
-                                     "MB": round(key[0][0] * key[0][1] * key[0][2] * key[0][3] * (4 if args.fp32 else 2) / 1e6, 2),
-                                     "us": {k.replace("bn_", "").replace("_kernel", ""): round(ms * 1e3, 2) for k, (ms, nb) in t.items()},
-                                     "GB/s": {k.replace("bn_", "").replace("_kernel", ""): round(nb / ms / 1e6) for k, (ms, nb) in t.items()}}
-                                    for key, t in cache.items()]},
+                      "algorithmic_bytes_per_step": int(tot_bytes), "distinct_layer_shapes": len(by_shape),
+                      "layer_bytes_min_max": [int(sizes[0]), int(sizes[-1])] if sizes else None,
+                      "timed": "inside 3 eager forward+loss+backward passes of this workload right after the timed region: every "
+                               "fused-BN launch stamps its own HIP event pair with the kernel's begin / end (hipExtLaunchKernel "
+                               "through hd_debug_time_next_launch) on the launch stream; per kernel the summed time of a pass, "
+                               "median over the passes",
+                      "per_kernel": {k: {"sum_ms": round(ms_k[k], 4), "GB/s": round(bytes_k[k] / ms_k[k] / 1e6, 1),
+                                         "frac": round(bytes_k[k] / ms_k[k] / 1e6 / HBM_PEAK_GBS, 4), "launches": n_k[k]}
+                                     for k in names},
+                      "per_shape": [{"shape": list(key[0]), "act": key[1], "shortcut": bool(key[2]), "layers": e["layers"],
+                                     "MB": round(key[0][0] * key[0][1] * key[0][2] * key[0][3] * esz / 1e6, 2),
+                                     "us_per_layer": {k.replace("bn_", "").replace("_kernel", ""): round(v / e["layers"], 2)
+                                                      for k, v in e["us"].items()}}
+                                    for key, e in by_shape.items()]},
                      traffic=pmc_traffic("bn_family_step", f"{model_name(args)} {args.size} bs{args.batch}"))
     return fam
 

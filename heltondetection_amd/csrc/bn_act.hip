@@ -535,7 +535,9 @@ extern "C" hd_status hd_bn_act_stats(const void* x, int dtype, int64_t R, int C,
   if (!hd_aligned16(x)) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
+  // ~8 vectors per lane, <= 2 workgroups per CU (re-swept inside the train step, where x arrives cold for the backward
+  // pair: 4 / 2 vectors per lane and 1024 / 2048 workgroups are all within 3 % or worse, profiles/r02_bn_in_step.md)
+  const Launch l = plan(nvec / 8 + 1, C / V, 512);
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   if (dtype == 0)
     (void)hd_launch(bn_stats_kernel<float>, dim3(l.grid), dim3(l.block), lds, (hipStream_t)stream,

@@ -147,10 +147,7 @@ template <int C, int NCH>
 __global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __restrict__ a, int64_t a_bstride4,
                                                                 const float4* __restrict__ b,
                                                                 const int32_t* __restrict__ m_valid, int N, int M,
-                                                                int rpw, int split, float* __restrict__ out) {
-  // split > 1 (NCH == 1 only): `split` consecutive waves share one row tile and take one 64*C-column span each, so a
-  // wave keeps C boxes instead of NCH*C in registers (~60 VGPRs instead of ~110: twice the waves in flight to feed
-  // the store path) while the two halves of every output row are still written within a few instructions of each other.
+                                                                int rpw, float* __restrict__ out) {
   const int img = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mv = m_valid ? min(m_valid[img], M) : M;
@@ -159,18 +156,14 @@ __global__ __launch_bounds__(256) void pairwise_iou_cols_kernel(const float4* __
   float* __restrict__ o = out + (int64_t)img * N * M;
   // rpw rows per wave (8, 16 or 32; the host picks fewer rows per wave when the grid would otherwise run as only a
   // handful of rounds of resident waves: the last, partly filled round then costs a whole tile time)
-  const int gw = blockIdx.x * 4 + wave;       // global wave index within the image
-  const int tile = gw / split, my_span = gw - tile * split;
-  const int base = tile * rpw;
+  const int base = (blockIdx.x * 4 + wave) * rpw;
   const int nr = max(0, min(rpw, N - base));
   if (nr == 0) return;
   const float4 rb = lane < nr ? aa[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float ra = hd_box_area(rb);
   const bool rows_unsafe = lane < nr && !hd_box_div_safe_pos(rb);
   constexpr int span = 64 * C;
-  const int s_first = split > 1 ? my_span * span : 0;
-  const int s_last = split > 1 ? min(M, s_first + span) : M;
-  for (int s0 = s_first; s0 < s_last; s0 += span * NCH) {
+  for (int s0 = 0; s0 < M; s0 += span * NCH) {
     float4 g[NCH][C];
     float ga[NCH][C];
     bool ok[NCH];
@@ -520,19 +513,17 @@ extern "C" hd_status hd_pairwise_iou(const float* a, int64_t a_bstride, const fl
     if (M % 4 == 0 && hd_aligned16(out) && util(4) >= 0.7) C = 4;
     else if (M % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && util(2) >= 0.7) C = 2;
     const int spans = (M + 64 * C - 1) / (64 * C);
-    // spans 2 or 4: one span per wave, `spans` waves per row tile (see the kernel); 3: all three in one wave's
-    // registers (rows-outer); more: span-outer
-    const int split = (spans == 2 || spans == 4) ? spans : 1;
-    const int nch = split > 1 ? 1 : (spans <= 3 ? spans : 1);
-    // rows per wave: 32 when that still gives >= ~8 rounds of resident waves (>= 16 per CU x 256 CUs), else 16 or 8
+    const int nch = spans <= 3 ? spans : 1;  // rows-outer when the whole row fits in registers
+    // (tried and dropped: one 64*C-column span per wave with 2 / 4 waves sharing a row tile — half the registers, twice
+    // the waves in flight — measured the same 5.0-5.5 TB/s: the kernel is on the store path's side of the roofline)
+    // rows per wave: 32 when that still gives >= ~8 rounds of resident waves (16 per CU x 256 CUs), else 16 or 8
     // (measured: 16 x 25200 x 512 runs 5.0 / 5.3 / 5.6 TB/s at 32 / 16 / 8 rows, 2 x 409200 x 500 prefers 16-32)
     int rpw = 32;
-    while (rpw > 8 && (int64_t)B * ((N + rpw - 1) / rpw) * split < 8ll * 4096) rpw >>= 1;
-    const int64_t waves = (int64_t)((N + rpw - 1) / rpw) * split;
-    dim3 cgrid((unsigned)((waves + 3) / 4), (unsigned)B);
+    while (rpw > 8 && (int64_t)B * ((N + rpw - 1) / rpw) < 8ll * 4096) rpw >>= 1;
+    dim3 cgrid((unsigned)((N + 4 * rpw - 1) / (4 * rpw)), (unsigned)B);
 #define HD_LAUNCH_COLS(CC, NN)                                                                                      \
   (void)hd_launch(pairwise_iou_cols_kernel<CC, NN>, cgrid, dim3(256), 0, s, a4c, a_bstride / 4, b4c, m_valid, N, \
-                     M, rpw, split, out)
+                     M, rpw, out)
     if (C == 4) {
       if (nch == 1) HD_LAUNCH_COLS(4, 1);
       else if (nch == 2) HD_LAUNCH_COLS(4, 2);

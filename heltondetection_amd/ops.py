@@ -874,7 +874,8 @@ class _BNActFn(torch.autograd.Function):
         save = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
-        check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
+        with _ktimed("bn_stats_kernel"):
+            check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
         stat_rows = 0
         if sync_group is not None:
             # synchronised BatchNorm: the per-channel (sum, sum of squares) of every rank are added between the
@@ -882,10 +883,11 @@ class _BNActFn(torch.autograd.Function):
             import torch.distributed as dist
             dist.all_reduce(sums, group=sync_group)
             stat_rows = R * dist.get_world_size(sync_group)
-        check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
-                                  _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
-                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y),
-                                  C.byref(tail) if tail is not None else None, st), "hd_bn_act_apply")
+        with _ktimed("bn_apply_kernel"):
+            check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
+                                      _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
+                                      _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y),
+                                      C.byref(tail) if tail is not None else None, st), "hd_bn_act_apply")
         # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
         keep_res = res if (res is not None and int(res_mode) == 1) else None
         ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
@@ -930,8 +932,9 @@ class _BNActFn(torch.autograd.Function):
         dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         dres = torch.empty_like(x) if res is not None else None
-        check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
-                                       act, _ptr(res), _ptr(dsums), tail_ref, st), "hd_bn_act_bwd_reduce")
+        with _ktimed("bn_bwd_reduce_kernel"):
+            check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
+                                           act, _ptr(res), _ptr(dsums), tail_ref, st), "hd_bn_act_bwd_reduce")
         local = None
         if sync_group is not None:
             # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
@@ -939,9 +942,10 @@ class _BNActFn(torch.autograd.Function):
             import torch.distributed as dist
             local = dsums.view(rep, 2, Cc).sum(0)
             dist.all_reduce(dsums, group=sync_group)
-        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
-                                   _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), tail_ref,
-                                   st), "hd_bn_act_bwd_dx")
+        with _ktimed("bn_bwd_dx_kernel"):
+            check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
+                                       _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), tail_ref,
+                                       st), "hd_bn_act_bwd_dx")
         # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
         gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
         if local is not None:
