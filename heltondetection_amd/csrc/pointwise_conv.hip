@@ -1,0 +1,687 @@
+// pointwise_conv.hip — 1x1 convolution on channels-last rows as an MFMA GEMM, with the BatchNorm statistics of the
+// fused BN+activation that follows it taken in the epilogue.
+//
+// Why hand-written.  34 of YOLOv5s' 57 convolutions are 1x1, stride 1: on channels-last tensors that is
+//     Y[R, Cout] = X[R, Cin] . W[Cout, Cin]^T          (R = B*H*W rows)
+// with R up to 409 600 and Cin, Cout <= 1024 — a skinny GEMM whose arithmetic intensity (<= Cout flops per input
+// byte) keeps it on the HBM roofline, not the MFMA one.  The library kernels MIOpen picks for these shapes run at
+// 0.2-0.8 of that roofline, and a separate statistics kernel then reads Y again.  Here one persistent launch streams X
+// once, keeps W in LDS / L2, and folds sum(y), sum(y^2) per output channel (of the bf16-rounded y, the values the
+// normalisation will read) into the replicated accumulators of csrc/bn_act.hip, which removes that layer's
+// bn_stats_kernel launch and its pass over Y.
+// The same kernel is the data gradient (dX[R, Cin] = dY[R, Cout] . Wt[Cin, Cout]^T with the transposed weights).
+//
+// Tiling (wave64, 4 waves per workgroup).  A workgroup owns a BM x BN output tile and walks K in BK = 64 (or 32) steps;
+// both operands are K-contiguous, so a tile row is 128 (64) bytes and is staged global -> registers -> LDS in full
+// 16-byte chunks, coalesced over whole rows.  LDS rows are XOR-swizzled at 16-byte granularity
+// (chunk ^ (row / rows_per_256B) % chunks_per_row) so that both the ds_write_b128 of the staging pass and the
+// ds_read_b128 of the fragment reads (16 consecutive rows, same chunk, per 16-lane group) are bank-conflict free.
+// Each wave computes TM x TN tiles of v_mfma_f32_32x32x16_bf16 (lane l holds row/col l & 31, k = 8 (l >> 5) + j).
+// The grid is persistent (<= 512 workgroups = 2 per CU): a workgroup loops over output tiles with the loads of its next
+// (tile, k-step) in flight while it computes the current one from the other LDS buffer, so single-k-step shapes
+// (Cin = 64) still overlap load and compute, and the statistics need one global atomic per channel per workgroup.
+// Workgroup ids are remapped so that consecutive logical ids (the N-tiles of one row block, which share X) run on one
+// XCD and hit in its L2.
+#include <hip/hip_bf16.h>
+
+#include "hd_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int kStatReplicas = 16;  // == hd_bn_act_replicas(), checked on the host
+
+template <int BK>
+struct Tile {  // [rows][BK] bf16 LDS image, 16-byte chunks swizzled
+  static constexpr int CPR = BK / 8;    // chunks per row
+  static constexpr int RPL = 16 / CPR;  // rows per 256-byte bank line
+  __device__ static __forceinline__ int off(int row, int chunk) {
+    return row * (BK * 2) + ((chunk ^ ((row / RPL) % CPR)) << 4);
+  }
+};
+
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short float_to_bf16_bits(float f) {  // round to nearest even (finite inputs; NaN kept)
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool STATS>
+__global__ __launch_bounds__(256) void pointwise_conv_kernel(const unsigned short* __restrict__ A, long long lda,
+                                                             const unsigned short* __restrict__ Bw,
+                                                             unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
+                                                             int K, float* __restrict__ stats) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
+  constexpr int CPR = BK / 8;
+  constexpr int A_CHUNKS = BM * CPR, B_CHUNKS = BN * CPR;
+  constexpr int A_IT = (A_CHUNKS + 255) / 256, B_IT = (B_CHUNKS + 255) / 256;
+  constexpr int BUF_BYTES = (BM + BN) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x [A tile | B tile]; reused for the statistics fold
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int MT = (M + BM - 1) / BM, NT = N / BN, KT = K / BK;
+  const int G = gridDim.x;
+  // consecutive logical ids on one XCD (hardware deals consecutive blockIdx round-robin over the 8 XCDs)
+  const int lb = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  const long long tiles = (long long)MT * NT;
+  const int my_tiles = lb < tiles ? (int)((tiles - 1 - lb) / G) + 1 : 0;
+  const int W = my_tiles * KT;
+
+  uint4 ra[A_IT], rb[B_IT];
+  auto gload = [&](int w) {
+    const long long t = lb + (long long)(w / KT) * G;
+    const int kt = w % KT;
+    const int m0 = (int)(t / NT) * BM, n0 = (int)(t % NT) * BN;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int id = i * 256 + tid;
+      if (A_CHUNKS % 256 == 0 || id < A_CHUNKS) {
+        int m = m0 + id / CPR;
+        m = m < M ? m : M - 1;  // rows past the end re-read the last row; their results are never stored
+        ra[i] = *reinterpret_cast<const uint4*>(A + (long long)m * lda + kt * BK + (id % CPR) * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int id = i * 256 + tid;
+      if (B_CHUNKS % 256 == 0 || id < B_CHUNKS)
+        rb[i] = *reinterpret_cast<const uint4*>(Bw + (long long)(n0 + id / CPR) * K + kt * BK + (id % CPR) * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sa = smem + buf * BUF_BYTES;
+    unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int id = i * 256 + tid;
+      if (A_CHUNKS % 256 == 0 || id < A_CHUNKS) *reinterpret_cast<uint4*>(sa + Tile<BK>::off(id / CPR, id % CPR)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int id = i * 256 + tid;
+      if (B_CHUNKS % 256 == 0 || id < B_CHUNKS) *reinterpret_cast<uint4*>(sb + Tile<BK>::off(id / CPR, id % CPR)) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float s_sum[TN], s_sq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s_sum[j] = s_sq[j] = 0.0f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  if (W > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int w = 0; w < W; ++w) {
+    if (w + 1 < W) gload(w + 1);
+    const unsigned char* sa = smem + (w & 1) * BUF_BYTES;
+    const unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(sa + Tile<BK>::off((wm * TM + i) * 32 + frow, 2 * s + fh));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(sb + Tile<BK>::off((wn * TN + j) * 32 + frow, 2 * s + fh));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (w % KT == KT - 1) {  // the tile is complete: write it (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+      const long long t = lb + (long long)(w / KT) * G;
+      const int m0 = (int)(t / NT) * BM, n0 = (int)(t % NT) * BN;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 32 + frow;
+          const int mb = m0 + (wm * TM + i) * 32 + 4 * fh;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < M) {
+              const unsigned short v = float_to_bf16_bits(acc[i][j][r]);
+              Cmat[(long long)m * ldc + n] = v;
+              if (STATS) {
+                const float f = bf16_bits_to_float(v);
+                s_sum[j] += f;
+                s_sq[j] = fmaf(f, f, s_sq[j]);
+              }
+            }
+            acc[i][j][r] = 0.0f;
+          }
+        }
+    }
+    if (w + 1 < W) lstore((w + 1) & 1);
+    __syncthreads();
+  }
+
+  if (STATS && my_tiles > 0) {
+    // every tile of this workgroup has the same N-tile (G is a multiple of NT), so the lane's columns never changed
+    float* s_st = reinterpret_cast<float*>(smem);  // [2][BN]
+    for (int i = tid; i < 2 * BN; i += 256) s_st[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float a = s_sum[j] + __shfl_xor(s_sum[j], 32);
+      const float q = s_sq[j] + __shfl_xor(s_sq[j], 32);
+      if (fh == 0) {
+        const int c = (wn * TN + j) * 32 + frow;
+        atomicAdd(&s_st[c], a);  // WM waves per address
+        atomicAdd(&s_st[BN + c], q);
+      }
+    }
+    __syncthreads();
+    const int n0 = (int)(lb % NT) * BN;
+    float* dst = stats + (size_t)(blockIdx.x % kStatReplicas) * 2 * N;
+    for (int i = tid; i < 2 * BN; i += 256) atomicAdd(&dst[(i / BN) * N + n0 + (i % BN)], s_st[i]);
+  }
+}
+
+// ---- streaming form: Cin <= 256 --------------------------------------------------------------------------------
+// With a short reduction the weight slab of a workgroup's column tile (BN x K bf16 <= 32 KB) stays in LDS for the whole
+// launch and the waves never meet at a barrier again: each wave owns 32 TM rows of X, pulls them straight into MFMA
+// operand registers (lane l: row l & 31, 16-byte chunk 2 s + (l >> 5) of k-step s — the natural fragment, 32 bytes per
+// row per instruction), has the NEXT row block's loads in flight while it multiplies the current one, and transposes
+// its result through a wave-private LDS patch so that the global stores are 16 bytes per lane along full rows.
+template <int K>
+struct Slab {  // [rows][K] bf16, 16-byte chunks swizzled so that 16 consecutive rows at one chunk index hit 16 bank groups
+  static constexpr int CPR = K / 8;
+  __device__ static __forceinline__ int off(int row, int chunk) {
+    const int f = CPR >= 16 ? (row & 15) : (row / (16 / CPR)) % CPR;
+    return row * (K * 2) + ((chunk ^ f) << 4);
+  }
+};
+
+template <int K, int TN, int TM>
+struct StreamLds {
+  static constexpr int BN = TN * 32;
+  static constexpr int SLAB_BYTES = BN * K * 2;
+  static constexpr int PATCH_ROW = BN * 2 + 16;  // +16: the two half-waves' rows (4 apart) land 16 banks apart
+  static constexpr int STAGE_BYTES = 32 * TM * K * 2, PATCH_BYTES = 32 * PATCH_ROW;
+  static constexpr int WAVE_BYTES = STAGE_BYTES > PATCH_BYTES ? STAGE_BYTES : PATCH_BYTES;  // one area, two uses in turn
+  static constexpr int TOTAL = SLAB_BYTES + 4 * WAVE_BYTES;
+};
+
+template <int K, int TN, int TM, bool STATS>
+__global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
+                                                               const unsigned short* __restrict__ Bw,
+                                                               unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
+                                                               float* __restrict__ stats) {
+  using L = StreamLds<K, TN, TM>;
+  constexpr int BN = TN * 32, KS = K / 16, CPR = K / 8;
+  constexpr int NLD = TM * KS;  // 16-byte loads per lane per row block: 32 TM rows x CPR chunks over 64 lanes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [slab | 4 wave areas]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int NT = N / BN, G = gridDim.x;
+  const int lb = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int nt = lb % NT, n0 = nt * BN;                    // G is a multiple of NT: one column tile per workgroup
+  const int gw = (lb / NT) * 4 + wave, GW = (G / NT) * 4;  // this wave among the waves of its column tile
+  const int RT = (M + 32 * TM - 1) / (32 * TM);            // row blocks of 32 TM rows
+  const int my = gw < RT ? (RT - 1 - gw) / GW + 1 : 0;
+
+  // coalesced: instruction p of a lane takes chunk (p * 64 + lane) of the row block, i.e. 64 / CPR whole rows at a time
+  u32x4 nxt[NLD];
+  auto load_rows = [&](int rt) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      const int id = p * 64 + lane;
+      int m = rt * (32 * TM) + id / CPR;
+      m = m < M ? m : M - 1;  // rows past the end re-read the last row; their results are never stored
+      nxt[p] = *reinterpret_cast<const u32x4*>(A + (long long)m * lda + (id % CPR) * 8);
+    }
+  };
+  if (my > 0) load_rows(gw);  // in flight while the weight slab is staged
+  for (int id = tid; id < BN * CPR; id += 256) {
+    const int row = id / CPR, c = id % CPR;
+    *reinterpret_cast<uint4*>(smem + Slab<K>::off(row, c)) =
+        *reinterpret_cast<const uint4*>(Bw + (long long)(n0 + row) * K + c * 8);
+  }
+  __syncthreads();
+
+  unsigned char* area = smem + L::SLAB_BYTES + wave * L::WAVE_BYTES;  // wave-private: row-block stage, then output patch
+  float s_sum[TN], s_sq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s_sum[j] = s_sq[j] = 0.0f;
+
+  for (int it = 0; it < my; ++it) {
+    const int rt = gw + it * GW;
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      const int id = p * 64 + lane;
+      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = nxt[p];
+    }
+    if (it + 1 < my) load_rows(rt + GW);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before its lanes read each other's
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 a[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(area + Slab<K>::off(i * 32 + frow, 2 * s + fh));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage reads done before the patch overwrites the area
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m0 = (rt * TM + i) * 32;
+      // C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)  ->  patch[row][col] as bf16
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)acc[i][j][r]);  // v_cvt_pk_bf16_f32, RNE
+          *reinterpret_cast<unsigned short*>(area + row * L::PATCH_ROW + (j * 32 + frow) * 2) = v;
+          if (STATS && m0 + row < M) {
+            const float f = bf16_bits_to_float(v);
+            s_sum[j] += f;
+            s_sq[j] = fmaf(f, f, s_sq[j]);
+          }
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < BN / 16; ++q) {  // 32 rows x BN/8 chunks of 16 bytes over 64 lanes
+        const int id = q * 64 + lane, row = id / (BN / 8), c = id % (BN / 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(area + row * L::PATCH_ROW + c * 16);
+        if (m0 + row < M) *reinterpret_cast<uint4*>(Cmat + (long long)(m0 + row) * ldc + n0 + c * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before it is overwritten
+    }
+  }
+
+  if (STATS) {
+    __syncthreads();  // every wave is past its last slab read: the slab's first bytes become the fold area
+    float* s_st = reinterpret_cast<float*>(smem);  // [2][BN]
+    for (int i = tid; i < 2 * BN; i += 256) s_st[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float a = s_sum[j] + __shfl_xor(s_sum[j], 32);
+      const float q = s_sq[j] + __shfl_xor(s_sq[j], 32);
+      if (fh == 0) {
+        atomicAdd(&s_st[j * 32 + frow], a);
+        atomicAdd(&s_st[BN + j * 32 + frow], q);
+      }
+    }
+    __syncthreads();
+    float* dst = stats + (size_t)(blockIdx.x % kStatReplicas) * 2 * N;
+    for (int i = tid; i < 2 * BN; i += 256) atomicAdd(&dst[(i / BN) * N + n0 + (i % BN)], s_st[i]);
+  }
+}
+
+template <int K, int TN, int TM>
+hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats,
+                        hipStream_t s) {
+  constexpr int BN = TN * 32;
+  const int NT = N / BN;
+  const long long RT = ((long long)M + 32 * TM - 1) / (32 * TM);
+  long long g = (RT + 3) / 4 * NT;  // one row block per wave, or the persistent cap
+  g = (g + 7) / 8 * 8;
+  if (g > 512) g = 512;
+  const size_t lds = StreamLds<K, TN, TM>::TOTAL;
+  const auto* a = static_cast<const unsigned short*>(A);
+  const auto* b = static_cast<const unsigned short*>(Bw);
+  auto* c = static_cast<unsigned short*>(Cmat);
+  if (stats)
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M, N,
+                    stats);
+  else
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M, N,
+                    stats);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+// -> true when the streaming form took the call
+template <int K>
+bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
+                hd_status* st) {
+  constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
+  const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
+  if (N / bn > 8) return false;
+  if (bn == 128) {
+    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s); return true; }
+    return false;
+  }
+  if (bn == 64) {
+    if constexpr (K <= 64) *st = launch_stream<K, 2, 2>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+    else *st = launch_stream<K, 2, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+    return true;
+  }
+  if constexpr (K <= 64) *st = launch_stream<K, 1, 2>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+  else *st = launch_stream<K, 1, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+hd_status launch_cfg(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, int K, float* stats,
+                     hipStream_t s) {
+  const long long tiles = (long long)((M + BM - 1) / BM) * (N / BN);
+  long long g = (tiles + 7) / 8 * 8;
+  if (g > 512) g = 512;
+  const size_t lds = 2u * (BM + BN) * BK * 2u;
+  const auto* a = static_cast<const unsigned short*>(A);
+  const auto* b = static_cast<const unsigned short*>(Bw);
+  auto* c = static_cast<unsigned short*>(Cmat);
+  if (stats)
+    (void)hd_launch(pointwise_conv_kernel<BM, BN, WM, WN, BK, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                    N, K, stats);
+  else
+    (void)hd_launch(pointwise_conv_kernel<BM, BN, WM, WN, BK, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                    N, K, stats);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+template <int BK>
+hd_status launch_bk(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, int K, float* stats,
+                    hipStream_t s) {
+  const int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
+  // 128-row tiles unless that leaves CUs idle (the 20x20 / 40x40 levels)
+  const bool small = (long long)((M + 127) / 128) * (N / bn) < 256;
+  if (bn == 128)
+    return small ? launch_cfg<64, 128, 2, 2, BK>(A, lda, Bw, Cmat, ldc, M, N, K, stats, s)
+                 : launch_cfg<128, 128, 2, 2, BK>(A, lda, Bw, Cmat, ldc, M, N, K, stats, s);
+  if (bn == 64)
+    return small ? launch_cfg<64, 64, 2, 2, BK>(A, lda, Bw, Cmat, ldc, M, N, K, stats, s)
+                 : launch_cfg<128, 64, 2, 2, BK>(A, lda, Bw, Cmat, ldc, M, N, K, stats, s);
+  return launch_cfg<128, 32, 4, 1, BK>(A, lda, Bw, Cmat, ldc, M, N, K, stats, s);
+}
+
+// ---- weight gradient: dW[Cout, Cin] = dY[R, Cout]^T . X[R, Cin] -------------------------------------------------
+// The reduction runs over the ROWS of both operands, which are the slow index of their channels-last storage, so the
+// MFMA fragments (8 consecutive reduction indices per lane) are columns of the staged tiles: rows are staged
+// global -> registers -> LDS as they lie (coalesced 16-byte chunks), and each fragment is two ds_read_b64_tr_b16
+// (the LDS transpose read: a 16-lane group fetches 4 rows x 16 columns and hands lane i column i).  Rows are padded by
+// 64 bytes so that the 8 (group, row) windows of a 32-lane half fall on disjoint banks.
+// A workgroup owns a (64 TM) x (64 TN) tile of dW and one of S slices of the rows; two register stages of 64 rows each
+// are in flight while the current one is multiplied.  Partial tiles go to a float32 slab [S][Cout][Cin] with plain
+// stores (no zero-fill, no atomics) and wgrad_reduce_kernel sums the S slabs into the bf16 gradient — two launches where
+// the library's split-K path takes a zero-fill, the convolution and a cast.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 tr_fragment(const unsigned char* tile, int stride, int col0, int m_base, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (m_base + 8 * (g >> 1) + q) * stride + (col0 + 16 * (g & 1) + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+                                                              const unsigned short* __restrict__ X, long long ld_x, int M, int N,
+                                                              int K, int rows_per_split, float* __restrict__ slab) {
+  constexpr int BNT = 64 * TM, BKT = 64 * TN, ROWS = 64;
+  constexpr int SN = BNT * 2 + 64, SK = BKT * 2 + 64;  // padded row strides (bytes)
+  constexpr int CN = BNT / 8, CK = BKT / 8;             // 16-byte chunks per row
+  constexpr int IT_N = ROWS * CN / 256, IT_K = ROWS * CK / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [64 rows of dY tile | 64 rows of X tile]
+  unsigned char* tY = smem;
+  unsigned char* tX = smem + ROWS * SN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = K / BKT;
+  const int n0 = (blockIdx.x / tiles_k) * BNT, k0 = (blockIdx.x % tiles_k) * BKT;
+  const int split = blockIdx.y;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int steps = m_end > m_begin ? (m_end - m_begin + ROWS - 1) / ROWS : 0;
+
+  u32x4 ry[2][IT_N], rx[2][IT_K];
+  auto issue = [&](int t, u32x4* py, u32x4* px) {
+    const int mb = m_begin + t * ROWS;
+#pragma unroll
+    for (int i = 0; i < IT_N; ++i) {
+      const int id = i * 256 + tid;
+      int m = mb + id / CN;
+      m = m < M ? m : M - 1;
+      py[i] = *reinterpret_cast<const u32x4*>(dY + (long long)m * ld_dy + n0 + (id % CN) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IT_K; ++i) {
+      const int id = i * 256 + tid;
+      int m = mb + id / CK;
+      m = m < M ? m : M - 1;
+      px[i] = *reinterpret_cast<const u32x4*>(X + (long long)m * ld_x + k0 + (id % CK) * 8);
+    }
+  };
+  auto stash = [&](int t, const u32x4* py, const u32x4* px) {  // rows past the slice end count as zero
+    const int mb = m_begin + t * ROWS;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < IT_N; ++i) {
+      const int id = i * 256 + tid, row = id / CN;
+      *reinterpret_cast<u32x4*>(tY + row * SN + (id % CN) * 16) = (mb + row < m_end) ? py[i] : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < IT_K; ++i) {
+      const int id = i * 256 + tid, row = id / CK;
+      *reinterpret_cast<u32x4*>(tX + row * SK + (id % CK) * 16) = (mb + row < m_end) ? px[i] : zero;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto multiply = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < ROWS / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = tr_fragment(tY, SN, (wn * TM + i) * 32, ks * 16, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = tr_fragment(tX, SK, (wk * TN + j) * 32, ks * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (steps > 0) issue(0, ry[0], rx[0]);
+  if (steps > 1) issue(1, ry[1], rx[1]);
+  for (int t = 0; t < steps; t += 2) {
+    stash(t, ry[0], rx[0]);
+    if (t + 2 < steps) issue(t + 2, ry[0], rx[0]);
+    __syncthreads();
+    multiply();
+    __syncthreads();
+    if (t + 1 < steps) {
+      stash(t + 1, ry[1], rx[1]);
+      if (t + 3 < steps) issue(t + 3, ry[1], rx[1]);
+      __syncthreads();
+      multiply();
+      __syncthreads();
+    }
+  }
+
+  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* out = slab + (size_t)split * N * K;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k0 + (wk * TN + j) * 32 + (lane & 31);
+      const int nb = n0 + (wn * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(size_t)(nb + (r & 3) + 8 * (r >> 2)) * K + k] = acc[i][j][r];
+    }
+}
+
+// dW[q] (4 consecutive elements) = sum over the S slabs; 16 quads x 16 slab lanes per workgroup
+__global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float* __restrict__ slab, int S, long long NK,
+                                                                     unsigned short* __restrict__ dW) {
+  __shared__ float4 part[16][17];
+  const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long quad = (long long)blockIdx.x * 16 + ql;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (quad * 4 < NK) {
+    int s = sl;
+    for (; s + 48 < S; s += 64) {  // four independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)s * NK + quad * 4);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 16) * NK + quad * 4);
+      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 32) * NK + quad * 4);
+      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 48) * NK + quad * 4);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x);
+      a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z);
+      a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * NK + quad * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  part[sl][ql] = a;
+  __syncthreads();
+  if (sl == 0 && quad * 4 < NK) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      const float4 v = part[i][ql];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const f32x4 f = {a.x, a.y, a.z, a.w};
+    *reinterpret_cast<bf16x4*>(dW + quad * 4) = __builtin_convertvector(f, bf16x4);
+  }
+}
+
+struct WgradPlan {
+  int tm, tn, tiles, splits, rows_per_split;
+};
+inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
+  WgradPlan p;
+  // 128-wide tiles read each operand once per tile row / column; for a 128 x 128 gradient that is ONE tile, whose
+  // ~200 row slices would write (and the reduce kernel read) as many slab bytes as the operands themselves: four
+  // 64 x 64 tiles with a quarter of the slices instead
+  const bool big = (int64_t)Cin * Cout > 128 * 128;
+  p.tm = Cout % 128 == 0 && big ? 2 : 1;
+  p.tn = Cin % 128 == 0 && big ? 2 : 1;
+  p.tiles = (Cout / (64 * p.tm)) * (Cin / (64 * p.tn));
+  int s = 512 / p.tiles;  // ~2 workgroups per CU
+  const int64_t max_s = (R + 127) / 128;  // at least two 64-row steps per slice
+  if (s > max_s) s = (int)max_s;
+  if (s < 1) s = 1;
+  int64_t rps = (R + s - 1) / s;
+  rps = (rps + 63) / 64 * 64;
+  p.rows_per_split = (int)rps;
+  p.splits = (int)((R + rps - 1) / rps);
+  return p;
+}
+
+}  // namespace
+
+extern "C" int hd_pointwise_conv_supported(int64_t R, int Cin, int Cout) {
+  return R >= 1 && R <= 0x7fffffff && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0 && Cin <= 8192 &&
+         Cout <= 1024;  // <= 8 column tiles: the persistent grid (a multiple of 8) keeps one column tile per workgroup
+}
+
+extern "C" hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout,
+                                       void* y, int64_t y_row_stride, float* stats, hd_stream stream) {
+  if (!x || !w || !y) return HD_ERR_NULL;
+  if (!hd_pointwise_conv_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
+  if (x_row_stride == 0) x_row_stride = Cin;
+  if (y_row_stride == 0) y_row_stride = Cout;
+  if (x_row_stride < Cin || y_row_stride < Cout || x_row_stride % 8 || y_row_stride % 8) return HD_ERR_SHAPE;
+  if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
+  if (hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hd_status st = HD_OK;
+  const int M = (int)R;
+  if (Cin == 32 && try_stream<32>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
+  if (Cin == 64 && try_stream<64>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
+  if (Cin == 128 && try_stream<128>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
+  if (Cin == 256 && try_stream<256>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
+  if (Cin % 64 == 0) return launch_bk<64>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
+  return launch_bk<32>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
+}
+
+extern "C" int hd_pointwise_wgrad_supported(int64_t R, int Cin, int Cout) {
+  return R >= 1 && R <= 0x7fffffff && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && Cin <= 8192 && Cout <= 8192;
+}
+
+extern "C" size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout) {
+  if (!hd_pointwise_wgrad_supported(R, Cin, Cout)) return 0;
+  const WgradPlan p = wgrad_plan(R, Cin, Cout);
+  return (size_t)p.splits * Cin * Cout * sizeof(float);
+}
+
+extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R,
+                                        int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                        hd_stream stream) {
+  if (!dy || !x || !dw || !workspace) return HD_ERR_NULL;
+  if (!hd_pointwise_wgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
+  if (dy_row_stride == 0) dy_row_stride = Cout;
+  if (x_row_stride == 0) x_row_stride = Cin;
+  if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
+  if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  const WgradPlan p = wgrad_plan(R, Cin, Cout);
+  if (workspace_bytes < (size_t)p.splits * Cin * Cout * sizeof(float)) return HD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const auto* a = static_cast<const unsigned short*>(dy);
+  const auto* b = static_cast<const unsigned short*>(x);
+  float* slab = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
+  const size_t lds = 64u * ((64u * p.tm * 2u + 64u) + (64u * p.tn * 2u + 64u));
+  const int M = (int)R;
+  if (p.tm == 2 && p.tn == 2)
+    (void)hd_launch(pointwise_wgrad_kernel<2, 2>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                    p.rows_per_split, slab);
+  else if (p.tm == 2)
+    (void)hd_launch(pointwise_wgrad_kernel<2, 1>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                    p.rows_per_split, slab);
+  else if (p.tn == 2)
+    (void)hd_launch(pointwise_wgrad_kernel<1, 2>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                    p.rows_per_split, slab);
+  else
+    (void)hd_launch(pointwise_wgrad_kernel<1, 1>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                    p.rows_per_split, slab);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  const long long NK = (long long)Cin * Cout;
+  (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
+                  p.splits, NK, static_cast<unsigned short*>(dw));
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}

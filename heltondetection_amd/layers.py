@@ -48,7 +48,17 @@ class FusedBNAct:
     _ACTS = {"silu": torch.nn.functional.silu, "relu": torch.relu, None: (lambda t: t)}
 
     @staticmethod
-    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False, out=None):
+    def slot_of(bn: nn.BatchNorm2d, device):
+        slot = getattr(bn, "_hd_slot", None)
+        if slot is None and bn.training:
+            from . import ops
+            slot = ops.bn_act_slot(device, bn.num_features)
+            bn._hd_slot = slot
+        return slot
+
+    @staticmethod
+    def apply(bn: nn.BatchNorm2d, x: torch.Tensor, act, residual=None, residual_after_act: bool = False, out=None,
+              stats_done: bool = False):
         """residual: added inside the fused kernel, before (`act(bn(x) + r)`) or after (`act(bn(x)) + r`) the
         activation; the unfused fallback computes the same expression with torch ops.
         out: a CatBuffer slot — the fused kernel writes its result there (the caller's CatBuffer.join then has nothing
@@ -57,13 +67,12 @@ class FusedBNAct:
         if FusedBNAct.enabled and x.is_cuda and bn.momentum is not None:
             from . import ops
             if ops.bn_act_supported(x):
-                slot = getattr(bn, "_hd_slot", None)
-                if slot is None and bn.training:
-                    slot = ops.bn_act_slot(x.device, x.shape[1])
-                    bn._hd_slot = slot
+                slot = FusedBNAct.slot_of(bn, x.device)
                 training = bn.training or bn.running_mean is None
                 return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, training, slot,
-                                  FusedBNAct.sync_group if training else None, residual, residual_after_act, out)
+                                  FusedBNAct.sync_group if training else None, residual, residual_after_act, out, stats_done)
+        if stats_done:
+            raise RuntimeError("FusedBNAct.apply(stats_done=True) needs the fused HIP path")
         if residual is None:
             return FusedBNAct._ACTS[act](bn(x))
         if residual_after_act:
@@ -99,6 +108,7 @@ class ConvBNAct(nn.Module):
     """Conv2d(bias=False) + BatchNorm2d + activation (SiLU for the YOLOv5 family, ReLU for ResNet)."""
 
     fused = True  # class-wide switch: run BN+activation as the fused HIP kernels on HIP tensors
+    pointwise = True  # 1x1 convolutions on the MFMA kernel of csrc/pointwise_conv.hip, BatchNorm statistics in its epilogue
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
@@ -106,10 +116,23 @@ class ConvBNAct(nn.Module):
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act
+        self._is_pointwise = k == 1 and s == 1 and g == 1
 
     def forward(self, x, residual=None, out=None):
         """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut).
         out: a CatBuffer slot for the result (see FusedBNAct.apply)."""
+        if self.fused and self.pointwise and self._is_pointwise and x.is_cuda and FusedBNAct.enabled and self.bn.training \
+                and self.bn.momentum is not None and torch.is_autocast_enabled("cuda") \
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            from . import ops
+            w = self.conv.lp_weight()
+            if w.dtype != torch.bfloat16:
+                w = w.to(torch.bfloat16)
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            if ops.pointwise_conv_usable(xb, w) and self.bn.num_features // 8 <= 256:
+                # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
+                y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(self.bn, x.device))
+                return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out, stats_done=True)
         y = self.conv(x)
         if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
             return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out)

@@ -835,10 +835,147 @@ def _cl_row_stride(t: torch.Tensor, vec: int):
     return ld
 
 
+# ------------------------------------------------------------------------------- 1x1 convolution (MFMA GEMM)
+def pointwise_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """x: [B, Cin, H, W] bf16 channels-last rows (dense or a channel slice); weight: [Cout, Cin, 1, 1] bf16 dense."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and weight.dim() == 4 and weight.shape[2:] == (1, 1) and weight.shape[1] == x.shape[1]):
+        return False
+    B, Cin, H, W = x.shape
+    if not _lib.load().hd_pointwise_conv_supported(B * H * W, Cin, weight.shape[0]):
+        return False
+    return _cl_row_stride(x, 8) is not None and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+
+
+def pointwise_conv_rows(x: torch.Tensor, w2: torch.Tensor, stats: Optional[torch.Tensor] = None,
+                        out: Optional[torch.Tensor] = None, name: str = "pointwise_conv") -> torch.Tensor:
+    """y[B, N, H, W] = 1x1 convolution of x[B, K, H, W] (channels-last rows) with w2[N, K] (bf16, dense), no autograd.
+    stats: float32 [replicas * 2 * N], zeroed by the caller — the fused BatchNorm's (sum, sum of squares) are added."""
+    lib = _lib.load()
+    B, K, H, W = x.shape
+    N = w2.shape[0]
+    ld_x = _cl_row_stride(x, 8)
+    if ld_x is None or x.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or w2.shape[1] != K or not w2.is_contiguous():
+        raise _lib.HdError("pointwise_conv: needs bf16 channels-last rows and a dense bf16 [Cout, Cin] weight")
+    if out is None:
+        out = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ld_y = _cl_row_stride(out, 8)
+    if ld_y is None or out.shape != (B, N, H, W) or out.dtype != torch.bfloat16:
+        raise _lib.HdError("pointwise_conv: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cout, H, W]")
+    with _ktimed(name):
+        check(lib.hd_pointwise_conv(_ptr(x), int(ld_x), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_y), _ptr(stats), _stream(x)),
+              "hd_pointwise_conv")
+    return out
+
+
+def _fwd_sums(slot: "_StatSlot", channels: int) -> torch.Tensor:
+    """The slot's forward accumulators [replicas, 2, C], zero: the arena reset zeroed them once per step; a second
+    forward of the same layer since then clears its own."""
+    sums = slot.buf[: _lib.load().hd_bn_act_replicas() * 2 * channels]
+    if slot.fwd_gen == slot.arena.gen:
+        sums.zero_()
+    slot.fwd_gen = slot.arena.gen
+    return sums
+
+
+_WGRAD_WS: dict = {}
+
+
+def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
+    """One float32 slab per device, grown on demand and shared by every layer (launches on one stream run in order)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
+def pointwise_wgrad_supported(R: int, cin: int, cout: int) -> bool:
+    return bool(_lib.load().hd_pointwise_wgrad_supported(int(R), int(cin), int(cout)))
+
+
+def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dw[Cout, Cin] (bf16) = sum over rows of dy[B, Cout, H, W]^T x[B, Cin, H, W], channels-last rows, no autograd."""
+    lib = _lib.load()
+    B, N, H, W = dy.shape
+    K = x.shape[1]
+    ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
+    if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
+            or x.shape[0] != B or x.shape[2:] != dy.shape[2:]):
+        raise _lib.HdError("pointwise_wgrad: needs bf16 channels-last rows of equal batch and spatial size")
+    R = B * H * W
+    nbytes = lib.hd_pointwise_wgrad_workspace_bytes(R, K, N)
+    if nbytes == 0:
+        raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64")
+    ws = _wgrad_workspace(dy.device, nbytes)
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+    with _timed("pointwise_wgrad"):
+        check(lib.hd_pointwise_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), R, K, N, _ptr(dw), _ptr(ws), ws.numel(),
+                                     _stream(dy)), "hd_pointwise_wgrad")
+    return dw
+
+
+POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen
+
+
+class _PointwiseConvFn(torch.autograd.Function):
+    """1x1 convolution (stride 1, no bias) of channels-last bf16 rows on the MFMA kernel of csrc/pointwise_conv.hip.
+    forward: y = x . w^T, and the following fused BatchNorm's batch statistics go into `slot` from the epilogue.
+    backward: the data gradient is the same kernel with the transposed weights (when Cout is short enough to be the
+    reduction); the weight gradient is hd_pointwise_wgrad (channel counts that are multiples of 64), else MIOpen's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, slot):
+        N, K = weight.shape[0], weight.shape[1]
+        sums = _fwd_sums(slot, N) if slot is not None else None
+        y = pointwise_conv_rows(x, weight.view(N, K), sums)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape[0], weight.shape[1]
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if dy.dtype != torch.bfloat16 or _cl_row_stride(dy, 8) is None:
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        ours = need_dx and N <= POINTWISE_MAX_REDUCTION and _lib.load().hd_pointwise_conv_supported(x.shape[0] * x.shape[2] * x.shape[3], N, K)
+        if ours:
+            dx = pointwise_conv_rows(dy, weight.view(N, K).t().contiguous(), name="pointwise_dgrad")
+        R = x.shape[0] * x.shape[2] * x.shape[3]
+        ours_w = need_dw and pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
+        if ours_w:
+            dw = pointwise_wgrad_rows(dy, x).view(N, K, 1, 1)
+        lib_w, lib_x = need_dw and not ours_w, need_dx and not ours
+        if lib_w or lib_x:
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            dyd = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
+            gi, gw, _ = torch.ops.aten.convolution_backward(dyd, xd, weight, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                            (lib_x, lib_w, False))
+            if lib_w:
+                dw = gw
+            if lib_x:
+                dx = gi
+        return dx, dw, None
+
+
+def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatSlot"] = None) -> torch.Tensor:
+    """Differentiable 1x1 convolution; with `slot` (a bn_act_slot of Cout channels) the BatchNorm statistics of the
+    result are accumulated there, and the bn_act that follows is called with stats_done=True."""
+    return _PointwiseConvFn.apply(x, weight, slot)
+
+
+def pointwise_conv_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return weight.shape[1] <= POINTWISE_MAX_REDUCTION and pointwise_conv_supported(x, weight)
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None, res=None,
-                res_mode=0, out_slot=None):
+                res_mode=0, out_slot=None, stats_done=False):
+        """stats_done: the producer of x (pointwise_conv) already added x's per-channel sums into the slot."""
         lib = _lib.load()
         if res is not None:
             if res.shape != x.shape or res.dtype != x.dtype or res.stride() != x.stride():
@@ -848,12 +985,7 @@ class _BNActFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         R = B * H * W
         dt = 0 if x.dtype == torch.float32 else 1
-        arena = slot.arena
-        rep = lib.hd_bn_act_replicas()
-        sums = slot.buf[: rep * 2 * Cc]
-        if slot.fwd_gen == arena.gen:   # second forward since the last arena reset: clear our own slot
-            sums.zero_()
-        slot.fwd_gen = arena.gen
+        sums = slot.buf[: lib.hd_bn_act_replicas() * 2 * Cc] if stats_done else _fwd_sums(slot, Cc)
         vec = 4 if dt == 0 else 8
         split = 0
         y2, tail = None, None
@@ -874,8 +1006,9 @@ class _BNActFn(torch.autograd.Function):
         save = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
-        with _ktimed("bn_stats_kernel"):
-            check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
+        if not stats_done:
+            with _ktimed("bn_stats_kernel"):
+                check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
         stat_rows = 0
         if sync_group is not None:
             # synchronised BatchNorm: the per-channel (sum, sum of squares) of every rank are added between the
@@ -949,8 +1082,8 @@ class _BNActFn(torch.autograd.Function):
         # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
         gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
         if local is not None:
-            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None, None
-        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None, None
+            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None, None, None
+        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None, None, None
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:
@@ -960,7 +1093,7 @@ def bn_act_slot(device, channels: int) -> _StatSlot:
 
 def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: float, act: str, training: bool,
            slot: Optional[_StatSlot] = None, sync_group=None, residual: Optional[torch.Tensor] = None,
-           residual_after_act: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual_after_act: bool = False, out: Optional[torch.Tensor] = None, stats_done: bool = False) -> torch.Tensor:
     """Fused BatchNorm2d + activation on a dense channels-last HIP tensor (see csrc/bn_act.hip).
     sync_group: a torch.distributed process group -> statistics (and the backward sums) are taken over the
     batches of all its ranks (SyncBN; ranks must hold equal shards).  Training mode only, not graph-capturable.
@@ -976,7 +1109,7 @@ def bn_act(x, weight, bias, running_mean, running_var, eps: float, momentum: flo
             slot = bn_act_slot(x.device, x.shape[1])
         return _BNActFn.apply(x, weight, bias, running_mean, running_var, eps, momentum, code, slot, sync_group, residual,
                               (2 if residual_after_act else 1) if residual is not None else 0,
-                              _OutSlot(out) if out is not None else None)
+                              _OutSlot(out) if out is not None else None, bool(stats_done))
     lib = _lib.load()
     B, Cc, H, W = x.shape
     vec = 4 if x.dtype == torch.float32 else 8

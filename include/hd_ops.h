@@ -408,6 +408,30 @@ hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride,
                            const float* beta, int act, const void* res, const float* dsums, void* dx,
                            void* dres, float* dgamma, float* dbeta, const hd_rows2* dy_tail, hd_stream stream);
 
+/* ---- 1x1 convolution on channels-last rows, BatchNorm statistics in the epilogue (csrc/pointwise_conv.hip) ----
+ * The convolution half of the reference's Conv+BN+SiLU block (README.md:9 "YOLOv5 ... backbone/neck"; the block
+ * itself is NOT IN SNAPSHOT, SURVEY.md section 8a "Backbone + neck fwd/bwd") for kernel 1x1, stride 1, groups 1, no
+ * bias — 34 of YOLOv5s' 57 convolutions:
+ *     y[R, Cout] = x[R, Cin] . w[Cout, Cin]^T      bfloat16 in / out, float32 accumulate (MFMA)
+ * x rows may be a channel slice of a wider channels-last tensor (x_row_stride elements between rows, 0 = Cin, multiple
+ * of 8); likewise y (y_row_stride, 0 = Cout).  w is dense [Cout, Cin].  Cin, Cout multiples of 32, Cout <= 1024.
+ * stats (nullable): float32 [hd_bn_act_replicas(), 2, Cout], ZEROED BY THE CALLER — per-channel (sum, sum of squares)
+ * of the bf16-rounded y are ADDED, exactly what hd_bn_act_stats(y) would add, so hd_bn_act_apply can follow directly.
+ * The data gradient of the same convolution is this entry point with the transposed weights:
+ *     dx[R, Cin] = dy[R, Cout] . wt[Cin, Cout]^T   ->  hd_pointwise_conv(dy, ld, wt, R, Cout, Cin, dx, ld, NULL, s). */
+int hd_pointwise_conv_supported(int64_t R, int Cin, int Cout);
+hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout, void* y,
+                            int64_t y_row_stride, float* stats, hd_stream stream);
+
+/* Weight gradient of the same convolution: dw[Cout, Cin] (bfloat16) = dy[R, Cout]^T . x[R, Cin], float32 accumulate.
+ * Two launches (row-sliced partial products into a float32 slab in `workspace`, then the sum over slices), no zero-fill.
+ * Cin, Cout multiples of 64.  workspace: hd_pointwise_wgrad_workspace_bytes(R, Cin, Cout), 16-byte aligned, contents
+ * undefined on entry and exit. */
+int hd_pointwise_wgrad_supported(int64_t R, int Cin, int Cout);
+size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout);
+hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R, int Cin,
+                             int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
+
 /* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
 
 /* images/out: float32 [B,3,S,S] with element strides (b,c,y,x); S even; out must not alias images.

@@ -1,0 +1,135 @@
+"""hd_pointwise_conv (csrc/pointwise_conv.hip): the 1x1 convolution as an MFMA GEMM with the fused BatchNorm's
+statistics in its epilogue.  Checked against float32 matmuls of the same bf16-rounded operands (tolerance = one bf16
+rounding of the result, 2^-8 relative, plus the float32 accumulation-order noise)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(B, K, H, W, N, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, K, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((N, K, 1, 1), generator=g) * K ** -0.5).to(dev).to(torch.bfloat16)
+    return x, w
+
+
+def _ref(x, w):
+    return torch.nn.functional.conv2d(x.float(), w.float())
+
+
+# (B, Cin, H, W, Cout): every streaming-form tile shape (K 32/64/128/256 x column tiles 32/64/128), the K-loop form
+# (K 512, 96, 1024), ragged row counts (not a multiple of 32 / 64 / 128) and a single-row input
+SHAPES = [(2, 32, 20, 20, 32), (2, 64, 24, 20, 64), (1, 64, 17, 13, 128), (2, 128, 9, 11, 128), (1, 128, 16, 16, 64),
+          (2, 256, 10, 10, 256), (1, 256, 7, 9, 128), (1, 256, 5, 5, 32), (2, 64, 16, 16, 256), (1, 32, 33, 7, 96),
+          (2, 512, 10, 10, 512), (1, 1024, 6, 6, 512), (1, 96, 7, 7, 160), (1, 64, 1, 1, 64), (16, 64, 80, 80, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_pointwise_conv_matches_fp32_reference_and_statistics(shape):
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    x, w = _mk(B, K, H, W, N, 7 + K + N, dev)
+    rep = _lib.load().hd_bn_act_replicas()
+    stats = torch.zeros(rep * 2 * N, dtype=torch.float32, device=dev)
+    y = ops.pointwise_conv_rows(x, w.view(N, K), stats)
+    ref = _ref(x, w)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    tol = 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max()
+    assert bool(((y.float() - ref).abs() <= tol * 1.01).all()), float((y.float() - ref).abs().max())
+    # the epilogue's statistics are those of the bf16 tensor it wrote
+    yf = y.double()
+    want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    got = stats.view(rep, 2, N).double().sum(0)
+    scale = torch.stack([yf.abs().sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]) + 1e-6
+    assert float(((got - want).abs() / scale).max()) < 2e-6
+
+
+def test_pointwise_conv_reads_and_writes_channel_slices():
+    """x a channel slice of a wider channels-last tensor, y written into a slice of a concatenation buffer."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 12, 10
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn((B, 192, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 64:128]
+    w = (torch.randn((96, 64, 1, 1), generator=g) * 0.125).to(dev).to(torch.bfloat16)
+    buf = torch.full((B, 160, H, W), 7.0, dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    out = buf[:, 32:128]
+    ops.pointwise_conv_rows(x, w.view(96, 64), None, out)
+    ref = _ref(x, w)
+    assert torch.allclose(out.float(), ref, rtol=2.0 ** -7, atol=1e-3)
+    assert bool((buf[:, :32] == 7.0).all()) and bool((buf[:, 128:] == 7.0).all())  # neighbours untouched
+
+
+def test_pointwise_conv_rejects_what_it_cannot_take():
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    x, w = _mk(1, 48, 4, 4, 64, 0, dev)  # Cin not a multiple of 32
+    assert not ops.pointwise_conv_supported(x, w)
+    with pytest.raises(_lib.HdError):
+        ops.pointwise_conv_rows(x, w.view(64, 48))
+    x, w = _mk(1, 64, 4, 4, 64, 0, dev)
+    assert not ops.pointwise_conv_supported(x.float(), w)  # bf16 only
+    assert not ops.pointwise_conv_supported(x.contiguous(), w)  # NCHW rows are not channels-last rows
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 64, 24), (128, 256, 10), (256, 128, 12), (512, 256, 6)])
+def test_conv_bn_act_pointwise_path_matches_library_path(cin, cout, hw):
+    """ConvBNAct forward + backward with the MFMA 1x1 path on vs MIOpen + the separate statistics kernel."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = layers.ConvBNAct(cin, cout, 1, 1).to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((4, cin, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((4, cout, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.pointwise = on
+        try:
+            m.zero_grad(set_to_none=True)
+            m.bn.running_mean.zero_(); m.bn.running_var.fill_(1.0)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            (y.float() * gy).sum().backward()
+            res[on] = (y.float(), x.grad.float(), m.conv.weight.grad.float(), m.bn.weight.grad.float(),
+                       m.bn.bias.grad.float(), m.bn.running_mean.clone(), m.bn.running_var.clone())
+        finally:
+            layers.ConvBNAct.pointwise = True
+    names = ("y", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")
+    for name, a, b in zip(names, res[True], res[False]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        assert err < 3e-2, (name, err)  # two bf16 pipelines with different accumulation orders
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 64), (2, 128, 9, 7, 64), (1, 64, 13, 5, 128), (2, 128, 8, 8, 128),
+                                   (1, 256, 5, 5, 128), (1, 64, 13, 13, 192), (2, 512, 6, 6, 256), (16, 64, 40, 40, 64)])
+def test_pointwise_wgrad_is_exact_on_integer_data(shape):
+    """Small-integer operands: every product and partial sum is exactly representable in float32, so the transposed
+    LDS fragments, the row slicing (ragged last slice, rows past the end zeroed) and the slab reduction must give the
+    exact sums (then rounded once to bf16)."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H)
+    x = torch.randint(-3, 4, (B, K, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randint(-3, 4, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = ops.pointwise_wgrad_rows(dy, x)
+    ref = torch.einsum("bnhw,bkhw->nk", dy.float(), x.float())
+    assert dw.shape == (N, K) and dw.dtype == torch.bfloat16
+    assert torch.equal(dw, ref.to(torch.bfloat16))
+
+
+def test_pointwise_wgrad_reads_channel_slices():
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    wide_x = torch.randn((2, 192, 9, 9), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wide_dy = torch.randn((2, 256, 9, 9), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x, dy = wide_x[:, 64:128], wide_dy[:, 128:256]
+    dw = ops.pointwise_wgrad_rows(dy, x).float()
+    ref = torch.einsum("bnhw,bkhw->nk", dy.float(), x.float())
+    assert torch.allclose(dw, ref, rtol=2.0 ** -7, atol=2e-2)
