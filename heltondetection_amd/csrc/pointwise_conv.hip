@@ -212,22 +212,38 @@ struct Slab {  // [rows][K] bf16, 16-byte chunks swizzled so that 16 consecutive
   }
 };
 
-template <int K, int TN, int TM>
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 tr_fragment(const unsigned char* tile, int stride, int col0, int m_base, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (m_base + 8 * (g >> 1) + q) * stride + (col0 + 16 * (g & 1) + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// TRB: the weight operand is given [K][N] (the forward weight, seen from the data gradient): its slab keeps that
+// layout (rows of BN columns, padded by 64 bytes) and the B fragments are LDS transpose reads instead of row reads.
+template <int K, int TN, int TM, bool TRB = false>
 struct StreamLds {
   static constexpr int BN = TN * 32;
-  static constexpr int SLAB_BYTES = BN * K * 2;
+  static constexpr int SLAB_ROW_T = BN * 2 + 64;
+  static constexpr int SLAB_BYTES = TRB ? K * SLAB_ROW_T : BN * K * 2;
   static constexpr int PATCH_ROW = BN * 2 + 16;  // +16: the two half-waves' rows (4 apart) land 16 banks apart
   static constexpr int STAGE_BYTES = 32 * TM * K * 2, PATCH_BYTES = 32 * PATCH_ROW;
   static constexpr int WAVE_BYTES = STAGE_BYTES > PATCH_BYTES ? STAGE_BYTES : PATCH_BYTES;  // one area, two uses in turn
   static constexpr int TOTAL = SLAB_BYTES + 4 * WAVE_BYTES;
 };
 
-template <int K, int TN, int TM, bool STATS>
+template <int K, int TN, int TM, bool STATS, bool TRB>
 __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
                                                                const unsigned short* __restrict__ Bw,
                                                                unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
                                                                float* __restrict__ stats) {
-  using L = StreamLds<K, TN, TM>;
+  using L = StreamLds<K, TN, TM, TRB>;
   constexpr int BN = TN * 32, KS = K / 16, CPR = K / 8;
   constexpr int NLD = TM * KS;  // 16-byte loads per lane per row block: 32 TM rows x CPR chunks over 64 lanes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [slab | 4 wave areas]
@@ -252,10 +268,18 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
     }
   };
   if (my > 0) load_rows(gw);  // in flight while the weight slab is staged
-  for (int id = tid; id < BN * CPR; id += 256) {
-    const int row = id / CPR, c = id % CPR;
-    *reinterpret_cast<uint4*>(smem + Slab<K>::off(row, c)) =
-        *reinterpret_cast<const uint4*>(Bw + (long long)(n0 + row) * K + c * 8);
+  if (TRB) {
+    for (int id = tid; id < K * (BN / 8); id += 256) {
+      const int row = id / (BN / 8), c = id % (BN / 8);
+      *reinterpret_cast<uint4*>(smem + row * L::SLAB_ROW_T + c * 16) =
+          *reinterpret_cast<const uint4*>(Bw + (long long)row * N + n0 + c * 8);
+    }
+  } else {
+    for (int id = tid; id < BN * CPR; id += 256) {
+      const int row = id / CPR, c = id % CPR;
+      *reinterpret_cast<uint4*>(smem + Slab<K>::off(row, c)) =
+          *reinterpret_cast<const uint4*>(Bw + (long long)(n0 + row) * K + c * 8);
+    }
   }
   __syncthreads();
 
@@ -287,7 +311,8 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
       for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(area + Slab<K>::off(i * 32 + frow, 2 * s + fh));
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
+        const bf16x8 b = TRB ? tr_fragment(smem, L::SLAB_ROW_T, j * 32, s * 16, lane)
+                             : *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
       }
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   }
 }
 
-template <int K, int TN, int TM>
+template <int K, int TN, int TM, bool TRB>
 hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats,
                         hipStream_t s) {
   constexpr int BN = TN * 32;
@@ -350,38 +375,38 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   long long g = (RT + 3) / 4 * NT;  // one row block per wave, or the persistent cap
   g = (g + 7) / 8 * 8;
   if (g > 512) g = 512;
-  const size_t lds = StreamLds<K, TN, TM>::TOTAL;
+  const size_t lds = StreamLds<K, TN, TM, TRB>::TOTAL;
   const auto* a = static_cast<const unsigned short*>(A);
   const auto* b = static_cast<const unsigned short*>(Bw);
   auto* c = static_cast<unsigned short*>(Cmat);
-  if (stats)
-    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M, N,
-                    stats);
+  if (stats && !TRB)
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                    N, stats);
   else
-    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M, N,
-                    stats);
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                    N, (float*)nullptr);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
 
 // -> true when the streaming form took the call
-template <int K>
+template <int K, bool TRB = false>
 bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
                 hd_status* st) {
   constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
   const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > 8) return false;
   if (bn == 128) {
-    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s); return true; }
+    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s); return true; }
     return false;
   }
   if (bn == 64) {
-    if constexpr (K <= 64) *st = launch_stream<K, 2, 2>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
-    else *st = launch_stream<K, 2, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+    if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+    else *st = launch_stream<K, 2, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
     return true;
   }
-  if constexpr (K <= 64) *st = launch_stream<K, 1, 2>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
-  else *st = launch_stream<K, 1, 1>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+  if constexpr (K <= 64) *st = launch_stream<K, 1, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+  else *st = launch_stream<K, 1, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
   return true;
 }
 
@@ -430,19 +455,6 @@ hd_status launch_bk(const void* A, int64_t lda, const void* Bw, void* Cmat, int6
 // are in flight while the current one is multiplied.  Partial tiles go to a float32 slab [S][Cout][Cin] with plain
 // stores (no zero-fill, no atomics) and wgrad_reduce_kernel sums the S slabs into the bf16 gradient — two launches where
 // the library's split-K path takes a zero-fill, the convolution and a cast.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-__device__ __forceinline__ bf16x8 tr_fragment(const unsigned char* tile, int stride, int col0, int m_base, int lane) {
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const unsigned char* a = tile + (m_base + 8 * (g >> 1) + q) * stride + (col0 + 16 * (g & 1) + 4 * p) * 2;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                               const unsigned short* __restrict__ X, long long ld_x, int M, int N,
@@ -684,4 +696,22 @@ extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, c
                   p.splits, NK, static_cast<unsigned short*>(dw));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
+}
+
+extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout,
+                                             void* dx, int64_t dx_row_stride, hd_stream stream) {
+  if (!dy || !w || !dx) return HD_ERR_NULL;
+  if (!hd_pointwise_conv_supported(R, Cout, Cin) || Cout > 256) return HD_ERR_SHAPE;  // the reduction runs over Cout
+  if (dy_row_stride == 0) dy_row_stride = Cout;
+  if (dx_row_stride == 0) dx_row_stride = Cin;
+  if (dy_row_stride < Cout || dx_row_stride < Cin || dy_row_stride % 8 || dx_row_stride % 8) return HD_ERR_SHAPE;
+  if (!hd_aligned16(dy) || !hd_aligned16(w) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  hd_status st = HD_OK;
+  const int M = (int)R;
+  if (Cout == 32 && try_stream<32, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  if (Cout == 64 && try_stream<64, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  if (Cout == 128 && try_stream<128, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  if (Cout == 256 && try_stream<256, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  return HD_ERR_SHAPE;
 }

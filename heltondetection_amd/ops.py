@@ -891,6 +891,25 @@ def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[B, Cin, H, W] = dy[B, Cout, H, W] . w2[Cout, Cin] on channels-last rows, no autograd; Cout in {32, 64, 128, 256}."""
+    lib = _lib.load()
+    B, N, H, W = dy.shape
+    K = w2.shape[1]
+    ld_dy = _cl_row_stride(dy, 8)
+    if ld_dy is None or dy.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or w2.shape[0] != N or not w2.is_contiguous():
+        raise _lib.HdError("pointwise_dgrad: needs bf16 channels-last rows and the dense bf16 [Cout, Cin] forward weight")
+    if out is None:
+        out = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    ld_dx = _cl_row_stride(out, 8)
+    if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
+        raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
+    with _ktimed("pointwise_dgrad"):
+        check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
+              "hd_pointwise_conv_dgrad")
+    return out
+
+
 def pointwise_wgrad_supported(R: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().hd_pointwise_wgrad_supported(int(R), int(cin), int(cout)))
 
@@ -941,9 +960,9 @@ class _PointwiseConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16 or _cl_row_stride(dy, 8) is None:
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        ours = need_dx and N <= POINTWISE_MAX_REDUCTION and _lib.load().hd_pointwise_conv_supported(x.shape[0] * x.shape[2] * x.shape[3], N, K)
+        ours = need_dx and N in (32, 64, 128, 256) and _lib.load().hd_pointwise_conv_supported(x.shape[0] * x.shape[2] * x.shape[3], N, K)
         if ours:
-            dx = pointwise_conv_rows(dy, weight.view(N, K).t().contiguous(), name="pointwise_dgrad")
+            dx = pointwise_dgrad_rows(dy, weight.view(N, K))
         R = x.shape[0] * x.shape[2] * x.shape[3]
         ours_w = need_dw and pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
         if ours_w:

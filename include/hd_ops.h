@@ -417,9 +417,14 @@ hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_row_stride,
  * of 8); likewise y (y_row_stride, 0 = Cout).  w is dense [Cout, Cin].  Cin, Cout multiples of 32, Cout <= 1024.
  * stats (nullable): float32 [hd_bn_act_replicas(), 2, Cout], ZEROED BY THE CALLER — per-channel (sum, sum of squares)
  * of the bf16-rounded y are ADDED, exactly what hd_bn_act_stats(y) would add, so hd_bn_act_apply can follow directly.
- * The data gradient of the same convolution is this entry point with the transposed weights:
- *     dx[R, Cin] = dy[R, Cout] . wt[Cin, Cout]^T   ->  hd_pointwise_conv(dy, ld, wt, R, Cout, Cin, dx, ld, NULL, s). */
+ * With transposed weights wt[Cin, Cout] the same entry point is the data gradient (any supported shape):
+ *     dx[R, Cin] = dy[R, Cout] . wt^T   ->  hd_pointwise_conv(dy, ld, wt, R, Cout, Cin, dx, ld, NULL, s). */
 int hd_pointwise_conv_supported(int64_t R, int Cin, int Cout);
+/* Data gradient straight from the forward weight w[Cout, Cin] (its columns are read through LDS transpose reads, no
+ * transposed copy): dx[R, Cin] = dy[R, Cout] . w.  Cout in {32, 64, 128, 256} (the weight slab must stay in LDS);
+ * other shapes: HD_ERR_SHAPE, and the caller uses hd_pointwise_conv with a transposed copy or the library. */
+hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout, void* dx,
+                                  int64_t dx_row_stride, hd_stream stream);
 hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout, void* y,
                             int64_t y_row_stride, float* stats, hd_stream stream);
 

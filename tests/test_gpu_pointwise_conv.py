@@ -133,3 +133,23 @@ def test_pointwise_wgrad_reads_channel_slices():
     dw = ops.pointwise_wgrad_rows(dy, x).float()
     ref = torch.einsum("bnhw,bkhw->nk", dy.float(), x.float())
     assert torch.allclose(dw, ref, rtol=2.0 ** -7, atol=2e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 9, 9, 32), (2, 64, 8, 8, 64), (1, 128, 13, 5, 64), (2, 64, 7, 7, 128),
+                                   (2, 128, 8, 8, 128), (1, 512, 5, 5, 256), (1, 256, 6, 6, 256), (1, 96, 9, 9, 32),
+                                   (16, 128, 40, 40, 128)])
+def test_pointwise_dgrad_from_the_forward_weight(shape):
+    """dx = dy . w read through LDS transpose fragments: exact on small-integer data, and equal (bit for bit) to the
+    same product computed by hd_pointwise_conv from a transposed copy of w."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape  # K = Cin, N = Cout
+    g = torch.Generator().manual_seed(K * 3 + N)
+    dy = torch.randint(-3, 4, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randint(-2, 3, (N, K), generator=g).float().to(dev).to(torch.bfloat16)
+    dx = ops.pointwise_dgrad_rows(dy, w)
+    ref = torch.einsum("bnhw,nk->bkhw", dy.float(), w.float())
+    assert dx.shape == ref.shape and torch.equal(dx.float(), ref.to(torch.bfloat16).float())
+    dy = torch.randn(dy.shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((N, K), generator=g) * N ** -0.5).to(dev).to(torch.bfloat16)
+    assert torch.equal(ops.pointwise_dgrad_rows(dy, w), ops.pointwise_conv_rows(dy, w.t().contiguous()))
