@@ -40,12 +40,22 @@ class YOLOv5PAFPN(nn.Module):
             return torch.cat((down(x), lateral), 1)
         return cb.join((down(x, None, cb.slot(0)), lateral))
 
+    @staticmethod
+    def _up_cat(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+        """cat(upsample2x(small), big): one HIP gather into the bf16 concatenation (ops.upsample2x_cat) instead of a
+        float32 upsample, a promoting torch.cat and the casts back."""
+        if ConvBNAct.fused and small.is_cuda:
+            from . import ops
+            if ops.upsample2x_cat_supported(small, big):
+                return ops.upsample2x_cat(small, big)
+        return torch.cat((F.interpolate(small, scale_factor=2.0, mode="nearest"), big), 1)
+
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         p3, p4, p5 = feats
         l5 = self.lat5(p5)
-        t4 = self.td4(torch.cat((F.interpolate(l5, scale_factor=2.0, mode="nearest"), p4), 1))
+        t4 = self.td4(self._up_cat(l5, p4))
         l4 = self.lat4(t4)
-        o3 = self.td3(torch.cat((F.interpolate(l4, scale_factor=2.0, mode="nearest"), p3), 1))
+        o3 = self.td3(self._up_cat(l4, p3))
         o4 = self.bu4(self._down_cat(self.down3, o3, l4))
         o5 = self.bu5(self._down_cat(self.down4, o4, l5))
         return [self.drop(o3), self.drop(o4), self.drop(o5)]

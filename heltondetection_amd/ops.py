@@ -835,6 +835,54 @@ def _cl_row_stride(t: torch.Tensor, vec: int):
     return ld
 
 
+# ------------------------------------------------------------------------------- upsample 2x + concat
+class _UpCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, small, big):
+        lib = _lib.load()
+        B, Cs, Hs, Ws = small.shape
+        Cb, H, W = big.shape[1], big.shape[2], big.shape[3]
+        dt = 0 if small.dtype == torch.float32 else 1
+        vec = 4 if dt == 0 else 8
+        out = torch.empty((B, Cs + Cb, H, W), dtype=small.dtype, device=small.device, memory_format=torch.channels_last)
+        check(lib.hd_upsample2x_cat_fwd(_ptr(small), int(_cl_row_stride(small, vec)), _ptr(big), int(_cl_row_stride(big, vec)), dt,
+                                        B, H, W, Cs, Cb, _ptr(out), Cs + Cb, _stream(small)), "hd_upsample2x_cat_fwd")
+        ctx.meta = (dt, B, H, W, Cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        dt, B, H, W, Cs = ctx.meta
+        vec = 4 if dt == 0 else 8
+        want = torch.float32 if dt == 0 else torch.bfloat16
+        if g.dtype != want or _cl_row_stride(g, vec) is None:
+            g = g.to(want).contiguous(memory_format=torch.channels_last)
+        d_small = None
+        if ctx.needs_input_grad[0]:
+            d_small = torch.empty((B, Cs, H // 2, W // 2), dtype=want, device=g.device, memory_format=torch.channels_last)
+            check(lib.hd_upsample2x_cat_bwd(_ptr(g), int(_cl_row_stride(g, vec)), dt, B, H, W, Cs, _ptr(d_small), Cs, _stream(g)),
+                  "hd_upsample2x_cat_bwd")
+        return d_small, (g[:, Cs:] if ctx.needs_input_grad[1] else None)
+
+
+def upsample2x_cat_supported(small: torch.Tensor, big: torch.Tensor) -> bool:
+    if not (small.is_cuda and big.is_cuda and small.dim() == 4 and big.dim() == 4 and small.dtype == big.dtype
+            and small.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    vec = 4 if small.dtype == torch.float32 else 8
+    return (big.shape[0] == small.shape[0] and big.shape[2] == 2 * small.shape[2] and big.shape[3] == 2 * small.shape[3]
+            and small.shape[1] % vec == 0 and big.shape[1] % vec == 0
+            and _cl_row_stride(small, vec) is not None and _cl_row_stride(big, vec) is not None)
+
+
+def upsample2x_cat(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+    """cat(nearest-upsample-2x(small), big) along channels, one kernel, channels-last (csrc/upcat.hip)."""
+    if not upsample2x_cat_supported(small, big):
+        raise _lib.HdError("upsample2x_cat: needs same-dtype channels-last HIP tensors with big = 2x small spatially")
+    return _UpCatFn.apply(small, big)
+
+
 # ------------------------------------------------------------------------------- 1x1 convolution (MFMA GEMM)
 def pointwise_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """x: [B, Cin, H, W] bf16 channels-last rows (dense or a channel slice); weight: [Cout, Cin, 1, 1] bf16 dense."""

@@ -437,6 +437,17 @@ size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout);
 hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R, int Cin,
                              int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
 
+/* ---- nearest 2x upsampling + channel concatenation in one pass (csrc/upcat.hip) ----
+ * The top-down junctions of the YOLOv5 PAFPN neck (README.md:9): out[b, y, x, :] = [small[b, y/2, x/2, :] | big[b, y, x, :]]
+ * on channels-last rows.  H, W: the fine grid (even); small is [B, H/2, W/2, Cs], big [B, H, W, Cb], out [B, H, W, Cs+Cb];
+ * dtype 0 float32 (channels % 4 == 0) / 1 bfloat16 (channels % 8 == 0); row strides in elements, 0 = dense.
+ * Backward: d_small[b, y, x, :] = sum of the four fine gradients grad_out[b, 2y+{0,1}, 2x+{0,1}, :Cs] (float32
+ * accumulate); the gradient of `big` is the channel slice grad_out[..., Cs:] itself (a view for the caller). */
+hd_status hd_upsample2x_cat_fwd(const void* small, int64_t small_row_stride, const void* big, int64_t big_row_stride, int dtype,
+                                int B, int H, int W, int Cs, int Cb, void* out, int64_t out_row_stride, hd_stream stream);
+hd_status hd_upsample2x_cat_bwd(const void* grad_out, int64_t grad_row_stride, int dtype, int B, int H, int W, int Cs,
+                                void* d_small, int64_t d_small_row_stride, hd_stream stream);
+
 /* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
 
 /* images/out: float32 [B,3,S,S] with element strides (b,c,y,x); S even; out must not alias images.
