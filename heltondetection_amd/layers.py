@@ -133,6 +133,8 @@ class ConvBNAct(nn.Module):
                 # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
                 y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(self.bn, x.device))
                 return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out, stats_done=True)
+            if ops.pointwise_backward_usable(xb, w):  # Cin > 256: the library's forward, our weight / data gradients
+                return FusedBNAct.apply(self.bn, ops.pointwise_conv(xb, w, None), self.act_name, residual, True, out)
         y = self.conv(x)
         if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
             return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out)

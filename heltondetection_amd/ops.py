@@ -995,8 +995,12 @@ class _PointwiseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, slot):
         N, K = weight.shape[0], weight.shape[1]
-        sums = _fwd_sums(slot, N) if slot is not None else None
-        y = pointwise_conv_rows(x, weight.view(N, K), sums)
+        if slot is not None or pointwise_conv_usable(x, weight):
+            sums = _fwd_sums(slot, N) if slot is not None else None
+            y = pointwise_conv_rows(x, weight.view(N, K), sums)
+        else:  # a reduction too long for the resident-weight kernel: MIOpen's forward, our backward
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            y = torch.nn.functional.conv2d(xd, weight)
         ctx.save_for_backward(x, weight)
         return y
 
@@ -1036,6 +1040,16 @@ def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatS
 
 def pointwise_conv_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return weight.shape[1] <= POINTWISE_MAX_REDUCTION and pointwise_conv_supported(x, weight)
+
+
+def pointwise_backward_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """The backward kernels alone are worth taking (weight gradient without zero-fill / cast launches) even where the
+    forward stays with the library: channel counts that are multiples of 64, bf16 channels-last rows."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 4
+            and weight.shape[2:] == (1, 1) and weight.shape[1] == x.shape[1] and weight.is_contiguous()):
+        return False
+    B, K, H, W = x.shape
+    return pointwise_wgrad_supported(B * H * W, K, weight.shape[0]) and _cl_row_stride(x, 8) is not None
 
 
 class _BNActFn(torch.autograd.Function):

@@ -153,3 +153,35 @@ def test_pointwise_dgrad_from_the_forward_weight(shape):
     dy = torch.randn(dy.shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn((N, K), generator=g) * N ** -0.5).to(dev).to(torch.bfloat16)
     assert torch.equal(ops.pointwise_dgrad_rows(dy, w), ops.pointwise_conv_rows(dy, w.t().contiguous()))
+
+
+def test_long_reduction_layer_uses_library_forward_and_our_backward():
+    """Cin = 512 > 256: forward through MIOpen (+ the separate statistics kernel), weight gradient through
+    hd_pointwise_wgrad; results must match the all-library path."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = layers.ConvBNAct(512, 512, 1, 1).to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((4, 512, 10, 10), device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((4, 512, 10, 10), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.pointwise = on
+        try:
+            m.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            ops.enable_timing("pointwise_wgrad")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            (y.float() * gy).sum().backward()
+            torch.cuda.synchronize()
+            ran = len(ops.collect_timing()["pointwise_wgrad"])
+            ops.disable_timing()
+            assert ran == (1 if on else 0)
+            res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
+        finally:
+            layers.ConvBNAct.pointwise = True
+    for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        assert err < 3e-2, (name, err)
