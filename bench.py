@@ -350,71 +350,53 @@ def bn_family_roofline(model, batch, args, device):
     backward passes of this workload with every fused-BN launch stamping its own HIP event pair (kernel begin / end,
     hd_debug_time_next_launch), so each kernel is timed on its real tensors in its real cache state (x fresh from the
     convolution for stats / apply, x cold and dy fresh for the backward pair) — what a profiler reports for the same
-    launches inside the replayed graph.  achieved = algorithmic bytes of all launches of a step / their summed time."""
+    launches inside the replayed graph.  achieved = algorithmic bytes of all launches of a step / their summed time;
+    the ops note each launch's algorithmic bytes and shape themselves (ops._note_bytes), in launch order."""
     from heltondetection_amd import ops
-    from heltondetection_amd.layers import ConvBNAct
-    recs, hooks = [], []
-
-    def hook(mod, inp, out):
-        if isinstance(out, tuple):  # a two-place output (the merged C3 branch convolutions): one BN over all channels
-            shape = (out[0].shape[0], sum(o.shape[1] for o in out)) + tuple(out[0].shape[2:])
-        else:
-            shape = tuple(out.shape)
-        recs.append((shape, mod.act_name, len(inp) > 1 and inp[1] is not None))
-
-    for m in model.modules():
-        if isinstance(m, ConvBNAct):
-            hooks.append(m.register_forward_hook(hook))
     names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
-    passes, per_pass = 3, []
+    pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad")
+    passes, per_pass, notes, tags = 3, [], None, None
     try:
-        for it in range(passes + 1):  # the first pass warms up and fills `recs`
-            if it == 1:
-                for h in hooks:
-                    h.remove()
-                hooks = []
+        for it in range(passes + 1):  # the first pass warms up
             model.zero_grad(set_to_none=True)
             ops.bn_arena_reset(device)
             if it >= 1:
-                ops.enable_timing(*names)
+                ops.enable_timing(*names, *pw_names)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
                 loss, _ = model.forward_train(*batch)
             loss.backward()
             torch.cuda.synchronize()
             if it >= 1:
                 per_pass.append({k: v for k, v in ops.collect_timing().items()})
+                notes, tags = ops.collect_bytes(), ops.collect_tags()
                 ops.disable_timing()
     finally:
         ops.disable_timing()
-        for h in hooks:
-            h.remove()
         model.zero_grad(set_to_none=True)
     esz = 4 if args.fp32 else 2
-    tb = [s[0] * s[1] * s[2] * s[3] * esz for s, _, _ in recs]
-    # algorithmic tensor passes: stats 1, apply 2 (+1 with a fused shortcut read), bwd_reduce 2, bwd_dx 3
-    bytes_k = {"bn_stats_kernel": sum(tb), "bn_apply_kernel": sum((3 if r[2] else 2) * t for r, t in zip(recs, tb)),
-               "bn_bwd_reduce_kernel": 2 * sum(tb), "bn_bwd_dx_kernel": 3 * sum(tb)}
+    # algorithmic tensor passes: stats 1 (only where the convolution's epilogue did not take them), apply 2 (+1 with a
+    # fused residual read), bwd_reduce 2 (+1), bwd_dx 3 (+2: residual in, d(residual) out)
+    bytes_k = {k: sum(notes[k]) for k in names}
     med = lambda v: sorted(v)[len(v) // 2]
     ms_k = {k: med([sum(p[k]) for p in per_pass]) for k in names}
     n_k = {k: len(per_pass[0][k]) for k in names}
     tot_ms, tot_bytes, n_launch = sum(ms_k.values()), sum(bytes_k.values()), sum(n_k.values())
-    sizes = sorted(set(tb))
-    # per layer shape (forward order of the first occurrence): the launch times of the middle pass
+    n_layers = n_k["bn_apply_kernel"]
+    # per layer shape: the launch times of the middle pass, paired with the tags noted at the same launches
     mid = per_pass[len(per_pass) // 2]
     by_shape = {}
-    for i, key in enumerate(recs):
-        e = by_shape.setdefault(key, {"layers": 0, "us": {k: 0.0 for k in names}})
-        e["layers"] += 1
-        e["us"]["bn_stats_kernel"] += mid["bn_stats_kernel"][i] * 1e3
-        e["us"]["bn_apply_kernel"] += mid["bn_apply_kernel"][i] * 1e3
-        j = len(recs) - 1 - i  # backward visits the layers in reverse order
-        e["us"]["bn_bwd_reduce_kernel"] += mid["bn_bwd_reduce_kernel"][j] * 1e3 if j < len(mid["bn_bwd_reduce_kernel"]) else 0.0
-        e["us"]["bn_bwd_dx_kernel"] += mid["bn_bwd_dx_kernel"][j] * 1e3 if j < len(mid["bn_bwd_dx_kernel"]) else 0.0
+    for k in names:
+        for t_ms, tag in zip(mid[k], tags[k]):
+            e = by_shape.setdefault(tag, {"n": {q: 0 for q in names}, "us": {q: 0.0 for q in names}})
+            e["n"][k] += 1
+            e["us"][k] += t_ms * 1e3
+    sizes = sorted(int(torch.tensor(tag[0]).prod().item()) * esz for tag in by_shape)
     fam = _hbm_entry("fused BN+act family (bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_dx), step-weighted over the "
-                     f"model's {len(recs)} BatchNorm layers", tot_ms, tot_bytes, n_launch,
-                     {"bn_layers": len(recs), "launches_per_step": n_launch, "sum_launch_ms_per_step": round(tot_ms, 4),
+                     f"model's {n_layers} BatchNorm layers", tot_ms, tot_bytes, n_launch,
+                     {"bn_layers": n_layers, "stats_in_conv_epilogue_layers": n_layers - n_k["bn_stats_kernel"],
+                      "launches_per_step": n_launch, "sum_launch_ms_per_step": round(tot_ms, 4),
                       "algorithmic_bytes_per_step": int(tot_bytes), "distinct_layer_shapes": len(by_shape),
-                      "layer_bytes_min_max": [int(sizes[0]), int(sizes[-1])] if sizes else None,
+                      "layer_bytes_min_max": [sizes[0], sizes[-1]] if sizes else None,
                       "timed": "inside 3 eager forward+loss+backward passes of this workload right after the timed region: every "
                                "fused-BN launch stamps its own HIP event pair with the kernel's begin / end (hipExtLaunchKernel "
                                "through hd_debug_time_next_launch) on the launch stream; per kernel the summed time of a pass, "
@@ -422,12 +404,32 @@ def bn_family_roofline(model, batch, args, device):
                       "per_kernel": {k: {"sum_ms": round(ms_k[k], 4), "GB/s": round(bytes_k[k] / ms_k[k] / 1e6, 1),
                                          "frac": round(bytes_k[k] / ms_k[k] / 1e6 / HBM_PEAK_GBS, 4), "launches": n_k[k]}
                                      for k in names},
-                      "per_shape": [{"shape": list(key[0]), "act": key[1], "shortcut": bool(key[2]), "layers": e["layers"],
-                                     "MB": round(key[0][0] * key[0][1] * key[0][2] * key[0][3] * esz / 1e6, 2),
-                                     "us_per_layer": {k.replace("bn_", "").replace("_kernel", ""): round(v / e["layers"], 2)
-                                                      for k, v in e["us"].items()}}
-                                    for key, e in by_shape.items()]},
+                      "per_shape": [{"shape": list(tag[0]), "act": {0: None, 1: "silu", 2: "relu"}.get(tag[1], tag[1]),
+                                     "residual_mode": tag[2], "stats_in_conv_epilogue": bool(tag[3]),
+                                     "layers": e["n"]["bn_apply_kernel"],
+                                     "MB": round(int(torch.tensor(tag[0]).prod().item()) * esz / 1e6, 2),
+                                     "us_per_launch": {k.replace("bn_", "").replace("_kernel", ""):
+                                                       (round(e["us"][k] / e["n"][k], 2) if e["n"][k] else None) for k in names}}
+                                    for tag, e in by_shape.items()]},
                      traffic=pmc_traffic("bn_family_step", f"{model_name(args)} {args.size} bs{args.batch}"))
+    # the hand-written 1x1 convolution kernels of the same passes (csrc/pointwise_conv.hip), step-weighted likewise
+    pw = None
+    if any(len(per_pass[0].get(k, ())) for k in pw_names):
+        pms = {k: med([sum(p[k]) for p in per_pass]) for k in pw_names}
+        pby = {k: sum(notes[k]) for k in pw_names}
+        pn = {k: len(per_pass[0][k]) for k in pw_names}
+        pw = _hbm_entry("1x1 convolution family (pointwise_conv fwd + BN statistics / pointwise_dgrad / pointwise_wgrad + "
+                        "reduce), step-weighted over the model's 1x1 ConvBNAct layers", sum(pms.values()), sum(pby.values()),
+                        sum(pn.values()),
+                        {"sum_launch_ms_per_step": round(sum(pms.values()), 4), "algorithmic_bytes_per_step": int(sum(pby.values())),
+                         "algorithmic_bytes": "2 (R (Cin + Cout) + Cin Cout) per call: each operand once, bf16",
+                         "timed": "same passes and event mechanism as the BN family; pointwise_wgrad is an event pair around its "
+                                  "two launches (row-sliced partial products, slab reduction)",
+                         "per_kernel": {k: {"sum_ms": round(pms[k], 4), "calls": pn[k],
+                                            "GB/s": round(pby[k] / pms[k] / 1e6, 1) if pms[k] > 0 else None,
+                                            "frac": round(pby[k] / pms[k] / 1e6 / HBM_PEAK_GBS, 4) if pms[k] > 0 else None}
+                                        for k in pw_names}})
+    fam["_pointwise"] = pw
     return fam
 
 
@@ -682,10 +684,13 @@ def main():
                 out["roofline"] = None
             elif args.model == "yolov5":
                 out["roofline"] = bn_family_roofline(model, batches[0], args, device)
-                out["roofline_secondary"] = [yolo_dense_grad_roofline(model, batches[0], args)]
+                pw_entry = out["roofline"].pop("_pointwise", None)
+                out["roofline_secondary"] = ([pw_entry] if pw_entry else []) + [yolo_dense_grad_roofline(model, batches[0], args)]
             else:
                 out["roofline"] = roi_align_roofline(model, batches[0], args, device)
-                out["roofline_secondary"] = [bn_family_roofline(model, batches[0], args, device)]
+                fam_ = bn_family_roofline(model, batches[0], args, device)
+                pw_entry = fam_.pop("_pointwise", None)
+                out["roofline_secondary"] = [fam_] + ([pw_entry] if pw_entry else [])
         except Exception as e:  # never lose the headline number to a secondary measurement
             out["roofline_error"] = repr(e)[:300]
         if world == 1 and not args.no_micro:

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -107,6 +107,8 @@ SIGNATURES = {
     "hd_yolo_nms": (_I, [_P, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "hd_pointwise_conv_supported": (_I, [_L, _I, _I]),
     "hd_pointwise_conv": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _P]),
+    "hd_pointwise_conv_resident": (_I, [_L, _I, _I]),
+    "hd_pointwise_conv_dgrad_supported": (_I, [_L, _I, _I]),
     "hd_pointwise_conv_dgrad": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "hd_pointwise_wgrad_supported": (_I, [_L, _I, _I]),
     "hd_pointwise_wgrad_workspace_bytes": (_Z, [_L, _I, _I]),

@@ -698,10 +698,25 @@ extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, c
   return HD_OK;
 }
 
+extern "C" int hd_pointwise_conv_resident(int64_t R, int Cin, int Cout) {
+  // 1 when hd_pointwise_conv takes the streaming form (weights resident in LDS), the one worth preferring to the library
+  if (!(Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256) || !hd_pointwise_conv_supported(R, Cin, Cout)) return 0;
+  const int max_bn = Cin <= 128 ? 128 : 64;
+  const int bn = (Cout % 128 == 0 && max_bn >= 128) ? 128 : (Cout % 64 == 0 ? 64 : 32);
+  return Cout / bn <= 8;
+}
+
+extern "C" int hd_pointwise_conv_dgrad_supported(int64_t R, int Cin, int Cout) {
+  if (!(Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) || !hd_pointwise_conv_supported(R, Cout, Cin)) return 0;
+  const int max_bn = Cout <= 128 ? 128 : 64;  // the column tile try_stream<Cout, true> picks over the Cin output channels
+  const int bn = (Cin % 128 == 0 && max_bn >= 128) ? 128 : (Cin % 64 == 0 ? 64 : 32);
+  return Cin / bn <= 8;
+}
+
 extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout,
                                              void* dx, int64_t dx_row_stride, hd_stream stream) {
   if (!dy || !w || !dx) return HD_ERR_NULL;
-  if (!hd_pointwise_conv_supported(R, Cout, Cin) || Cout > 256) return HD_ERR_SHAPE;  // the reduction runs over Cout
+  if (!hd_pointwise_conv_dgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;  // the reduction runs over Cout
   if (dy_row_stride == 0) dy_row_stride = Cout;
   if (dx_row_stride == 0) dx_row_stride = Cin;
   if (dy_row_stride < Cout || dx_row_stride < Cin || dy_row_stride % 8 || dx_row_stride % 8) return HD_ERR_SHAPE;

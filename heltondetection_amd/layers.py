@@ -118,23 +118,36 @@ class ConvBNAct(nn.Module):
         self.act_name = act
         self._is_pointwise = k == 1 and s == 1 and g == 1
 
+    def pointwise_mode(self, x) -> int:
+        """How this layer's convolution runs on `x` in training: 2 = hd_pointwise_conv with the BatchNorm statistics in its
+        epilogue (+ our backward kernels), 1 = library forward + our backward kernels, 0 = the library throughout."""
+        if not (self.fused and self.pointwise and self._is_pointwise and x.is_cuda and FusedBNAct.enabled and self.bn.training
+                and self.bn.momentum is not None and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.bn.num_features // 8 <= 256):
+            return 0
+        from . import ops
+        w = self.conv.lp_weight()
+        if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:  # decide on what the kernels would see
+            w = w.detach().to(torch.bfloat16)
+            x = x.detach().to(torch.bfloat16)
+        if ops.pointwise_conv_usable(x, w):
+            return 2
+        return 1 if ops.pointwise_backward_usable(x, w) else 0
+
     def forward(self, x, residual=None, out=None):
         """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut).
         out: a CatBuffer slot for the result (see FusedBNAct.apply)."""
-        if self.fused and self.pointwise and self._is_pointwise and x.is_cuda and FusedBNAct.enabled and self.bn.training \
-                and self.bn.momentum is not None and torch.is_autocast_enabled("cuda") \
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        mode = self.pointwise_mode(x)
+        if mode:
             from . import ops
             w = self.conv.lp_weight()
-            if w.dtype != torch.bfloat16:
-                w = w.to(torch.bfloat16)
+            w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-            if ops.pointwise_conv_usable(xb, w) and self.bn.num_features // 8 <= 256:
-                # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
+            if mode == 2:  # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
                 y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(self.bn, x.device))
                 return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out, stats_done=True)
-            if ops.pointwise_backward_usable(xb, w):  # Cin > 256: the library's forward, our weight / data gradients
-                return FusedBNAct.apply(self.bn, ops.pointwise_conv(xb, w, None), self.act_name, residual, True, out)
+            # Cin > 256: the library's forward, our weight / data gradients
+            return FusedBNAct.apply(self.bn, ops.pointwise_conv(xb, w, None), self.act_name, residual, True, out)
         y = self.conv(x)
         if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
             return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out)

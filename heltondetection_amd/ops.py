@@ -44,16 +44,40 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 # Events are recorded on the stream the kernel is launched on (torch's current stream, the one
 # handed to the C ABI), immediately around the call; nothing is synchronised here.
 _TIMED: dict = {}
+_TIMED_BYTES: dict = {}
+_TIMED_TAGS: dict = {}
 
 
 def enable_timing(*names: str) -> None:
     _TIMED.clear()
+    _TIMED_BYTES.clear()
+    _TIMED_TAGS.clear()
     for n in names:
         _TIMED[n] = []
+        _TIMED_BYTES[n] = []
+        _TIMED_TAGS[n] = []
 
 
 def disable_timing() -> None:
     _TIMED.clear()
+    _TIMED_BYTES.clear()
+    _TIMED_TAGS.clear()
+
+
+def _note_bytes(name: str, nbytes: int, tag=None) -> None:
+    """Algorithmic bytes (and a shape tag) of a timed launch, noted by ops that know their own operand sizes, in launch
+    order — bench.py's step-weighted rooflines pair them with the launch's event times."""
+    if name in _TIMED_BYTES:
+        _TIMED_BYTES[name].append(int(nbytes))
+        _TIMED_TAGS[name].append(tag)
+
+
+def collect_bytes() -> dict:
+    return {n: list(v) for n, v in _TIMED_BYTES.items()}
+
+
+def collect_tags() -> dict:
+    return {n: list(v) for n, v in _TIMED_TAGS.items()}
 
 
 def collect_timing() -> dict:
@@ -910,6 +934,7 @@ def pointwise_conv_rows(x: torch.Tensor, w2: torch.Tensor, stats: Optional[torch
     ld_y = _cl_row_stride(out, 8)
     if ld_y is None or out.shape != (B, N, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_conv: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cout, H, W]")
+    _note_bytes(name, 2 * (B * H * W * (K + N) + N * K))
     with _ktimed(name):
         check(lib.hd_pointwise_conv(_ptr(x), int(ld_x), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_y), _ptr(stats), _stream(x)),
               "hd_pointwise_conv")
@@ -952,6 +977,7 @@ def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch
     ld_dx = _cl_row_stride(out, 8)
     if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
+    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K))
     with _ktimed("pointwise_dgrad"):
         check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
               "hd_pointwise_conv_dgrad")
@@ -977,6 +1003,7 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64")
     ws = _wgrad_workspace(dy.device, nbytes)
     dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K))
     with _timed("pointwise_wgrad"):
         check(lib.hd_pointwise_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), R, K, N, _ptr(dw), _ptr(ws), ws.numel(),
                                      _stream(dy)), "hd_pointwise_wgrad")
@@ -1012,7 +1039,7 @@ class _PointwiseConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16 or _cl_row_stride(dy, 8) is None:
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        ours = need_dx and N in (32, 64, 128, 256) and _lib.load().hd_pointwise_conv_supported(x.shape[0] * x.shape[2] * x.shape[3], N, K)
+        ours = need_dx and bool(_lib.load().hd_pointwise_conv_dgrad_supported(x.shape[0] * x.shape[2] * x.shape[3], K, N))
         if ours:
             dx = pointwise_dgrad_rows(dy, weight.view(N, K))
         R = x.shape[0] * x.shape[2] * x.shape[3]
@@ -1039,7 +1066,10 @@ def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatS
 
 
 def pointwise_conv_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    return weight.shape[1] <= POINTWISE_MAX_REDUCTION and pointwise_conv_supported(x, weight)
+    """The forward kernel is preferred to the library where it runs in its streaming form (Cin <= 256, <= 8 column tiles)."""
+    if not pointwise_conv_supported(x, weight):
+        return False
+    return bool(_lib.load().hd_pointwise_conv_resident(x.shape[0] * x.shape[2] * x.shape[3], weight.shape[1], weight.shape[0]))
 
 
 def pointwise_backward_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -1087,7 +1117,10 @@ class _BNActFn(torch.autograd.Function):
         save = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         w, b = weight.detach().float(), bias.detach().float()
+        tb = x.numel() * x.element_size()
+        tag = (tuple(x.shape), int(act), int(res_mode) if res is not None else 0, bool(stats_done))
         if not stats_done:
+            _note_bytes("bn_stats_kernel", tb, tag)
             with _ktimed("bn_stats_kernel"):
                 check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
         stat_rows = 0
@@ -1097,6 +1130,7 @@ class _BNActFn(torch.autograd.Function):
             import torch.distributed as dist
             dist.all_reduce(sums, group=sync_group)
             stat_rows = R * dist.get_world_size(sync_group)
+        _note_bytes("bn_apply_kernel", (3 if res is not None else 2) * tb, tag)
         with _ktimed("bn_apply_kernel"):
             check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
                                       _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
@@ -1106,6 +1140,7 @@ class _BNActFn(torch.autograd.Function):
         keep_res = res if (res is not None and int(res_mode) == 1) else None
         ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
         ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows, 0 if res is None else int(res_mode), split)
+        ctx.tag = tag
         return y if y2 is None else (y, y2)
 
     @staticmethod
@@ -1146,6 +1181,9 @@ class _BNActFn(torch.autograd.Function):
         dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
         st = _stream(x)
         dres = torch.empty_like(x) if res is not None else None
+        tb = x.numel() * x.element_size()
+        _note_bytes("bn_bwd_reduce_kernel", (3 if res is not None else 2) * tb, ctx.tag)  # x, dy (+ the pre-activation residual)
+        _note_bytes("bn_bwd_dx_kernel", (5 if res is not None else 3) * tb, ctx.tag)      # x, dy -> dx (+ residual in, d(res) out)
         with _ktimed("bn_bwd_reduce_kernel"):
             check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
                                            act, _ptr(res), _ptr(dsums), tail_ref, st), "hd_bn_act_bwd_reduce")

@@ -423,6 +423,8 @@ int hd_pointwise_conv_supported(int64_t R, int Cin, int Cout);
 /* Data gradient straight from the forward weight w[Cout, Cin] (its columns are read through LDS transpose reads, no
  * transposed copy): dx[R, Cin] = dy[R, Cout] . w.  Cout in {32, 64, 128, 256} (the weight slab must stay in LDS);
  * other shapes: HD_ERR_SHAPE, and the caller uses hd_pointwise_conv with a transposed copy or the library. */
+int hd_pointwise_conv_resident(int64_t R, int Cin, int Cout);  /* 1: streaming form (weights resident in LDS) */
+int hd_pointwise_conv_dgrad_supported(int64_t R, int Cin, int Cout);
 hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout, void* dx,
                                   int64_t dx_row_stride, hd_stream stream);
 hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout, void* y,

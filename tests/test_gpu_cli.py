@@ -37,8 +37,9 @@ def test_cli_yolov5_train_eval_test_on_hip(gpu, tmp_path):
     assert out["metrics"] is not None and 0.0 <= out["metrics"]["mAP50"] <= 1.0        # eval_every ran inside the loop
     m = cli.main(["eval", "--config", cfg, "--work-dir", work])
     assert m["images"] == 8 and os.path.exists(m["results"])
-    # the in-loop evaluation and the stand-alone one see the same weights -> the same detections
-    assert m["detections"] == out["metrics"]["detections"] and abs(m["mAP50"] - out["metrics"]["mAP50"]) < 1e-9
+    # the in-loop evaluation and the stand-alone one see the same weights -> the same detections, up to the bf16
+    # convolution solvers MIOpen's find mode picks per process (a low-confidence box can change rank)
+    assert m["detections"] == out["metrics"]["detections"] and abs(m["mAP50"] - out["metrics"]["mAP50"]) < 1e-3
     t = cli.main(["test", "--config", cfg, "--work-dir", work, "--set", "test.conf_thr=0.05"])
     assert t["images"] == 8 and os.path.exists(t["path"])
     dets = json.load(open(t["path"]))

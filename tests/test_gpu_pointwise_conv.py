@@ -185,3 +185,34 @@ def test_long_reduction_layer_uses_library_forward_and_our_backward():
     for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 1024), (1024, 256), (2048, 512), (64, 256)])
+def test_resnet_width_layers_train_through_conv_bn_act(cin, cout):
+    """ResNet50 bottleneck widths (up to 2048): whichever of our kernels does not take a shape, the layer must still
+    train (library fallback per direction) and agree with the all-library path."""
+    from heltondetection_amd import _lib, layers, ops
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    assert lib.hd_pointwise_conv_dgrad_supported(1000, 1024, 256) == 0  # 16 column tiles of 64: not resident
+    assert lib.hd_pointwise_conv_resident(1000, 256, 1024) == 0
+    torch.manual_seed(2)
+    m = layers.ConvBNAct(cin, cout, 1, 1, act="relu").to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((2, cin, 13, 13), device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((2, cout, 13, 13), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.pointwise = on
+        try:
+            m.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            (y.float() * gy).sum().backward()
+            res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
+        finally:
+            layers.ConvBNAct.pointwise = True
+    for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        assert err < 3e-2, (name, err)

@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+(cd $R && python3 bench.py --steps 5 --warmup 6 --no-micro --no-cpu-baseline --no-roofline > /tmp/warm.log 2>&1)
+rm -rf /tmp/pt1
+(cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt1 -- python3 bench.py --steps 30 --warmup 8 --no-micro --no-cpu-baseline --no-roofline > gpurun_out/trace_bench.log 2>&1)
+python3 $R/tools/step_trace_parse_r02.py /tmp/pt1 160 > $R/gpurun_out/trace_steps.txt 2>&1
+head -5 $R/gpurun_out/trace_steps.txt | cut -c1-150
