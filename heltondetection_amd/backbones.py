@@ -8,7 +8,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import C3, SPPF, ConvBNAct, FusedBNAct, ShadowConv2d
+from .layers import C3, SPPF, ConvBNAct, FusedBNAct, ShadowConv2d, conv_bn_act
 from .registry import BACKBONES
 
 
@@ -75,11 +75,12 @@ class _ResBottleneck(nn.Module):
         if self.downsample is None:
             idt = x
         else:
-            idt = FusedBNAct.apply(self.downsample[1], self.downsample[0](x), None)
-        y = FusedBNAct.apply(self.bn1, self.conv1(x), "relu")
-        y = FusedBNAct.apply(self.bn2, self.conv2(y), "relu")
+            idt = conv_bn_act(self.downsample[0], self.downsample[1], None, x)
+        # the 1x1 convolutions (conv1, conv3, a stride-1 downsample) take the MFMA kernels of csrc/pointwise_conv.hip
+        y = conv_bn_act(self.conv1, self.bn1, "relu", x)
+        y = conv_bn_act(self.conv2, self.bn2, "relu", y)
         # relu(bn3(conv3) + identity) in one fused kernel (residual added before the activation)
-        return FusedBNAct.apply(self.bn3, self.conv3(y), "relu", idt, False)
+        return conv_bn_act(self.conv3, self.bn3, "relu", y, idt, False)
 
 
 @BACKBONES.register()

@@ -600,6 +600,139 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float
   }
 }
 
+// ---- 3x3 / stride 1 / pad 1 weight gradient -------------------------------------------------------------------
+//     dW[n][ky][kx][k] = sum over (b, h, w) of dY[b, h, w, n] * X[b, h + ky - 1, w + kx - 1, k]
+// The same transposed-fragment scheme, one image row at a time: a workgroup owns a 64 x 64 (n, k) tile for ALL nine
+// taps (9 x 16 accumulator registers per lane) and a slice of image rows.  LDS holds a ring of three X rows
+// (h - 1, h, h + 1), each with one zero pixel of halo on both sides and zero padding up to a multiple of 16 pixels, and
+// the dY row; the nine taps are nine (row slot, pixel shift) views of that ring, so borders need no masks — out-of-image
+// rows are stored as zeros, out-of-image pixels are the halo.  Per 16 pixels a wave issues one dY fragment, nine X
+// fragments and nine MFMAs.  The next X row and dY row travel in registers while the current row is multiplied.
+template <int W>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+                                                            const unsigned short* __restrict__ X, long long ld_x, int B, int H,
+                                                            int N, int K, int rows_per_slice, float* __restrict__ slab) {
+  constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
+  constexpr int SX = 64 * 2 + 64;                 // bytes per pixel row of a 64-channel tile, padded
+  constexpr int XROW = (WP + 2) * SX, DYROW = WP * SX;
+  constexpr int CH = W * 8;                       // 16-byte chunks per image row of a 64-channel tile
+  constexpr int IT = (CH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 X rows | dY row]
+  unsigned char* xs = smem;
+  unsigned char* ys = smem + 3 * XROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = K / 64;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int spi = (H + rows_per_slice - 1) / rows_per_slice;  // slices per image
+  const int b = blockIdx.y / spi, h0 = (blockIdx.y % spi) * rows_per_slice;
+  const int h1 = min(H, h0 + rows_per_slice);
+
+  for (int i = tid; i < (3 * XROW + DYROW) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  auto load_x = [&](int h, u32x4* r) {  // image row h of X (zeros outside the image)
+    const int hc = min(max(h, 0), H - 1);
+    const unsigned short* base = X + ((long long)(b * H + hc) * W) * ld_x + k0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int id = i * 256 + tid;
+      if (CH % 256 == 0 || id < CH) r[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_x + (id & 7) * 8);
+    }
+  };
+  auto load_y = [&](int h, u32x4* r) {
+    const int hc = min(h, H - 1);
+    const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int id = i * 256 + tid;
+      if (CH % 256 == 0 || id < CH) r[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_dy + (id & 7) * 8);
+    }
+  };
+  auto stash_x = [&](int h, const u32x4* r) {
+    unsigned char* slot = xs + ((h + 3) % 3) * XROW;
+    const bool in = h >= 0 && h < H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int id = i * 256 + tid;
+      if (CH % 256 == 0 || id < CH) *reinterpret_cast<u32x4*>(slot + ((id >> 3) + 1) * SX + (id & 7) * 16) = in ? r[i] : zero;
+    }
+  };
+  auto stash_y = [&](const u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int id = i * 256 + tid;
+      if (CH % 256 == 0 || id < CH) *reinterpret_cast<u32x4*>(ys + (id >> 3) * SX + (id & 7) * 16) = r[i];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  u32x4 rx[IT], ry[IT];
+  if (h0 < h1) {
+    load_x(h0 - 1, rx); stash_x(h0 - 1, rx);
+    load_x(h0, rx);     stash_x(h0, rx);
+    load_x(h0 + 1, rx); stash_x(h0 + 1, rx);
+    load_y(h0, ry);     stash_y(ry);
+    load_x(h0 + 2, rx);
+    load_y(h0 + 1, ry);
+  }
+  for (int h = h0; h < h1; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const unsigned char* slot = xs + ((h + ky - 1 + 3) % 3) * XROW;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bf16x8 bq = tr_fragment(slot, SX, wk * 32, ks * 16 + kx, lane);
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (h + 1 < h1) {
+      stash_x(h + 2, rx);  // into the slot row h - 1 just left
+      stash_y(ry);
+      load_x(h + 3, rx);
+      load_y(h + 2, ry);
+    }
+  }
+
+  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice][n][tap][k]
+  float* out = slab + (size_t)blockIdx.y * N * 9 * K;
+  const int k = k0 + wk * 32 + (lane & 31);
+  const int nb = n0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((size_t)(nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * K + k] = acc[t][r];
+}
+
+struct Wgrad3Plan {
+  int tiles, rows_per_slice, slices;
+};
+inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout) {
+  Wgrad3Plan p;
+  p.tiles = (Cout / 64) * (Cin / 64);
+  int want = 512 / p.tiles;  // slices: ~2 workgroups per CU in total
+  if (want < B) want = B;
+  int spi = want / B;        // slices per image
+  if (spi < 1) spi = 1;
+  int rps = (H + spi - 1) / spi;
+  if (rps < 4 && H >= 4) rps = 4;  // two halo rows per slice: keep them under a third of the loads
+  p.rows_per_slice = rps;
+  p.slices = B * ((H + rps - 1) / rps);
+  return p;
+}
+
 struct WgradPlan {
   int tm, tn, tiles, splits, rows_per_split;
 };
@@ -729,4 +862,49 @@ extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stri
   if (Cout == 128 && try_stream<128, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   if (Cout == 256 && try_stream<256, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   return HD_ERR_SHAPE;
+}
+
+extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
+  return B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
+         Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff;
+}
+
+extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout)) return 0;
+  return (size_t)wgrad3_plan(B, H, Cin, Cout).slices * Cout * 9 * Cin * sizeof(float);
+}
+
+extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
+                                      int W, int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                      hd_stream stream) {
+  if (!dy || !x || !dw || !workspace) return HD_ERR_NULL;
+  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout)) return HD_ERR_SHAPE;
+  if (dy_row_stride == 0) dy_row_stride = Cout;
+  if (x_row_stride == 0) x_row_stride = Cin;
+  if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
+  if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
+  const Wgrad3Plan p = wgrad3_plan(B, H, Cin, Cout);
+  if (workspace_bytes < (size_t)p.slices * Cout * 9 * Cin * sizeof(float)) return HD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const auto* a = static_cast<const unsigned short*>(dy);
+  const auto* b = static_cast<const unsigned short*>(x);
+  float* slab = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.slices);
+  const int WP = (W + 15) / 16 * 16;
+  const size_t lds = (size_t)(3 * (WP + 2) + WP) * (64 * 2 + 64);
+  if (W == 20)
+    (void)hd_launch(conv3x3_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                    p.rows_per_slice, slab);
+  else if (W == 40)
+    (void)hd_launch(conv3x3_wgrad_kernel<40>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                    p.rows_per_slice, slab);
+  else
+    (void)hd_launch(conv3x3_wgrad_kernel<80>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                    p.rows_per_slice, slab);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  const long long NK = (long long)Cout * 9 * Cin;
+  (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
+                  p.slices, NK, static_cast<unsigned short*>(dw));
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
 }

@@ -116,43 +116,71 @@ class ConvBNAct(nn.Module):
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU(inplace=True), "relu": nn.ReLU(inplace=True), None: nn.Identity()}[act]
         self.act_name = act
-        self._is_pointwise = k == 1 and s == 1 and g == 1
 
     def pointwise_mode(self, x) -> int:
-        """How this layer's convolution runs on `x` in training: 2 = hd_pointwise_conv with the BatchNorm statistics in its
-        epilogue (+ our backward kernels), 1 = library forward + our backward kernels, 0 = the library throughout."""
-        if not (self.fused and self.pointwise and self._is_pointwise and x.is_cuda and FusedBNAct.enabled and self.bn.training
-                and self.bn.momentum is not None and torch.is_autocast_enabled("cuda")
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.bn.num_features // 8 <= 256):
-            return 0
-        from . import ops
-        w = self.conv.lp_weight()
-        if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:  # decide on what the kernels would see
-            w = w.detach().to(torch.bfloat16)
-            x = x.detach().to(torch.bfloat16)
-        if ops.pointwise_conv_usable(x, w):
-            return 2
-        return 1 if ops.pointwise_backward_usable(x, w) else 0
+        """How this layer's convolution runs on `x` in training (see pointwise_mode below)."""
+        return pointwise_mode(self.conv, self.bn, x) if self.fused else 0
 
     def forward(self, x, residual=None, out=None):
         """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut).
         out: a CatBuffer slot for the result (see FusedBNAct.apply)."""
-        mode = self.pointwise_mode(x)
-        if mode:
-            from . import ops
-            w = self.conv.lp_weight()
-            w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
-            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-            if mode == 2:  # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
-                y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(self.bn, x.device))
-                return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out, stats_done=True)
-            # Cin > 256: the library's forward, our weight / data gradients
-            return FusedBNAct.apply(self.bn, ops.pointwise_conv(xb, w, None), self.act_name, residual, True, out)
-        y = self.conv(x)
-        if self.fused:  # fused BN(batch stats)+activation, csrc/bn_act.hip: 4 launches instead of 8
-            return FusedBNAct.apply(self.bn, y, self.act_name, residual, True, out)
-        y = self.act(self.bn(y))
+        if self.fused:
+            return conv_bn_act(self.conv, self.bn, self.act_name, x, residual, True, out)
+        y = self.act(self.bn(self.conv(x)))
         return y if residual is None else y + residual
+
+
+def pointwise_mode(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> int:
+    """How a Conv2d(bias=False) -> BatchNorm2d pair runs on `x` in training: 2 = hd_pointwise_conv with the BatchNorm
+    statistics in its epilogue (+ our backward kernels), 1 = library forward + our weight / data gradients (reductions
+    too long for the resident-weight kernel), 0 = the library throughout (k x k, strided, grouped, biased, eval, fp32)."""
+    if not (ConvBNAct.pointwise and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+            and conv.bias is None and conv.padding == (0, 0) and x.is_cuda and FusedBNAct.enabled and bn.training
+            and bn.momentum is not None and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and bn.num_features // 8 <= 256
+            and conv.weight.requires_grad):
+        return 0
+    from . import ops
+    w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+    if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:  # decide on what the kernels would see
+        w = w.detach().to(torch.bfloat16)
+        x = x.detach().to(torch.bfloat16)
+    if ops.pointwise_conv_usable(x, w):
+        return 2
+    return 1 if ops.pointwise_backward_usable(x, w) else 0
+
+
+def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, residual_after_act: bool = False, out=None):
+    """Conv2d(bias=False) -> BatchNorm2d -> activation [-> / <- residual] on the fused HIP kernels: the 1x1 convolutions on
+    csrc/pointwise_conv.hip where pointwise_mode says so, the BatchNorm + activation always (FusedBNAct.apply)."""
+    mode = pointwise_mode(conv, bn, x)
+    if mode:
+        from . import ops
+        w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+        w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        if mode == 2:  # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
+            y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(bn, x.device))
+            return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
+        return FusedBNAct.apply(bn, ops.pointwise_conv(xb, w, None), act, residual, residual_after_act, out)
+    if _conv3x3_ours(conv, bn, x):
+        from . import ops
+        w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+        w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)  # what autocast would hand the library
+        return FusedBNAct.apply(bn, ops.conv3x3(x, w), act, residual, residual_after_act, out)
+    return FusedBNAct.apply(bn, conv(x), act, residual, residual_after_act, out)
+
+
+def _conv3x3_ours(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
+    """3x3 / stride 1 / pad 1 layers whose weight gradient hd_conv3x3_wgrad takes (bf16 rows, W in {20, 40, 80}, channel
+    counts multiples of 64): forward and data gradient stay with the library."""
+    if not (ConvBNAct.pointwise and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.is_cuda and bn.training
+            and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and conv.weight.requires_grad):
+        return False
+    from . import ops
+    return ops.conv3x3_wgrad_supported(x, conv.out_channels)
 
 
 class Bottleneck(nn.Module):

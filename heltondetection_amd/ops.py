@@ -1010,6 +1010,62 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+def conv3x3_wgrad_supported(x: torch.Tensor, cout: int) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and _cl_row_stride(x, 8) is not None):
+        return False
+    B, K, H, W = x.shape
+    return bool(_lib.load().hd_conv3x3_wgrad_supported(B, H, W, K, int(cout)))
+
+
+def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of a 3x3 / stride 1 / pad 1 convolution: dy [B, Cout, H, W], x [B, Cin, H, W] bf16 channels-last
+    rows -> dw [Cout, Cin, 3, 3] bf16 in channels-last memory ([Cout][ky][kx][Cin]); no autograd."""
+    lib = _lib.load()
+    B, N, H, W = dy.shape
+    K = x.shape[1]
+    ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
+    if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
+            or x.shape[0] != B or x.shape[2:] != dy.shape[2:]):
+        raise _lib.HdError("conv3x3_wgrad: needs bf16 channels-last rows of equal batch and spatial size")
+    nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N)
+    if nbytes == 0:
+        raise _lib.HdError("conv3x3_wgrad: W must be 20, 40 or 80 and the channel counts multiples of 64")
+    ws = _wgrad_workspace(dy.device, nbytes)
+    dw = torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (K + N) + 9 * N * K))
+    with _timed("conv3x3_wgrad"):
+        check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, _ptr(dw), _ptr(ws), ws.numel(),
+                                   _stream(dy)), "hd_conv3x3_wgrad")
+    return dw
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution: forward and data gradient stay with MIOpen, the weight gradient runs on
+    hd_conv3x3_wgrad (no split-K zero-fill, cast or memset launches)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            g = dy if (dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None) else \
+                dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = conv3x3_wgrad_rows(g, x)
+        return dx, dw
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return _Conv3x3Fn.apply(x, weight)
+
+
 POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen
 
 

@@ -1,0 +1,58 @@
+"""hd_conv3x3_wgrad (csrc/pointwise_conv.hip): the 3x3 / stride 1 / pad 1 weight gradient through LDS transpose
+fragments, nine taps as views of a three-row ring with a zero halo."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(dy, x):
+    w = torch.zeros((dy.shape[1], x.shape[1], 3, 3), dtype=torch.float32, device=x.device)
+    return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                               (False, True, False))[1]
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (3, 64, 40, 40, 128), (2, 128, 13, 40, 128),
+                                   (1, 64, 80, 80, 64), (2, 64, 5, 80, 64), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64)])
+def test_conv3x3_wgrad_is_exact_on_integer_data(shape):
+    """Small integers: all products and sums are exact in float32, so borders (zero halo), row slices with their halo
+    rows, the pixel padding to 16 and the tap -> (row slot, shift) mapping must reproduce the exact gradient."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H + W)
+    x = torch.randint(-2, 3, (B, K, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randint(-2, 3, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = ops.conv3x3_wgrad_rows(dy, x)
+    ref = _ref(dy, x)
+    assert dw.shape == (N, K, 3, 3) and dw.dtype == torch.bfloat16
+    assert torch.equal(dw.float(), ref.to(torch.bfloat16).float())
+
+
+def test_conv3x3_layer_matches_library_path():
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = layers.ConvBNAct(64, 64, 3, 1).to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((4, 64, 40, 40), device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((4, 64, 40, 40), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.pointwise = on
+        try:
+            m.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            ops.enable_timing("conv3x3_wgrad")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x.to(torch.bfloat16))
+            (y.float() * gy).sum().backward()
+            torch.cuda.synchronize()
+            assert len(ops.collect_timing()["conv3x3_wgrad"]) == (1 if on else 0)
+            ops.disable_timing()
+            res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
+        finally:
+            layers.ConvBNAct.pointwise = True
+    for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        assert err < 3e-2, (name, err)
