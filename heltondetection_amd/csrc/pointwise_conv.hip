@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float
 template <int W>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                             const unsigned short* __restrict__ X, long long ld_x, int B, int H,
-                                                            int N, int K, int rows_per_slice, float* __restrict__ slab) {
+                                                            int N, int K, int rows_per_slice, int images_per_slice,
+                                                            float* __restrict__ slab) {
   constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
   constexpr int SX = 64 * 2 + 64;                 // bytes per pixel row of a 64-channel tile, padded
   constexpr int XROW = (WP + 2) * SX, DYROW = WP * SX;
@@ -624,14 +625,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = K / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
-  const int spi = (H + rows_per_slice - 1) / rows_per_slice;  // slices per image
-  const int b = blockIdx.y / spi, h0 = (blockIdx.y % spi) * rows_per_slice;
+  // a slice is a range of image rows of one image (rows_per_slice < H), or images_per_slice whole images
+  const int spi = (H + rows_per_slice - 1) / rows_per_slice;  // slices per image (1 when a slice holds whole images)
+  const int b_first = spi > 1 ? blockIdx.y / spi : blockIdx.y * images_per_slice;
+  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
+  const int h0 = spi > 1 ? (blockIdx.y % spi) * rows_per_slice : 0;
   const int h1 = min(H, h0 + rows_per_slice);
 
   for (int i = tid; i < (3 * XROW + DYROW) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   const u32x4 zero = {0u, 0u, 0u, 0u};
+  int b = b_first;
   auto load_x = [&](int h, u32x4* r) {  // image row h of X (zeros outside the image)
     const int hc = min(max(h, 0), H - 1);
     const unsigned short* base = X + ((long long)(b * H + hc) * W) * ld_x + k0;
@@ -674,7 +679,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   u32x4 rx[IT], ry[IT];
+  for (b = b_first; b < b_last; ++b) {
   if (h0 < h1) {
+    if (b > b_first) __syncthreads();  // the previous image's last row has been read
     load_x(h0 - 1, rx); stash_x(h0 - 1, rx);
     load_x(h0, rx);     stash_x(h0, rx);
     load_x(h0 + 1, rx); stash_x(h0 + 1, rx);
@@ -705,6 +712,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short
       load_y(h + 2, ry);
     }
   }
+  }
 
   // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice][n][tap][k]
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
@@ -717,19 +725,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short
 }
 
 struct Wgrad3Plan {
-  int tiles, rows_per_slice, slices;
+  int tiles, rows_per_slice, images_per_slice, slices;
 };
 inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout) {
+  // Every workgroup writes a 64 x 9 x 64 float32 partial (147 KB) that the reduce kernel reads back, so the slab traffic
+  // grows with the workgroup count (75 MB for the 128-channel 40 x 40 layer at 512 workgroups, against 13 MB of
+  // operands).  Measured all the same: 512 workgroups 26 / 25 / 33 us (W = 40 / 80 / 20) + 6.9 us reduce; 128
+  // workgroups 36 / 33 / 47 + 4.9 us — a workgroup's row loop is bound by its one-row-ahead load latency, so more,
+  // shorter workgroups win until the prefetch is deepened.
   Wgrad3Plan p;
   p.tiles = (Cout / 64) * (Cin / 64);
-  int want = 512 / p.tiles;  // slices: ~2 workgroups per CU in total
-  if (want < B) want = B;
-  int spi = want / B;        // slices per image
-  if (spi < 1) spi = 1;
-  int rps = (H + spi - 1) / spi;
-  if (rps < 4 && H >= 4) rps = 4;  // two halo rows per slice: keep them under a third of the loads
-  p.rows_per_slice = rps;
-  p.slices = B * ((H + rps - 1) / rps);
+  int want = 512 / p.tiles;
+  if (want < 1) want = 1;
+  if (want >= B) {  // one image, a range of rows
+    int spi = want / B;
+    int rps = (H + spi - 1) / spi;
+    if (rps < 4 && H >= 4) rps = 4;  // two halo rows per slice: keep them under a third of the loads
+    p.rows_per_slice = rps;
+    p.images_per_slice = 1;
+    p.slices = B * ((H + rps - 1) / rps);
+  } else {          // whole images
+    p.rows_per_slice = H;
+    p.images_per_slice = (B + want - 1) / want;
+    p.slices = (B + p.images_per_slice - 1) / p.images_per_slice;
+  }
   return p;
 }
 
@@ -745,7 +764,7 @@ inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
   p.tm = Cout % 128 == 0 && big ? 2 : 1;
   p.tn = Cin % 128 == 0 && big ? 2 : 1;
   p.tiles = (Cout / (64 * p.tm)) * (Cin / (64 * p.tn));
-  int s = 512 / p.tiles;  // ~2 workgroups per CU
+  int s = 512 / p.tiles;  // ~2 workgroups per CU (256 measured equal within noise)
   const int64_t max_s = (R + 127) / 128;  // at least two 64-row steps per slice
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
@@ -894,13 +913,13 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   const size_t lds = (size_t)(3 * (WP + 2) + WP) * (64 * 2 + 64);
   if (W == 20)
     (void)hd_launch(conv3x3_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, slab);
+                    p.rows_per_slice, p.images_per_slice, slab);
   else if (W == 40)
     (void)hd_launch(conv3x3_wgrad_kernel<40>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, slab);
+                    p.rows_per_slice, p.images_per_slice, slab);
   else
     (void)hd_launch(conv3x3_wgrad_kernel<80>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, slab);
+                    p.rows_per_slice, p.images_per_slice, slab);
   HD_RETURN_IF_LAUNCH_FAILED();
   const long long NK = (long long)Cout * 9 * Cin;
   (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
