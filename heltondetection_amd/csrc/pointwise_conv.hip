@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float
 // rows are stored as zeros, out-of-image pixels are the halo.  Per 16 pixels a wave issues one dY fragment, nine X
 // fragments and nine MFMAs.  The next X row and dY row travel in registers while the current row is multiplied.
 template <int W>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                             const unsigned short* __restrict__ X, long long ld_x, int B, int H,
                                                             int N, int K, int rows_per_slice, int images_per_slice,
                                                             float* __restrict__ slab) {
@@ -715,6 +715,132 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const unsigned short
   }
 
   // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice][n][tap][k]
+  float* out = slab + (size_t)blockIdx.y * N * 9 * K;
+  const int k = k0 + wk * 32 + (lane & 31);
+  const int nb = n0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((size_t)(nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * K + k] = acc[t][r];
+}
+
+// Stride 2 (the downsampling 3x3 convolutions): output pixel (ho, wo) reads input (2 ho + ky - 1, 2 wo + kx - 1).  An input
+// row is stored de-interleaved — even pixels E[j] = x[2 j] and odd pixels O[j] = x[2 j + 1], each with the one-pixel zero
+// halo — so the three column taps are again contiguous views: kx = 0 -> O[wo - 1], kx = 1 -> E[wo], kx = 2 -> O[wo].  The
+// ring holds input rows 2 ho - 1, 2 ho, 2 ho + 1; advancing one output row brings in two input rows.  H, W: OUTPUT size.
+template <int W>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+                                                              const unsigned short* __restrict__ X, long long ld_x, int B, int H,
+                                                              int N, int K, int rows_per_slice, int images_per_slice,
+                                                              float* __restrict__ slab) {
+  constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
+  constexpr int SX = 64 * 2 + 64;
+  constexpr int PLANE = (WP + 2) * SX, XROW = 2 * PLANE, DYROW = WP * SX;
+  constexpr int CHX = 2 * W * 8, CHY = W * 8;  // 16-byte chunks per input row / per dY row of a 64-channel tile
+  constexpr int ITX = (CHX + 255) / 256, ITY = (CHY + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 input rows (E | O planes) | dY row]
+  unsigned char* xs = smem;
+  unsigned char* ys = smem + 3 * XROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = K / 64;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int Hi = 2 * H, Wi = 2 * W;
+  const int spi = (H + rows_per_slice - 1) / rows_per_slice;
+  const int b_first = spi > 1 ? blockIdx.y / spi : blockIdx.y * images_per_slice;
+  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
+  const int h0 = spi > 1 ? (blockIdx.y % spi) * rows_per_slice : 0;
+  const int h1 = min(H, h0 + rows_per_slice);
+
+  for (int i = tid; i < (3 * XROW + DYROW) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  int b = b_first;
+  auto load_x = [&](int r, u32x4* v) {  // input row r (zeros outside the image)
+    const int rc = min(max(r, 0), Hi - 1);
+    const unsigned short* base = X + ((long long)(b * Hi + rc) * Wi) * ld_x + k0;
+#pragma unroll
+    for (int i = 0; i < ITX; ++i) {
+      const int id = i * 256 + tid;
+      if (CHX % 256 == 0 || id < CHX) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_x + (id & 7) * 8);
+    }
+  };
+  auto load_y = [&](int h, u32x4* v) {
+    const int hc = min(h, H - 1);
+    const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
+#pragma unroll
+    for (int i = 0; i < ITY; ++i) {
+      const int id = i * 256 + tid;
+      if (CHY % 256 == 0 || id < CHY) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_dy + (id & 7) * 8);
+    }
+  };
+  auto stash_x = [&](int r, const u32x4* v) {
+    unsigned char* slot = xs + ((r + 3) % 3) * XROW;
+    const bool in = r >= 0 && r < Hi;
+#pragma unroll
+    for (int i = 0; i < ITX; ++i) {
+      const int id = i * 256 + tid;
+      if (CHX % 256 == 0 || id < CHX) {
+        const int p = id >> 3;
+        *reinterpret_cast<u32x4*>(slot + (p & 1) * PLANE + ((p >> 1) + 1) * SX + (id & 7) * 16) = in ? v[i] : zero;
+      }
+    }
+  };
+  auto stash_y = [&](const u32x4* v) {
+#pragma unroll
+    for (int i = 0; i < ITY; ++i) {
+      const int id = i * 256 + tid;
+      if (CHY % 256 == 0 || id < CHY) *reinterpret_cast<u32x4*>(ys + (id >> 3) * SX + (id & 7) * 16) = v[i];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  u32x4 ra[ITX], rb[ITX], ry[ITY];
+  for (b = b_first; b < b_last; ++b) {
+    if (h0 < h1) {
+      if (b > b_first) __syncthreads();
+      load_x(2 * h0 - 1, ra); stash_x(2 * h0 - 1, ra);
+      load_x(2 * h0, ra);     stash_x(2 * h0, ra);
+      load_x(2 * h0 + 1, ra); stash_x(2 * h0 + 1, ra);
+      load_y(h0, ry);         stash_y(ry);
+      load_x(2 * h0 + 2, ra);
+      load_x(2 * h0 + 3, rb);
+      load_y(h0 + 1, ry);
+    }
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* slot = xs + ((2 * h + ky - 1 + 3) % 3) * XROW;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            // kx = 0: O[wo - 1] (pixel row wo), kx = 1: E[wo] (pixel row wo + 1), kx = 2: O[wo] (pixel row wo + 1)
+            const bf16x8 bq = tr_fragment(slot + (kx == 1 ? 0 : PLANE), SX, wk * 32, ks * 16 + (kx == 0 ? 0 : 1), lane);
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      if (h + 1 < h1) {
+        stash_x(2 * h + 2, ra);  // into the slots input rows 2 h - 1 and 2 h just left
+        stash_x(2 * h + 3, rb);
+        stash_y(ry);
+        load_x(2 * h + 4, ra);
+        load_x(2 * h + 5, rb);
+        load_y(h + 2, ry);
+      }
+    }
+  }
+
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
   const int k = k0 + wk * 32 + (lane & 31);
   const int nb = n0 + wn * 32 + 4 * (lane >> 5);
@@ -883,21 +1009,21 @@ extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stri
   return HD_ERR_SHAPE;
 }
 
-extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
-  return B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
-         Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff;
+extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride) {
+  return (stride == 1 || stride == 2) && B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 &&
+         Cout >= 64 && Cout % 64 == 0 && Cin <= 1024 && Cout <= 1024 && (long long)B * H * W * stride * stride <= 0x7fffffff;
 }
 
-extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout)) return 0;
+extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride) {
+  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return 0;
   return (size_t)wgrad3_plan(B, H, Cin, Cout).slices * Cout * 9 * Cin * sizeof(float);
 }
 
 extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
-                                      int W, int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                      int W, int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes,
                                       hd_stream stream) {
   if (!dy || !x || !dw || !workspace) return HD_ERR_NULL;
-  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout)) return HD_ERR_SHAPE;
+  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return HD_ERR_SHAPE;
   if (dy_row_stride == 0) dy_row_stride = Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
   if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
@@ -910,8 +1036,18 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   float* slab = static_cast<float*>(workspace);
   const dim3 grid((unsigned)p.tiles, (unsigned)p.slices);
   const int WP = (W + 15) / 16 * 16;
-  const size_t lds = (size_t)(3 * (WP + 2) + WP) * (64 * 2 + 64);
-  if (W == 20)
+  const size_t lds = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
+  if (stride == 2) {
+    if (W == 20)
+      (void)hd_launch(conv3x3s2_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                      p.rows_per_slice, p.images_per_slice, slab);
+    else if (W == 40)
+      (void)hd_launch(conv3x3s2_wgrad_kernel<40>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                      p.rows_per_slice, p.images_per_slice, slab);
+    else
+      (void)hd_launch(conv3x3s2_wgrad_kernel<80>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
+                      p.rows_per_slice, p.images_per_slice, slab);
+  } else if (W == 20)
     (void)hd_launch(conv3x3_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
                     p.rows_per_slice, p.images_per_slice, slab);
   else if (W == 40)

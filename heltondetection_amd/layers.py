@@ -167,20 +167,20 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
         from . import ops
         w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
         w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)  # what autocast would hand the library
-        return FusedBNAct.apply(bn, ops.conv3x3(x, w), act, residual, residual_after_act, out)
+        return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0]), act, residual, residual_after_act, out)
     return FusedBNAct.apply(bn, conv(x), act, residual, residual_after_act, out)
 
 
 def _conv3x3_ours(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
-    """3x3 / stride 1 / pad 1 layers whose weight gradient hd_conv3x3_wgrad takes (bf16 rows, W in {20, 40, 80}, channel
-    counts multiples of 64): forward and data gradient stay with the library."""
-    if not (ConvBNAct.pointwise and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+    """3x3 / pad 1 layers of stride 1 or 2 whose weight gradient hd_conv3x3_wgrad takes (bf16 rows, output W in {20, 40, 80},
+    channel counts multiples of 64): forward and data gradient stay with the library."""
+    if not (ConvBNAct.pointwise and conv.kernel_size == (3, 3) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.is_cuda and bn.training
             and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.bfloat16 and conv.weight.requires_grad):
         return False
     from . import ops
-    return ops.conv3x3_wgrad_supported(x, conv.out_channels)
+    return ops.conv3x3_wgrad_supported(x, conv.out_channels, conv.stride[0])
 
 
 class Bottleneck(nn.Module):

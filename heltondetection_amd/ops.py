@@ -1010,60 +1010,64 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dw
 
 
-def conv3x3_wgrad_supported(x: torch.Tensor, cout: int) -> bool:
+def conv3x3_wgrad_supported(x: torch.Tensor, cout: int, stride: int = 1) -> bool:
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and _cl_row_stride(x, 8) is not None):
         return False
     B, K, H, W = x.shape
-    return bool(_lib.load().hd_conv3x3_wgrad_supported(B, H, W, K, int(cout)))
+    if stride not in (1, 2) or H % stride or W % stride:
+        return False
+    return bool(_lib.load().hd_conv3x3_wgrad_supported(B, H // stride, W // stride, K, int(cout), int(stride)))
 
 
-def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """Weight gradient of a 3x3 / stride 1 / pad 1 convolution: dy [B, Cout, H, W], x [B, Cin, H, W] bf16 channels-last
-    rows -> dw [Cout, Cin, 3, 3] bf16 in channels-last memory ([Cout][ky][kx][Cin]); no autograd."""
+def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2: dy [B, Cout, H, W], x [B, Cin, stride H, stride W]
+    bf16 channels-last rows -> dw [Cout, Cin, 3, 3] bf16 in channels-last memory ([Cout][ky][kx][Cin]); no autograd."""
     lib = _lib.load()
     B, N, H, W = dy.shape
     K = x.shape[1]
     ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
     if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
-            or x.shape[0] != B or x.shape[2:] != dy.shape[2:]):
-        raise _lib.HdError("conv3x3_wgrad: needs bf16 channels-last rows of equal batch and spatial size")
-    nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N)
+            or x.shape[0] != B or x.shape[2] != stride * H or x.shape[3] != stride * W):
+        raise _lib.HdError("conv3x3_wgrad: needs bf16 channels-last rows, x spatially `stride` times dy")
+    nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N, int(stride))
     if nbytes == 0:
-        raise _lib.HdError("conv3x3_wgrad: W must be 20, 40 or 80 and the channel counts multiples of 64")
+        raise _lib.HdError("conv3x3_wgrad: output W must be 20, 40 or 80, channel counts multiples of 64, stride 1 or 2")
     ws = _wgrad_workspace(dy.device, nbytes)
     dw = torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
-    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (K + N) + 9 * N * K))
+    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K))
     with _timed("conv3x3_wgrad"):
-        check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, _ptr(dw), _ptr(ws), ws.numel(),
-                                   _stream(dy)), "hd_conv3x3_wgrad")
+        check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
+                                   ws.numel(), _stream(dy)), "hd_conv3x3_wgrad")
     return dw
 
 
 class _Conv3x3Fn(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 convolution: forward and data gradient stay with MIOpen, the weight gradient runs on
+    """3x3 / pad 1 convolution of stride 1 or 2: forward and data gradient stay with MIOpen, the weight gradient runs on
     hd_conv3x3_wgrad (no split-K zero-fill, cast or memset launches)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stride):
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+        ctx.stride = int(stride)
+        return torch.nn.functional.conv2d(x, weight, None, ctx.stride, 1)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        st = ctx.stride
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             g = dy if (dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None) else \
                 dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dw = conv3x3_wgrad_rows(g, x)
-        return dx, dw
+            dw = conv3x3_wgrad_rows(g, x, st)
+        return dx, dw, None
 
 
-def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    return _Conv3x3Fn.apply(x, weight)
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    return _Conv3x3Fn.apply(x, weight, stride)
 
 
 POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen

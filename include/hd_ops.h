@@ -439,16 +439,17 @@ size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout);
 hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R, int Cin,
                              int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
 
-/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution on channels-last rows (the bottleneck 3x3 of the YOLOv5 C3 blocks):
+/* Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2 on channels-last rows (the bottleneck and the downsampling
+ * 3x3 convolutions of the YOLOv5 backbone / neck):
  *     dw[n][ky][kx][k] (bfloat16, i.e. a channels-last [Cout, Cin, 3, 3] weight) = sum over (b, h, w) of
- *         dy[b, h, w, n] * x[b, h + ky - 1, w + kx - 1, k]            (zero outside the image; float32 accumulate)
- * x [B, H, W, Cin], dy [B, H, W, Cout] bfloat16 rows (strides in elements, 0 = dense).  W in {20, 40, 80}; Cin, Cout
- * multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
+ *         dy[b, h, w, n] * x[b, stride h + ky - 1, stride w + kx - 1, k]   (zero outside the image; float32 accumulate)
+ * H, W: the OUTPUT size; dy [B, H, W, Cout], x [B, stride H, stride W, Cin] bfloat16 rows (strides in elements, 0 = dense).
+ * W in {20, 40, 80}; Cin, Cout multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
  * workspace: hd_conv3x3_wgrad_workspace_bytes(...), 16-byte aligned, contents undefined on entry and exit. */
-int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout);
-size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride);
+size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H, int W,
-                           int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
+                           int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
 
 /* ---- nearest 2x upsampling + channel concatenation in one pass (csrc/upcat.hip) ----
  * The top-down junctions of the YOLOv5 PAFPN neck (README.md:9): out[b, y, x, :] = [small[b, y/2, x/2, :] | big[b, y, x, :]]

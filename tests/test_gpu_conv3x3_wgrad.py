@@ -6,9 +6,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _ref(dy, x):
+def _ref(dy, x, stride=1):
     w = torch.zeros((dy.shape[1], x.shape[1], 3, 3), dtype=torch.float32, device=x.device)
-    return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+    return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (stride, stride), (1, 1), (1, 1), False, (0, 0), 1,
                                                (False, True, False))[1]
 
 
@@ -56,3 +56,19 @@ def test_conv3x3_layer_matches_library_path():
     for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 64, 9, 40, 64),
+                                   (1, 64, 80, 80, 128), (16, 256, 20, 20, 512), (1, 64, 1, 20, 64)])
+def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
+    """Stride 2: (B, Cin, Ho, Wo, Cout) with the input 2 Ho x 2 Wo; even / odd pixel planes, two new input rows per output row."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H + W + 1)
+    x = torch.randint(-2, 3, (B, K, 2 * H, 2 * W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randint(-2, 3, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.conv3x3_wgrad_supported(x, N, 2)
+    dw = ops.conv3x3_wgrad_rows(dy, x, 2)
+    ref = _ref(dy, x, 2)
+    assert torch.equal(dw.float(), ref.to(torch.bfloat16).float())
