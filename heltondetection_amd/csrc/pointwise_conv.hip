@@ -855,13 +855,13 @@ struct Wgrad3Plan {
 };
 inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout) {
   // Every workgroup writes a 64 x 9 x 64 float32 partial (147 KB) that the reduce kernel reads back, so the slab traffic
-  // grows with the workgroup count (75 MB for the 128-channel 40 x 40 layer at 512 workgroups, against 13 MB of
-  // operands).  Measured all the same: 512 workgroups 26 / 25 / 33 us (W = 40 / 80 / 20) + 6.9 us reduce; 128
-  // workgroups 36 / 33 / 47 + 4.9 us — a workgroup's row loop is bound by its one-row-ahead load latency, so more,
-  // shorter workgroups win until the prefetch is deepened.
+  // grows with the workgroup count while the operands do not (75 MB for the 128-channel 40 x 40 layer at 512 workgroups
+  // against 13 MB of operands): the partial kernel is bound by that write.  Measured per launch in the step, W = 40 / 80 / 20
+  // stride 1: 512 workgroups 24.5 / 24.1 / 26.5 us (+ 6.9 us reduce); 256: 23.0 / 22.8 / 29.8 (+ 5.9); 128: 36 / 33 / 47
+  // (+ 4.9, the row loop then dominates).  Two rows of loads in flight instead of one changed nothing.
   Wgrad3Plan p;
   p.tiles = (Cout / 64) * (Cin / 64);
-  int want = 512 / p.tiles;
+  int want = 256 / p.tiles;
   if (want < 1) want = 1;
   if (want >= B) {  // one image, a range of rows
     int spi = want / B;
