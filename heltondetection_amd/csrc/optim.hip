@@ -1,0 +1,95 @@
+// optim.hip — AdamW over every parameter tensor of a group in ONE launch, writing the bf16 weight shadows in the same pass.
+//
+// Why hand-written: PyTorch-ROCm's fused AdamW is a multi-tensor-apply that takes 5 launches of ~34 us for YOLOv5s' 7.2 M
+// parameters (0.17 ms/step), and the bf16 shadows of the convolution weights (layers.ShadowConv2d) were re-cast from the
+// float32 masters by another two 26 us multi-tensor launches at the head of every step.  Here a descriptor table
+// (device-resident, built once) lists every tensor's parameter / gradient / moment pointers, and a chunk list maps
+// workgroups to (tensor, offset) ranges of 16 K elements, so one launch streams p, g, m, v once and writes p, m, v and the
+// bf16 shadow: 30 bytes per parameter, HBM-bound.
+// Arithmetic follows torch.optim.AdamW (decoupled weight decay, bias corrections folded on the host):
+//   p *= 1 - lr wd;  m += (1 - b1)(g - m);  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps).
+#include <hip/hip_bf16.h>
+
+#include <cmath>
+
+#include "hd_common.h"
+
+namespace {
+
+__device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v, float decay, float b1c, float b2, float b2c,
+                                           float step_size, float inv_sqrt_bc2, float eps) {
+  p *= decay;
+  m = m + b1c * (g - m);
+  v = b2 * v + b2c * (g * g);
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  return p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const hd_adamw_tensor* __restrict__ T,
+                                                          const int* __restrict__ chunk_tensor,
+                                                          const long long* __restrict__ chunk_start, int chunk_elems, float lr,
+                                                          float b1c, float b2, float b2c, float eps, float step_size,
+                                                          float inv_sqrt_bc2) {
+  const hd_adamw_tensor d = T[chunk_tensor[blockIdx.x]];
+  const long long start = chunk_start[blockIdx.x];
+  const long long end = start + chunk_elems < d.n ? start + chunk_elems : d.n;
+  float* __restrict__ p = static_cast<float*>(d.p);
+  const float* __restrict__ g = static_cast<const float*>(d.g);
+  float* __restrict__ m = static_cast<float*>(d.m);
+  float* __restrict__ v = static_cast<float*>(d.v);
+  unsigned short* __restrict__ sh = static_cast<unsigned short*>(d.shadow);
+  const float decay = 1.0f - lr * d.weight_decay;
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15u) == 0 && (!sh || (reinterpret_cast<uintptr_t>(sh) & 7u) == 0);
+  long long i = start + (long long)threadIdx.x * 4;
+  if (vec) {
+    for (; i + 3 < end; i += 1024) {
+      float4 pv = *reinterpret_cast<const float4*>(p + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 mv = *reinterpret_cast<const float4*>(m + i);
+      float4 vv = *reinterpret_cast<const float4*>(v + i);
+      pv.x = adamw_one(pv.x, gv.x, mv.x, vv.x, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+      pv.y = adamw_one(pv.y, gv.y, mv.y, vv.y, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+      pv.z = adamw_one(pv.z, gv.z, mv.z, vv.z, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+      pv.w = adamw_one(pv.w, gv.w, mv.w, vv.w, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+      *reinterpret_cast<float4*>(p + i) = pv;
+      *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+      if (sh) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        const f32x4 f = {pv.x, pv.y, pv.z, pv.w};
+        *reinterpret_cast<bf16x4*>(sh + i) = __builtin_convertvector(f, bf16x4);  // round to nearest even, as .to(bfloat16)
+      }
+    }
+    // the (< 4 element) tail of the chunk: lanes 0..2 of the first wave
+    const long long tail = start + ((end - start) & ~3LL) + threadIdx.x;
+    i = (threadIdx.x < 4 && tail < end) ? tail : end;
+  } else {
+    i = start + threadIdx.x;
+  }
+  for (; i < end; i += vec ? end : 256) {
+    float mv = m[i], vv = v[i];
+    const float pn = adamw_one(p[i], g[i], mv, vv, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+    p[i] = pn;
+    m[i] = mv;
+    v[i] = vv;
+    if (sh) sh[i] = __builtin_bit_cast(unsigned short, (__bf16)pn);
+  }
+}
+
+}  // namespace
+
+extern "C" hd_status hd_adamw_multi(const hd_adamw_tensor* tensors, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                                    int n_chunks, int chunk_elems, double lr, double beta1, double beta2, double eps, double bc1,
+                                    double bc2, hd_stream stream) {
+  if (n_chunks == 0) return HD_OK;
+  if (!tensors || !chunk_tensor || !chunk_start) return HD_ERR_NULL;
+  if (n_chunks < 0 || chunk_elems < 1024 || chunk_elems % 1024 || !(bc1 > 0.0) || !(bc2 > 0.0)) return HD_ERR_SHAPE;
+  // the scalar coefficients are formed in double (1 - 0.999 in float is off by 5e-5 relative) and rounded once
+  (void)hd_launch(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunk_tensor,
+                  (const long long*)chunk_start, chunk_elems, (float)lr, (float)(1.0 - beta1), (float)beta2,
+                  (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}

@@ -1,0 +1,110 @@
+"""AdamW on the one-launch HIP kernel of csrc/optim.hip (`hd_adamw_multi`).
+
+`HdAdamW` is a torch.optim.AdamW — same constructor arguments, param groups, state layout (`step`, `exp_avg`,
+`exp_avg_sq` per parameter), `state_dict()` / `load_state_dict()` and LR-scheduler behaviour — whose `step()` runs one
+kernel per parameter group over a device-resident descriptor table instead of PyTorch's multi-tensor-apply launches, and
+that also writes the bf16 shadows of the convolution weights (train.LowpShadows) in the same pass, so the per-step
+re-cast of the shadows disappears.  Reference: README.md:13 ("training ... optimizer"); the optimizer of the reference is
+not in the snapshot, AdamW with YOLOv5's betas is this repo's choice (train.Trainer)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+_CHUNK = 16384
+
+
+class _Desc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
+                ("n", C.c_int64), ("weight_decay", C.c_float), ("reserved", C.c_int32)]
+
+
+class HdAdamW(torch.optim.AdamW):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 shadows: Optional[Dict[torch.Tensor, torch.Tensor]] = None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
+        self.shadows = dict(shadows or {})   # float32 master parameter -> its bf16 shadow (same memory order)
+        self._tables = None                  # per group: (descriptor tensor, chunk_tensor, chunk_start, n_chunks, key)
+
+    @property
+    def writes_shadows(self) -> bool:
+        return bool(self.shadows)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = None
+
+    def _key(self, group):
+        return tuple((p.data_ptr(), p.grad.data_ptr()) for p in group["params"] if p.grad is not None)
+
+    def _build(self, group):
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return None
+        dev = ps[0].device
+        descs, ct, cs = (_Desc * len(ps))(), [], []
+        for i, p in enumerate(ps):
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            g, m, v, sh = p.grad, st["exp_avg"], st["exp_avg_sq"], self.shadows.get(p)
+            for t, what in ((p, "parameter"), (g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                if t.dtype != torch.float32 or t.device != dev or t.stride() != p.stride() or not _dense(t):
+                    raise _lib.HdError(f"HdAdamW: {what} must be a dense float32 tensor in the parameter's memory order")
+            if sh is not None and (sh.dtype != torch.bfloat16 or sh.stride() != p.stride() or sh.shape != p.shape):
+                raise _lib.HdError("HdAdamW: a shadow must be a bfloat16 tensor of the parameter's shape and memory order")
+            descs[i] = _Desc(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else None,
+                             p.numel(), float(group["weight_decay"]), 0)
+            for start in range(0, p.numel(), _CHUNK):
+                ct.append(i)
+                cs.append(start)
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        return (raw, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev), len(ct),
+                self._key(group), ps)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        if self._tables is None:
+            self._tables = [None] * len(self.param_groups)
+        for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("maximize"):
+                raise _lib.HdError("HdAdamW: amsgrad / maximize are not implemented")
+            tab = self._tables[gi]
+            if tab is None or tab[4] != self._key(group):   # first step, re-pointed gradients, loaded state
+                tab = self._tables[gi] = self._build(group)
+            if tab is None:
+                continue
+            raw, ct, cs, n_chunks, _, ps = tab
+            st0 = self.state[ps[0]]["step"]
+            t = float(st0) + 1.0
+            for p in ps:
+                self.state[p]["step"] += 1
+            b1, b2 = group["betas"]
+            stream = torch.cuda.current_stream(raw.device).cuda_stream
+            rc = lib.hd_adamw_multi(C.c_void_p(raw.data_ptr()), C.c_void_p(ct.data_ptr()), C.c_void_p(cs.data_ptr()), n_chunks,
+                                    _CHUNK, float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t,
+                                    1.0 - b2 ** t, C.c_void_p(stream))
+            if rc != 0:
+                raise _lib.HdError(f"hd_adamw_multi failed ({rc})")
+        return loss
+
+
+def _dense(t: torch.Tensor) -> bool:
+    """Non-overlapping and dense: the numel() elements occupy numel() consecutive storage slots (any dimension order)."""
+    if t.numel() <= 1:
+        return True
+    dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1))
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True

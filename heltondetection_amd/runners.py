@@ -105,6 +105,8 @@ def save_checkpoint(path: str, model: torch.nn.Module, trainer=None, **meta) -> 
 def load_checkpoint(path: str, model: torch.nn.Module, trainer=None) -> Dict[str, Any]:
     state = torch.load(path, map_location="cpu")
     model.load_state_dict(state["model"], strict=True)
+    if trainer is not None:
+        trainer.weights_changed()  # the bf16 shadows of the convolution weights follow the loaded masters
     if trainer is not None and "optimizer" in state:
         trainer.opt.load_state_dict(state["optimizer"])
         trainer.sched.load_state_dict(state["scheduler"])

@@ -56,7 +56,7 @@ class Trainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
                  total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
                  use_graph: bool = False, graph_warmup: int = 3, graph_sync: Optional[bool] = None,
-                 lowp_weights: bool = True, augment=None, graph_split: bool = True):
+                 lowp_weights: bool = True, augment=None, graph_split: bool = True, hd_optimizer: bool = True):
         self.model = model
         # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head
         # of every step (e.g. augment.Mosaic).  It is part of the captured region in hipGraph mode, so it must
@@ -99,10 +99,16 @@ class Trainer:
             if not p.requires_grad:
                 continue
             (no_decay if p.ndim <= 1 else decay).append(p)
-        fused = self.device.type == "cuda"
-        self.opt = torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                                      {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=(0.937, 0.999),
-                                     fused=fused)
+        groups = [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+        if self.device.type == "cuda" and hd_optimizer:
+            # one launch per parameter group (csrc/optim.hip) that also writes the bf16 weight shadows, so the per-step
+            # re-cast of the shadows (LowpShadows.refresh) is needed only when the masters were changed from outside
+            from .optim import HdAdamW
+            self.opt = HdAdamW(groups, lr=lr, betas=(0.937, 0.999),
+                               shadows=self.shadows.grad_sources() if self.shadows else None)
+        else:
+            self.opt = torch.optim.AdamW(groups, lr=lr, betas=(0.937, 0.999), fused=self.device.type == "cuda")
+        self._shadows_dirty = True  # the shadows start uninitialised; weights_changed() marks them stale again
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: warmup_cosine(s, total_steps, warmup_steps))
         self._graph = None
         self._static = None
@@ -122,7 +128,12 @@ class Trainer:
             with torch.no_grad():
                 images, gt_boxes, gt_cls, m_valid = self.augment(images, gt_boxes, gt_cls, m_valid)
         if self.shadows is not None:
-            self.shadows.refresh()
+            if not getattr(self.opt, "writes_shadows", False):
+                self.shadows.refresh()
+            elif self._shadows_dirty and not torch.cuda.is_current_stream_capturing():
+                # HdAdamW keeps the shadows current; they are stale only before the first step / after weights_changed()
+                self.shadows.refresh()
+                self._shadows_dirty = False
         LowpWeights.on = self.shadows is not None
         try:
             with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
@@ -189,8 +200,17 @@ class Trainer:
                     stream.synchronize()
                 red.bucket_replayed(seg.marker_of[k])
 
+    def weights_changed(self) -> None:
+        """Tell the trainer that the float32 master weights were modified outside `step()` (a checkpoint was loaded):
+        the bf16 shadows are re-cast before the next forward."""
+        self._shadows_dirty = True
+
     def step(self, images, gt_boxes, gt_cls, m_valid):
         batch = (images, gt_boxes, gt_cls, m_valid)
+        if self._shadows_dirty:
+            if self.shadows is not None:
+                self.shadows.refresh()  # an ordinary launch ahead of the captured region / the replay
+            self._shadows_dirty = False
         if self.use_graph and self._graph is None and self._eager_steps >= self._graph_warmup:
             err = None
             try:

@@ -462,6 +462,26 @@ hd_status hd_upsample2x_cat_fwd(const void* small, int64_t small_row_stride, con
 hd_status hd_upsample2x_cat_bwd(const void* grad_out, int64_t grad_row_stride, int dtype, int B, int H, int W, int Cs,
                                 void* d_small, int64_t d_small_row_stride, hd_stream stream);
 
+/* ---- AdamW over all tensors of a parameter group in one launch, bf16 weight shadows written in the same pass ----
+ * (csrc/optim.hip; the optimizer of the train step BASELINE.json's metric times.)  `tensors` is a DEVICE array of
+ * descriptors: float32 parameter / gradient / first / second moment (dense, same memory order, n elements), an optional
+ * bfloat16 shadow of the parameter (NULL: none) and the tensor's weight decay.  Workgroup c handles elements
+ * [chunk_start[c], chunk_start[c] + chunk_elems) of tensor chunk_tensor[c] (device arrays; chunk_elems a multiple of 1024).
+ * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t for the step count t (host side).  Semantics: torch.optim.AdamW. */
+typedef struct hd_adamw_tensor {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  void* shadow;
+  int64_t n;
+  float weight_decay;
+  int32_t reserved;
+} hd_adamw_tensor;
+hd_status hd_adamw_multi(const hd_adamw_tensor* tensors, const int32_t* chunk_tensor, const int64_t* chunk_start, int n_chunks,
+                         int chunk_elems, double lr, double beta1, double beta2, double eps, double bc1, double bc2,
+                         hd_stream stream);
+
 /* ---- Mosaic-4 augmentation on device (README.md:76-77,129-130; convention: DESIGN.md section 2 item 12) ---- */
 
 /* images/out: float32 [B,3,S,S] with element strides (b,c,y,x); S even; out must not alias images.

@@ -156,8 +156,13 @@ def test_lowp_weight_shadows_match_autocast_casts(gpu):
             losses = [float(tr.step(*batch)[0]) for _ in range(6)]
             assert np.isfinite(losses).all() and losses[-1] < losses[0]
             assert not torch.equal(before, model.c2.weight)               # the master moved
-            assert not torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))  # stale until ...
-            tr.shadows.refresh()                                          # ... the next step's refresh
+            # the HIP optimizer writes the shadow in the pass that updates the master (optim.HdAdamW)
+            assert torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))
+            with torch.no_grad():
+                model.c2.weight.mul_(1.5)                                 # a change from outside ...
+            assert not torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))
+            tr.weights_changed()                                          # ... is announced, and the next step re-casts
+            tr.step(*batch)
             assert torch.equal(model.c2.weight_lp, model.c2.weight.to(torch.bfloat16))
             # outside the Trainer's step the module uses its master weight (no stale shadow in eval)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
