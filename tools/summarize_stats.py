@@ -2,7 +2,8 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'naive_conv' not in r['Name']]
 steps = int(sys.argv[2])
 def c(n):
-    if 'pointwise_' in n: return 'OUR 1x1 convolutions (fwd+stats / dgrad / wgrad)'
+    if 'pointwise_' in n or 'conv3x3' in n: return 'OUR 1x1 convolutions (fwd+stats / dgrad / wgrad) + 3x3 wgrad'
+    if 'adamw_multi' in n: return 'OUR AdamW'
     if 'upcat' in n or 'graph_fill' in n or 'graph_copy' in n: return 'OUR HIP kernels'
     if 'igemm_fwd' in n or 'conv_fwd' in n or 'ConvFwd' in n or 'gemm_fwd' in n: return 'conv fwd'
     if 'igemm_bwd' in n or 'conv_bwd_data' in n: return 'conv bwd-data'
