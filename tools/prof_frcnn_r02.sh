@@ -13,6 +13,6 @@ rm -rf /tmp/pfr2
 echo "profiled rc=$?"
 f=$(ls /tmp/pfr2/*/*kernel_stats.csv | head -1)
 cp $f $R/gpurun_out/r02_frcnn_kernel_stats.csv
-python3 $R/tools/summarize_stats.py $f $((STEPS + WARM)) 40 > $R/gpurun_out/r02_frcnn_summary.txt
+python3 $R/tools/summarize_stats.py $f $((STEPS + WARM + 2)) 40 > $R/gpurun_out/r02_frcnn_summary.txt
 grep -c naive_conv $f
 head -24 $R/gpurun_out/r02_frcnn_summary.txt | cut -c1-170

@@ -1,5 +1,7 @@
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'naive_conv' not in r['Name']]
+allrows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in allrows if 'naive_conv' not in r['Name']]
+naive = [r for r in allrows if 'naive_conv' in r['Name']]
 steps = int(sys.argv[2])
 def c(n):
     if 'pointwise_' in n or 'conv3x3' in n: return 'OUR 1x1 convolutions (fwd+stats / dgrad / wgrad) + 3x3 wgrad'
@@ -32,3 +34,6 @@ for k, v in sorted(cat.items(), key=lambda x: -x[1]): print(f"  {k:40s} {v/1e6/s
 print("top kernels:")
 for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 25]:
     print(f"  {r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:8.1f} tot_ms/step={float(r['TotalDurationNs'])/1e6/steps:.3f}")
+if naive:
+    print(f"excluded: {sum(int(r['Calls']) for r in naive)} calls of MIOpen's find-mode reference kernels (naive_conv_*, the solver search of "
+          f"the first warm-up step of the process), {sum(float(r['TotalDurationNs']) for r in naive)/1e6:.1f} ms in total")
