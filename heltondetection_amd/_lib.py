@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -115,6 +115,8 @@ SIGNATURES = {
     "hd_pointwise_wgrad": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _Z, _P]),
     "hd_upsample2x_cat_fwd": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_upsample2x_cat_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "hd_conv3x3_fwd_supported": (_I, [_I, _I, _I, _I, _I]),
+    "hd_conv3x3_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_conv3x3_wgrad_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "hd_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "hd_conv3x3_wgrad": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),

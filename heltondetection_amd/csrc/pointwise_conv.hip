@@ -850,6 +850,188 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_wgrad_kernel(const unsigned 
     for (int r = 0; r < 16; ++r) out[((size_t)(nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * K + k] = acc[t][r];
 }
 
+// ---- 3x3 / stride 1 / pad 1 forward (and, with flipped + transposed weights, data gradient) -------------------------
+//     Y[b, h, w, n] = sum over (ky, kx, c) of X[b, h + ky - 1, w + kx - 1, c] * Wt[n][ky][kx][c]
+// Implicit GEMM per output row, M = pixels, N = Cout, K = 9 Cin, without an im2col: a workgroup owns 64 output channels
+// and ROWS output rows at a time; LDS holds the ROWS + 2 input rows of one 64-channel chunk (one zero pixel of halo on
+// both sides, zero rows outside the image — borders need no masks) and that chunk's 64 x 9 x 64 weight slab; the nine
+// taps are (row slot, pixel shift) views of the ring, both operands are read K-contiguous (ds_read_b128; pixel rows
+// padded to 144 B and weight rows to 1168 B so 16 consecutive rows fall on distinct bank groups).  A wave owns one
+// 32-channel half and TPW 32-pixel tiles; per (tap, k-step) it issues one weight fragment, TPW pixel fragments and TPW
+// MFMAs.  The accumulators of the pass persist over the Cin chunks.  Epilogue as in the 1x1 kernel: the BatchNorm
+// statistics of the bf16-rounded result per lane column, the tile transposed through a wave-private LDS patch so the
+// global stores are 16 bytes per lane.
+template <int W, int ROWS, bool STATS>
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const unsigned short* __restrict__ X, long long ld_x,
+                                                          const unsigned short* __restrict__ Wt,
+                                                          unsigned short* __restrict__ Y, long long ld_y, int B, int H, int Cin,
+                                                          int Cout, int passes_per_wg, float* __restrict__ stats) {
+  constexpr int PT = (W + 31) / 32, WPX = PT * 32, PXS = 144, XROW = (WPX + 2) * PXS, NSLOT = ROWS + 2;
+  constexpr int WROW = 9 * 64 * 2 + 16, SLAB = 64 * WROW;
+  constexpr int PATCH_ROW = 32 * 2 + 16, PATCH = 32 * PATCH_ROW;
+  constexpr int NT = ROWS * PT * 2, TPW = NT / 4;
+  static_assert(NT % 4 == 0, "tiles must divide over the four waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [input rows | weight slab | 4 patches]
+  unsigned char* xs = smem;
+  unsigned char* ws = smem + NSLOT * XROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fh = lane >> 5;
+  unsigned char* patch = ws + SLAB + wave * PATCH;
+  const int n0 = blockIdx.x * 64, ct = wave & 1;
+  const int ppi = (H + ROWS - 1) / ROWS;  // passes per image
+  const int total = B * ppi;
+  const int NC = Cin / 64;
+
+  for (int i = tid; i < NSLOT * XROW / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+  float s_sum = 0.0f, s_sq = 0.0f;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+
+  // One step = one (pass, Cin chunk).  The operands of step s + 1 travel in registers while step s is multiplied: all
+  // loads of a step are issued back to back (a load -> LDS store loop would serialise 18 L2 round trips per thread).
+  constexpr int XCH = NSLOT * W * 8, XIT = (XCH + 255) / 256, WIT = 64 * 9 * 8 / 256;
+  u32x4 xr[XIT], wr[WIT];
+  const int my_passes = min(passes_per_wg, total - (int)blockIdx.y * passes_per_wg);
+  const int steps = my_passes > 0 ? my_passes * NC : 0;
+  auto issue = [&](int st) {
+    const int pass = blockIdx.y * passes_per_wg + st / NC, c = st % NC;
+    const int b = pass / ppi, r0 = (pass % ppi) * ROWS;
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int id = i * 256 + tid;
+      if (XCH % 256 == 0 || id < XCH) {
+        const int slot = id / (W * 8), rem = id % (W * 8), px = rem >> 3, ch = rem & 7;
+        const int rc = min(max(r0 - 1 + slot, 0), H - 1);
+        xr[i] = *reinterpret_cast<const u32x4*>(X + ((long long)(b * H + rc) * W + px) * ld_x + c * 64 + ch * 8);
+      }
+    }
+    if (NC > 1 || st == 0) {
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) {
+        const int id = i * 256 + tid, co = id / 72, rem = id % 72, tap = rem >> 3, ch = rem & 7;
+        wr[i] = *reinterpret_cast<const u32x4*>(Wt + ((long long)(n0 + co) * 9 + tap) * Cin + c * 64 + ch * 8);
+      }
+    }
+  };
+  auto stash = [&](int st) {
+    const int pass = blockIdx.y * passes_per_wg + st / NC;
+    const int r0 = (pass % ppi) * ROWS;
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int id = i * 256 + tid;
+      if (XCH % 256 == 0 || id < XCH) {
+        const int slot = id / (W * 8), rem = id % (W * 8), px = rem >> 3, ch = rem & 7;
+        const int r = r0 - 1 + slot;
+        *reinterpret_cast<u32x4*>(xs + slot * XROW + (px + 1) * PXS + ch * 16) = (r >= 0 && r < H) ? xr[i] : zero;
+      }
+    }
+    if (NC > 1 || st == 0) {
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) {
+        const int id = i * 256 + tid, co = id / 72, rem = id % 72, tap = rem >> 3, ch = rem & 7;
+        *reinterpret_cast<u32x4*>(ws + co * WROW + tap * 128 + ch * 16) = wr[i];
+      }
+    }
+  };
+
+  if (steps > 0) issue(0);
+  for (int pi = 0; pi < my_passes; ++pi) {
+    const int pass = blockIdx.y * passes_per_wg + pi;
+    const int b = pass / ppi, r0 = (pass % ppi) * ROWS;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int c = 0; c < NC; ++c) {
+      const int st = pi * NC + c;
+      __syncthreads();  // the previous step has been read (and, first time, the zero fill is complete)
+      stash(st);
+      if (st + 1 < steps) issue(st + 1);
+      __syncthreads();
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int sk = 0; sk < 4; ++sk) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (ct * 32 + frow) * WROW + (ky * 3 + kx) * 128 + (2 * sk + fh) * 16);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+              const int t = wave + 4 * i, row = t / (PT * 2), pt = (t / 2) % PT;
+              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (row + ky) * XROW + (pt * 32 + frow + kx) * PXS + (2 * sk + fh) * 16);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wf, acc[i], 0, 0, 0);
+            }
+          }
+    }
+    // epilogue: C/D map col (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave + 4 * i, row = t / (PT * 2), pt = (t / 2) % PT;
+      const int h = r0 + row;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)acc[i][r]);
+        *reinterpret_cast<unsigned short*>(patch + prow * PATCH_ROW + frow * 2) = v;
+        if (STATS && h < H && pt * 32 + prow < W) {
+          const float f = bf16_bits_to_float(v);
+          s_sum += f;
+          s_sq = fmaf(f, f, s_sq);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {  // 32 pixels x 4 chunks of 16 bytes over 64 lanes
+        const int id = q * 64 + lane, prow = id >> 2, ch = id & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(patch + prow * PATCH_ROW + ch * 16);
+        const int px = pt * 32 + prow;
+        if (h < H && px < W)
+          *reinterpret_cast<uint4*>(Y + ((long long)(b * H + h) * W + px) * ld_y + n0 + ct * 32 + ch * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  if (STATS) {
+    __syncthreads();
+    float* s_st = reinterpret_cast<float*>(xs);  // [2][64]
+    for (int i = tid; i < 128; i += 256) s_st[i] = 0.0f;
+    __syncthreads();
+    const float a = s_sum + __shfl_xor(s_sum, 32);
+    const float q = s_sq + __shfl_xor(s_sq, 32);
+    if (fh == 0) {
+      atomicAdd(&s_st[ct * 32 + frow], a);
+      atomicAdd(&s_st[64 + ct * 32 + frow], q);
+    }
+    __syncthreads();
+    float* dst = stats + (size_t)((blockIdx.x + blockIdx.y) % kStatReplicas) * 2 * Cout;
+    for (int i = tid; i < 128; i += 256) atomicAdd(&dst[(i / 64) * Cout + n0 + (i % 64)], s_st[i]);
+  }
+}
+
+template <int W, int ROWS>
+hd_status launch_conv3x3_fwd(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int B, int H, int Cin, int Cout,
+                             float* stats, hipStream_t s) {
+  constexpr int PT = (W + 31) / 32;
+  const size_t lds = (size_t)(ROWS + 2) * (PT * 32 + 2) * 144 + 64 * (9 * 64 * 2 + 16) + 4 * 32 * (32 * 2 + 16);
+  const int total = B * ((H + ROWS - 1) / ROWS);
+  const int tiles = Cout / 64;
+  int wgs = 512 / tiles;  // workgroups per channel tile (a workgroup keeps its weight chunk when Cin == 64)
+  if (wgs < 1) wgs = 1;
+  const int ppw = (total + wgs - 1) / wgs;
+  const dim3 grid((unsigned)tiles, (unsigned)((total + ppw - 1) / ppw));
+  const auto* a = static_cast<const unsigned short*>(x);
+  const auto* b = static_cast<const unsigned short*>(w);
+  auto* c = static_cast<unsigned short*>(y);
+  if (stats)
+    (void)hd_launch(conv3x3_fwd_kernel<W, ROWS, true>, grid, dim3(256), lds, s, a, ld_x, b, c, ld_y, B, H, Cin, Cout, ppw, stats);
+  else
+    (void)hd_launch(conv3x3_fwd_kernel<W, ROWS, false>, grid, dim3(256), lds, s, a, ld_x, b, c, ld_y, B, H, Cin, Cout, ppw,
+                    (float*)nullptr);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
 struct Wgrad3Plan {
   int tiles, rows_per_slice, images_per_slice, slices;
 };
@@ -1062,4 +1244,24 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
                   p.slices, NK, static_cast<unsigned short*>(dw));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
+}
+
+extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {
+  return B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
+         Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff;
+}
+
+extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout,
+                                    void* y, int64_t y_row_stride, float* stats, hd_stream stream) {
+  if (!x || !w || !y) return HD_ERR_NULL;
+  if (!hd_conv3x3_fwd_supported(B, H, W, Cin, Cout)) return HD_ERR_SHAPE;
+  if (x_row_stride == 0) x_row_stride = Cin;
+  if (y_row_stride == 0) y_row_stride = Cout;
+  if (x_row_stride < Cin || y_row_stride < Cout || x_row_stride % 8 || y_row_stride % 8) return HD_ERR_SHAPE;
+  if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
+  if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (W == 80) return launch_conv3x3_fwd<80, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+  if (W == 40) return launch_conv3x3_fwd<40, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+  return launch_conv3x3_fwd<20, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
 }

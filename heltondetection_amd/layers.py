@@ -109,6 +109,10 @@ class ConvBNAct(nn.Module):
 
     fused = True  # class-wide switch: run BN+activation as the fused HIP kernels on HIP tensors
     pointwise = True  # 1x1 convolutions on the MFMA kernel of csrc/pointwise_conv.hip, BatchNorm statistics in its epilogue
+    # 3x3 / stride 1 forward + data gradient on hd_conv3x3_fwd instead of MIOpen.  Correct (exact on integer data) and at
+    # parity with the library's kernels in the step (29-39 us vs 25-38 us per layer, statistics included), no faster:
+    # off by default; the 3x3 WEIGHT gradient (hd_conv3x3_wgrad) does not depend on this switch.
+    conv3x3_forward = False
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
@@ -167,7 +171,13 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
         from . import ops
         w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
         w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)  # what autocast would hand the library
-        return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0]), act, residual, residual_after_act, out)
+        if ConvBNAct.conv3x3_forward and FusedBNAct.enabled and bn.momentum is not None and bn.num_features // 8 <= 256 \
+                and ops.conv3x3_takes_stats(x, w, conv.stride[0]):
+            # hand-written forward: the BatchNorm statistics come out of its epilogue
+            y = ops.conv3x3(x, w, 1, FusedBNAct.slot_of(bn, x.device))
+            return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
+        return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0], None, ConvBNAct.conv3x3_forward), act, residual,
+                                residual_after_act, out)
     return FusedBNAct.apply(bn, conv(x), act, residual, residual_after_act, out)
 
 

@@ -1041,14 +1041,46 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> to
     return dw
 
 
+def conv3x3_fwd_supported(x: torch.Tensor, cout: int) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and _cl_row_stride(x, 8) is not None):
+        return False
+    B, K, H, W = x.shape
+    return bool(_lib.load().hd_conv3x3_fwd_supported(B, H, W, K, int(cout)))
+
+
+def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Tensor] = None, name: str = "conv3x3_fwd") -> torch.Tensor:
+    """y = 3x3 / stride 1 / pad 1 convolution of x [B, Cin, H, W] (bf16 channels-last rows) with w [Cout, Cin, 3, 3] (bf16,
+    channels-last memory [Cout][3][3][Cin]); stats as for pointwise_conv_rows; no autograd."""
+    lib = _lib.load()
+    B, K, H, W = x.shape
+    N = w.shape[0]
+    ld_x = _cl_row_stride(x, 8)
+    if (ld_x is None or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or tuple(w.shape) != (N, K, 3, 3)
+            or not w.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.HdError("conv3x3_fwd: needs bf16 channels-last rows and a channels-last bf16 [Cout, Cin, 3, 3] weight")
+    y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _note_bytes(name, 2 * (B * H * W * (K + N) + 9 * N * K))
+    with _ktimed(name):
+        check(lib.hd_conv3x3_fwd(_ptr(x), int(ld_x), _ptr(w), B, H, W, K, N, _ptr(y), N, _ptr(stats), _stream(x)), "hd_conv3x3_fwd")
+    return y
+
+
 class _Conv3x3Fn(torch.autograd.Function):
-    """3x3 / pad 1 convolution of stride 1 or 2: forward and data gradient stay with MIOpen, the weight gradient runs on
-    hd_conv3x3_wgrad (no split-K zero-fill, cast or memset launches)."""
+    """3x3 / pad 1 convolution of stride 1 or 2.  Stride 1 with a supported shape: forward on hd_conv3x3_fwd (BatchNorm
+    statistics into `slot` from its epilogue) and the data gradient on the same kernel with the flipped, transposed weights;
+    otherwise those two stay with MIOpen.  The weight gradient always runs on hd_conv3x3_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, slot, ours_fwd):
         ctx.save_for_backward(x, weight)
         ctx.stride = int(stride)
+        N = weight.shape[0]
+        ctx.ours = (bool(ours_fwd) or slot is not None) and ctx.stride == 1 and conv3x3_fwd_supported(x, N) \
+            and weight.is_contiguous(memory_format=torch.channels_last)
+        if ctx.ours:
+            return conv3x3_fwd_rows(x, weight, _fwd_sums(slot, N) if slot is not None else None)
+        if slot is not None:
+            raise _lib.HdError("conv3x3: statistics in the epilogue need the hand-written forward (stride 1, supported shape)")
         return torch.nn.functional.conv2d(x, weight, None, ctx.stride, 1)
 
     @staticmethod
@@ -1056,18 +1088,32 @@ class _Conv3x3Fn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         st = ctx.stride
         dx = dw = None
+        g = dy if (dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None) else \
+            dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (True, False, False))[0]
+            if ctx.ours and conv3x3_fwd_supported(g, x.shape[1]):
+                # dx = conv3x3(dy, wt) with wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]
+                wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+                dx = conv3x3_fwd_rows(g, wt, None, name="conv3x3_dgrad")
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            g = dy if (dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None) else \
-                dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dw = conv3x3_wgrad_rows(g, x, st)
-        return dx, dw, None
+        return dx, dw, None, None, None
 
 
-def conv3x3(x: torch.Tensor, weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
-    return _Conv3x3Fn.apply(x, weight, stride)
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, slot: Optional["_StatSlot"] = None,
+            ours_forward: bool = False) -> torch.Tensor:
+    """3x3 / pad 1 convolution whose weight gradient runs on hd_conv3x3_wgrad.  ours_forward (or a BatchNorm `slot` to fill):
+    forward and data gradient on hd_conv3x3_fwd too (stride 1, supported shapes), else MIOpen's."""
+    return _Conv3x3Fn.apply(x, weight, stride, slot, ours_forward)
+
+
+def conv3x3_takes_stats(x: torch.Tensor, weight: torch.Tensor, stride: int) -> bool:
+    """True when conv3x3(x, weight, stride, slot) runs the hand-written forward (and so can fill a BatchNorm slot)."""
+    return (stride == 1 and weight.dtype == torch.bfloat16 and weight.is_contiguous(memory_format=torch.channels_last)
+            and conv3x3_fwd_supported(x, weight.shape[0]))
 
 
 POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen

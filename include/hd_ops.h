@@ -439,6 +439,17 @@ size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout);
 hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R, int Cin,
                              int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
 
+/* 3x3 / stride 1 / pad 1 convolution forward on channels-last rows, BatchNorm statistics in the epilogue like
+ * hd_pointwise_conv (the bottleneck 3x3 of the YOLOv5 C3 blocks):
+ *     y[b, h, w, n] (bfloat16) = sum over (ky, kx, c) of x[b, h + ky - 1, w + kx - 1, c] * w[n][ky][kx][c]
+ * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 40, 80}; Cin, Cout
+ * multiples of 64; row strides in elements (0 = dense, multiples of 8).  stats: nullable, as for hd_pointwise_conv.
+ * The data gradient is the same entry point applied to dy with the weights flipped and transposed:
+ *     wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]   ->   dx = hd_conv3x3_fwd(dy, wt, ..., Cin = Cout, Cout = Cin). */
+int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);
+hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout, void* y,
+                         int64_t y_row_stride, float* stats, hd_stream stream);
+
 /* Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2 on channels-last rows (the bottleneck and the downsampling
  * 3x3 convolutions of the YOLOv5 backbone / neck):
  *     dw[n][ky][kx][k] (bfloat16, i.e. a channels-last [Cout, Cin, 3, 3] weight) = sum over (b, h, w) of

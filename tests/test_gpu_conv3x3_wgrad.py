@@ -39,20 +39,23 @@ def test_conv3x3_layer_matches_library_path():
     res = {}
     for on in (True, False):
         layers.ConvBNAct.pointwise = on
+        layers.ConvBNAct.conv3x3_forward = on   # also the (off by default) hand-written forward / data gradient
         try:
             m.zero_grad(set_to_none=True)
             ops.bn_arena_reset(dev)
             x = x0.clone().requires_grad_(True)
-            ops.enable_timing("conv3x3_wgrad")
+            ops.enable_timing("conv3x3_wgrad", "conv3x3_fwd")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = m(x.to(torch.bfloat16))
             (y.float() * gy).sum().backward()
             torch.cuda.synchronize()
-            assert len(ops.collect_timing()["conv3x3_wgrad"]) == (1 if on else 0)
+            t_ = ops.collect_timing()
+            assert len(t_["conv3x3_wgrad"]) == (1 if on else 0) and len(t_["conv3x3_fwd"]) == (1 if on else 0)
             ops.disable_timing()
             res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
         finally:
             layers.ConvBNAct.pointwise = True
+            layers.ConvBNAct.conv3x3_forward = False
     for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)
@@ -72,3 +75,33 @@ def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
     dw = ops.conv3x3_wgrad_rows(dy, x, 2)
     ref = _ref(dy, x, 2)
     assert torch.equal(dw.float(), ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 128, 13, 40, 128),
+                                   (1, 64, 80, 80, 64), (2, 64, 5, 80, 128), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64),
+                                   (3, 192, 9, 40, 64)])
+def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
+    """Small integers: exact sums, so the ring / halo / tap views, the Cin chunking, the pixel-tile padding and the
+    transposed store must reproduce F.conv2d exactly; the epilogue's statistics are those of the tensor written."""
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H + W + 7)
+    x = torch.randint(-2, 3, (B, K, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randint(-1, 2, (N, K, 3, 3), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    rep = _lib.load().hd_bn_act_replicas()
+    stats = torch.zeros(rep * 2 * N, dtype=torch.float32, device=dev)
+    y = ops.conv3x3_fwd_rows(x, w, stats)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1)
+    assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
+    yf = y.double()
+    want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    got = stats.view(rep, 2, N).double().sum(0)
+    assert float(((got - want).abs() / (want.abs() + 1.0)).max()) < 1e-5
+    # the data gradient through the same kernel with flipped, transposed weights
+    dy = torch.randint(-2, 3, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+    dx = ops.conv3x3_fwd_rows(dy, wt)
+    dref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w.float(), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                               (True, False, False))[0]
+    assert torch.equal(dx.float(), dref.to(torch.bfloat16).float())
