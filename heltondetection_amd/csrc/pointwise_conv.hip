@@ -1016,7 +1016,9 @@ hd_status launch_conv3x3_fwd(const void* x, int64_t ld_x, const void* w, void* y
   const size_t lds = (size_t)(ROWS + 2) * (PT * 32 + 2) * 144 + 64 * (9 * 64 * 2 + 16) + 4 * 32 * (32 * 2 + 16);
   const int total = B * ((H + ROWS - 1) / ROWS);
   const int tiles = Cout / 64;
-  int wgs = 512 / tiles;  // workgroups per channel tile (a workgroup keeps its weight chunk when Cin == 64)
+  // one workgroup per CU (142-155 KB of LDS), so more workgroups than CUs run in rounds: keep the grid at <= 256 and
+  // choose ROWS so that (passes x channel tiles) is close to a multiple of 256 (W = 40: 16 x 8 x 2, W = 20: 16 x 4 x 4)
+  int wgs = 256 / tiles;
   if (wgs < 1) wgs = 1;
   const int ppw = (total + wgs - 1) / wgs;
   const dim3 grid((unsigned)tiles, (unsigned)((total + ppw - 1) / ppw));
@@ -1262,6 +1264,6 @@ extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const v
   if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (W == 80) return launch_conv3x3_fwd<80, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-  if (W == 40) return launch_conv3x3_fwd<40, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-  return launch_conv3x3_fwd<20, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+  if (W == 40) return launch_conv3x3_fwd<40, 5>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+  return launch_conv3x3_fwd<20, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
 }

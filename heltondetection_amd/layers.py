@@ -109,10 +109,10 @@ class ConvBNAct(nn.Module):
 
     fused = True  # class-wide switch: run BN+activation as the fused HIP kernels on HIP tensors
     pointwise = True  # 1x1 convolutions on the MFMA kernel of csrc/pointwise_conv.hip, BatchNorm statistics in its epilogue
-    # 3x3 / stride 1 forward + data gradient on hd_conv3x3_fwd instead of MIOpen.  Correct (exact on integer data) and at
-    # parity with the library's kernels in the step (29-39 us vs 25-38 us per layer, statistics included), no faster:
-    # off by default; the 3x3 WEIGHT gradient (hd_conv3x3_wgrad) does not depend on this switch.
-    conv3x3_forward = False
+    # 3x3 / stride 1 forward (+ BatchNorm statistics) and data gradient on hd_conv3x3_fwd instead of MIOpen: 20-28 us per
+    # layer in the step against 25-38 us (+ a 6 us statistics launch) for the library's kernels.  The 3x3 WEIGHT gradient
+    # (hd_conv3x3_wgrad) does not depend on this switch.
+    conv3x3_forward = True
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
