@@ -354,7 +354,7 @@ def bn_family_roofline(model, batch, args, device):
     the ops note each launch's algorithmic bytes and shape themselves (ops._note_bytes), in launch order."""
     from heltondetection_amd import ops
     names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
-    pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad")
+    pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")
     passes, per_pass, notes, tags = 3, [], None, None
     try:
         for it in range(passes + 1):  # the first pass warms up
@@ -418,13 +418,15 @@ def bn_family_roofline(model, batch, args, device):
         pms = {k: med([sum(p[k]) for p in per_pass]) for k in pw_names}
         pby = {k: sum(notes[k]) for k in pw_names}
         pn = {k: len(per_pass[0][k]) for k in pw_names}
-        pw = _hbm_entry("1x1 convolution family (pointwise_conv fwd + BN statistics / pointwise_dgrad / pointwise_wgrad + "
-                        "reduce), step-weighted over the model's 1x1 ConvBNAct layers", sum(pms.values()), sum(pby.values()),
+        pw = _hbm_entry("hand-written convolution family (1x1: pointwise_conv fwd + BN statistics / pointwise_dgrad / "
+                        "pointwise_wgrad + reduce; 3x3: conv3x3_fwd + BN statistics / conv3x3_dgrad / conv3x3_wgrad + reduce), "
+                        "step-weighted over the model's layers that take them", sum(pms.values()), sum(pby.values()),
                         sum(pn.values()),
                         {"sum_launch_ms_per_step": round(sum(pms.values()), 4), "algorithmic_bytes_per_step": int(sum(pby.values())),
-                         "algorithmic_bytes": "2 (R (Cin + Cout) + Cin Cout) per call: each operand once, bf16",
-                         "timed": "same passes and event mechanism as the BN family; pointwise_wgrad is an event pair around its "
-                                  "two launches (row-sliced partial products, slab reduction)",
+                         "algorithmic_bytes": "2 (R (Cin + Cout) + taps Cin Cout) per call: each operand once, bf16 (the 3x3 "
+                                              "kernels are MFMA / LDS bound, their HBM fraction is reported for completeness)",
+                         "timed": "same passes and event mechanism as the BN family; the two weight-gradient entries are event pairs "
+                                  "around their two launches (row-sliced partial products, slab reduction)",
                          "per_kernel": {k: {"sum_ms": round(pms[k], 4), "calls": pn[k],
                                             "GB/s": round(pby[k] / pms[k] / 1e6, 1) if pms[k] > 0 else None,
                                             "frac": round(pby[k] / pms[k] / 1e6 / HBM_PEAK_GBS, 4) if pms[k] > 0 else None}
