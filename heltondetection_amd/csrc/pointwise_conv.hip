@@ -372,10 +372,13 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   constexpr int BN = TN * 32;
   const int NT = N / BN;
   const long long RT = ((long long)M + 32 * TM - 1) / (32 * TM);
+  const size_t lds = StreamLds<K, TN, TM, TRB>::TOTAL;
+  // persistent cap = what is resident at once: two workgroups per CU when two fit in LDS, else one (K = 256: 96-112 KB;
+  // 512 workgroups then ran as two rounds, each paying its slab load and first-block latency)
+  const long long cap = lds > 80 * 1024 ? 256 : 512;
   long long g = (RT + 3) / 4 * NT;  // one row block per wave, or the persistent cap
   g = (g + 7) / 8 * 8;
-  if (g > 512) g = 512;
-  const size_t lds = StreamLds<K, TN, TM, TRB>::TOTAL;
+  if (g > cap) g = cap;
   const auto* a = static_cast<const unsigned short*>(A);
   const auto* b = static_cast<const unsigned short*>(Bw);
   auto* c = static_cast<unsigned short*>(Cmat);
