@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float
 // rows are stored as zeros, out-of-image pixels are the halo.  Per 16 pixels a wave issues one dY fragment, nine X
 // fragments and nine MFMAs.  The next X row and dY row travel in registers while the current row is multiplied.
 template <int W>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+__global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                             const unsigned short* __restrict__ X, long long ld_x, int B, int H,
                                                             int N, int K, int rows_per_slice, int images_per_slice,
                                                             float* __restrict__ slab) {
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const unsigned sh
 // halo — so the three column taps are again contiguous views: kx = 0 -> O[wo - 1], kx = 1 -> E[wo], kx = 2 -> O[wo].  The
 // ring holds input rows 2 ho - 1, 2 ho, 2 ho + 1; advancing one output row brings in two input rows.  H, W: OUTPUT size.
 template <int W>
-__global__ __launch_bounds__(256, 2) void conv3x3s2_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+__global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                               const unsigned short* __restrict__ X, long long ld_x, int B, int H,
                                                               int N, int K, int rows_per_slice, int images_per_slice,
                                                               float* __restrict__ slab) {
@@ -1037,6 +1037,10 @@ hd_status launch_conv3x3_fwd(const void* x, int64_t ld_x, const void* w, void* y
   return HD_OK;
 }
 
+// Row widths with an instantiation: the 640^2 / 1280^2 pyramids (20, 40, 80) and the 832^2 ones (26, 52, 104).  One image
+// row (+ halo) must fit the LDS ring, which ends at 104 pixels for the stride-2 weight gradient and the forward kernel.
+static inline bool conv3x3_width_ok(int W) { return W == 20 || W == 26 || W == 40 || W == 52 || W == 80 || W == 104; }
+
 struct Wgrad3Plan {
   int tiles, rows_per_slice, images_per_slice, slices;
 };
@@ -1197,7 +1201,7 @@ extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stri
 }
 
 extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride) {
-  return (stride == 1 || stride == 2) && B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 &&
+  return (stride == 1 || stride == 2) && B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 64 && Cin % 64 == 0 &&
          Cout >= 64 && Cout % 64 == 0 && Cin <= 1024 && Cout <= 1024 && (long long)B * H * W * stride * stride <= 0x7fffffff;
 }
 
@@ -1224,25 +1228,25 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   const dim3 grid((unsigned)p.tiles, (unsigned)p.slices);
   const int WP = (W + 15) / 16 * 16;
   const size_t lds = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
-  if (stride == 2) {
-    if (W == 20)
-      (void)hd_launch(conv3x3s2_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                      p.rows_per_slice, p.images_per_slice, slab);
-    else if (W == 40)
-      (void)hd_launch(conv3x3s2_wgrad_kernel<40>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                      p.rows_per_slice, p.images_per_slice, slab);
-    else
-      (void)hd_launch(conv3x3s2_wgrad_kernel<80>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                      p.rows_per_slice, p.images_per_slice, slab);
-  } else if (W == 20)
-    (void)hd_launch(conv3x3_wgrad_kernel<20>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, p.images_per_slice, slab);
-  else if (W == 40)
-    (void)hd_launch(conv3x3_wgrad_kernel<40>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, p.images_per_slice, slab);
-  else
-    (void)hd_launch(conv3x3_wgrad_kernel<80>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,
-                    p.rows_per_slice, p.images_per_slice, slab);
+#define HD_WGRAD3_CASE(WW)                                                                                              \
+  case WW:                                                                                                              \
+    if (stride == 2)                                                                                                    \
+      (void)hd_launch(conv3x3s2_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, \
+                      p.rows_per_slice, p.images_per_slice, slab);                                                      \
+    else                                                                                                                \
+      (void)hd_launch(conv3x3_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,   \
+                      p.rows_per_slice, p.images_per_slice, slab);                                                      \
+    break;
+  switch (W) {
+    HD_WGRAD3_CASE(20)
+    HD_WGRAD3_CASE(26)
+    HD_WGRAD3_CASE(40)
+    HD_WGRAD3_CASE(52)
+    HD_WGRAD3_CASE(80)
+    HD_WGRAD3_CASE(104)
+    default: return HD_ERR_SHAPE;
+  }
+#undef HD_WGRAD3_CASE
   HD_RETURN_IF_LAUNCH_FAILED();
   const long long NK = (long long)Cout * 9 * Cin;
   (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
@@ -1252,7 +1256,7 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
 }
 
 extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {
-  return B >= 1 && H >= 1 && (W == 20 || W == 40 || W == 80) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
+  return B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
          Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff;
 }
 
@@ -1266,7 +1270,15 @@ extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const v
   if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (W == 80) return launch_conv3x3_fwd<80, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-  if (W == 40) return launch_conv3x3_fwd<40, 5>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-  return launch_conv3x3_fwd<20, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+  // ROWS per width: the LDS ring must fit beside the weight slab, tiles must divide over four waves, and passes x channel
+  // tiles should be close to a multiple of the 256 CUs (one workgroup per CU)
+  switch (W) {
+    case 104: return launch_conv3x3_fwd<104, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 80: return launch_conv3x3_fwd<80, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 52: return launch_conv3x3_fwd<52, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 40: return launch_conv3x3_fwd<40, 5>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 26: return launch_conv3x3_fwd<26, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 20: return launch_conv3x3_fwd<20, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    default: return HD_ERR_SHAPE;
+  }
 }

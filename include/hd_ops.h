@@ -442,7 +442,7 @@ hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* 
 /* 3x3 / stride 1 / pad 1 convolution forward on channels-last rows, BatchNorm statistics in the epilogue like
  * hd_pointwise_conv (the bottleneck 3x3 of the YOLOv5 C3 blocks):
  *     y[b, h, w, n] (bfloat16) = sum over (ky, kx, c) of x[b, h + ky - 1, w + kx - 1, c] * w[n][ky][kx][c]
- * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 40, 80}; Cin, Cout
+ * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 26, 40, 52, 80, 104}; Cin, Cout
  * multiples of 64; row strides in elements (0 = dense, multiples of 8).  stats: nullable, as for hd_pointwise_conv.
  * The data gradient is the same entry point applied to dy with the weights flipped and transposed:
  *     wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]   ->   dx = hd_conv3x3_fwd(dy, wt, ..., Cin = Cout, Cout = Cin). */
@@ -455,7 +455,7 @@ hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int
  *     dw[n][ky][kx][k] (bfloat16, i.e. a channels-last [Cout, Cin, 3, 3] weight) = sum over (b, h, w) of
  *         dy[b, h, w, n] * x[b, stride h + ky - 1, stride w + kx - 1, k]   (zero outside the image; float32 accumulate)
  * H, W: the OUTPUT size; dy [B, H, W, Cout], x [B, stride H, stride W, Cin] bfloat16 rows (strides in elements, 0 = dense).
- * W in {20, 40, 80}; Cin, Cout multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
+ * W in {20, 26, 40, 52, 80, 104}; Cin, Cout multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
  * workspace: hd_conv3x3_wgrad_workspace_bytes(...), 16-byte aligned, contents undefined on entry and exit. */
 int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride);
 size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);

@@ -13,7 +13,8 @@ def _ref(dy, x, stride=1):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (3, 64, 40, 40, 128), (2, 128, 13, 40, 128),
-                                   (1, 64, 80, 80, 64), (2, 64, 5, 80, 64), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64)])
+                                   (1, 64, 80, 80, 64), (2, 64, 5, 80, 64), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64),
+                                   (2, 64, 26, 26, 128), (1, 128, 11, 52, 64), (1, 64, 9, 104, 64)])
 def test_conv3x3_wgrad_is_exact_on_integer_data(shape):
     """Small integers: all products and sums are exact in float32, so borders (zero halo), row slices with their halo
     rows, the pixel padding to 16 and the tap -> (row slot, shift) mapping must reproduce the exact gradient."""
@@ -62,7 +63,8 @@ def test_conv3x3_layer_matches_library_path():
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 64, 9, 40, 64),
-                                   (1, 64, 80, 80, 128), (16, 256, 20, 20, 512), (1, 64, 1, 20, 64)])
+                                   (1, 64, 80, 80, 128), (16, 256, 20, 20, 512), (1, 64, 1, 20, 64),
+                                   (2, 64, 13, 26, 64), (1, 64, 7, 52, 128), (1, 64, 5, 104, 64)])
 def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
     """Stride 2: (B, Cin, Ho, Wo, Cout) with the input 2 Ho x 2 Wo; even / odd pixel planes, two new input rows per output row."""
     from heltondetection_amd import ops
@@ -79,7 +81,7 @@ def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 128, 13, 40, 128),
                                    (1, 64, 80, 80, 64), (2, 64, 5, 80, 128), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64),
-                                   (3, 192, 9, 40, 64)])
+                                   (3, 192, 9, 40, 64), (2, 128, 26, 26, 64), (1, 64, 11, 52, 128), (1, 64, 7, 104, 64)])
 def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
     """Small integers: exact sums, so the ring / halo / tap views, the Cin chunking, the pixel-tile padding and the
     transposed store must reproduce F.conv2d exactly; the epilogue's statistics are those of the tensor written."""
