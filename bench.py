@@ -69,12 +69,51 @@ def parse():
     ap.add_argument("--graph-sync", choices=("auto", "on", "off"), default="auto",
                     help="drain the stream after each replayed graph segment before its collective (auto: only for the gloo "
                          "rehearsal backend, see train.Trainer)")
+    ap.add_argument("--graph-split", choices=("auto", "on", "off"), default="auto",
+                    help="multi-rank hipGraph mode: cut the captured step at the gradient-bucket boundaries (on / auto) or replay "
+                         "one graph and launch the collectives behind it (off)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the fp32 and 832x832 companion legs of the default run")
+    ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each companion leg (after 5 warm-up steps)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="skip MIOpen's per-shape solver search (faster first step, ~20%% slower steady state)")
     args = ap.parse_args()
     if args.size <= 0:
         args.size = 640 if args.model == "yolov5" else 832
     return args
+
+
+def ensure_world(args) -> None:
+    """`--gpus N` is a promise about the number of ranks.  Called before anything touches the GPU:
+      * WORLD_SIZE == N (the driver's torch.distributed.run launch, or N == 1 run directly): nothing to do;
+      * no launcher in the environment and N > 1: start the N ranks ourselves as fresh child processes
+        (`python -m torch.distributed.run ... bench.py <same flags>`), pass rank 0's JSON line through and exit with the
+        launcher's code — this process never initialises HIP, so nothing is exec'ed or forked behind a live GPU context;
+      * a launcher is present but disagrees with --gpus: exit non-zero with the launch line (never a line that claims
+        n_gpus = WORLD_SIZE for a run asked to use --gpus N)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}; launch as\n  python -m torch.distributed.run "
+                             f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import subprocess
+    if os.environ.get("HD_DIST_BACKEND") != "gloo":
+        n_dev = torch.cuda.device_count()  # counting devices does not initialise HIP on this image
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {n_dev} GPU(s) (HD_DIST_BACKEND=gloo rehearses "
+                             "several ranks on one device and labels the line as a rehearsal)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def model_cfg(args):
@@ -164,20 +203,27 @@ def cpu_baseline(args):
         loss.backward()
         opt.step()
 
-    print("[bench cpu] warm-up step ...", file=sys.stderr, flush=True)
-    step()  # warm-up
-    print("[bench cpu] timed steps ...", file=sys.stderr, flush=True)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    # SURVEY.md section 8d protocol, scaled to the bounded sample the bench contract allows (about 10-30 s of CPU work):
+    # 2 untimed warm-up steps, then >= 10 individually timed steps (or 30 s), the MEDIAN step time is what is reported
+    warm, want, budget_s = 2, 10, 30.0
+    load0 = os.getloadavg()[0] if hasattr(os, "getloadavg") else None
+    for i in range(warm):
+        print(f"[bench cpu] warm-up step {i} ...", file=sys.stderr, flush=True)
         step()
-        n += 1
-        el = time.perf_counter() - t0
-        print(f"[bench cpu] step {n}: {el:.1f} s elapsed", file=sys.stderr, flush=True)
-        if el > 12.0 or n >= 4:
-            break
-    return {"value": round(B * n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of YOLOv5s {args.size}x{args.size} bs={B} fp32 after 1 warm-up "
-                      f"(PyTorch-CPU restatement, oracle/torch_ref.py loss)"}
+    per, t_all = [], time.perf_counter()
+    while len(per) < want and (time.perf_counter() - t_all < budget_s or len(per) < 3):
+        t0 = time.perf_counter()
+        step()
+        per.append(time.perf_counter() - t0)
+        print(f"[bench cpu] step {len(per)}: {per[-1]:.2f} s", file=sys.stderr, flush=True)
+    srt = sorted(per)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_string(), "threads": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(),
+            "loadavg_1min_before": load0, "step_s": {"median": round(med, 3), "min": round(srt[0], 3), "max": round(srt[-1], 3)},
+            "sample": f"median of {len(per)} individually timed train steps of YOLOv5s {args.size}x{args.size} bs={B} fp32 after "
+                      f"{warm} warm-up steps (our PyTorch-CPU restatement of the step, oracle/torch_ref.py loss; not the reference's "
+                      f"CPU path, which is not in the snapshot)"}
 
 
 def _yolo_views(B, size, no, device, na=3, strides=(8, 16, 32)):
@@ -345,6 +391,19 @@ def _hbm_entry(kernel, ms, nbytes, launches, extra=None, traffic=None):
     return d
 
 
+def _conv_kernel_entry(name, ms, nbytes, calls, flops):
+    """One kernel of the convolution family against ITS bound: the 1x1 kernels stream their operands once (HBM), the 3x3
+    kernels are implicit GEMMs whose 9x operand reuse puts them under the MFMA roof (dense bf16 peak, not the sparse one)."""
+    if ms <= 0:
+        return {"sum_ms": 0.0, "calls": calls}
+    gbs, tfs = nbytes / ms / 1e6, flops / ms / 1e9
+    mfma = name.startswith("conv3x3")
+    return {"sum_ms": round(ms, 4), "calls": calls, "bound": "mfma" if mfma else "hbm",
+            "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+            "TFLOP/s": round(tfs, 1), "frac_mfma": round(tfs / MFMA_PEAK_TFLOPS, 4),
+            "frac": round(tfs / MFMA_PEAK_TFLOPS, 4) if mfma else round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def bn_family_roofline(model, batch, args, device):
     """Step-weighted roofline of the fused BN+act kernels, measured IN the train step: three eager forward + loss +
     backward passes of this workload with every fused-BN launch stamping its own HIP event pair (kernel begin / end,
@@ -427,12 +486,28 @@ def bn_family_roofline(model, batch, args, device):
                                               "kernels are MFMA / LDS bound, their HBM fraction is reported for completeness)",
                          "timed": "same passes and event mechanism as the BN family; the two weight-gradient entries are event pairs "
                                   "around their two launches (row-sliced partial products, slab reduction)",
-                         "per_kernel": {k: {"sum_ms": round(pms[k], 4), "calls": pn[k],
-                                            "GB/s": round(pby[k] / pms[k] / 1e6, 1) if pms[k] > 0 else None,
-                                            "frac": round(pby[k] / pms[k] / 1e6 / HBM_PEAK_GBS, 4) if pms[k] > 0 else None}
+                         "per_kernel": {k: _conv_kernel_entry(k, pms[k], pby[k], pn[k], sum((t or {}).get("flops", 0) for t in tags[k]))
                                         for k in pw_names}})
     fam["_pointwise"] = pw
     return fam
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec)
+
+
+def family_rooflines(model, batch, args, device):
+    """The hand-written kernel families of the step, largest summed launch time first: element 0 is the line's `roofline`
+    (the DOMINANT family), the rest ride in `roofline_secondary`.  Every kernel of a family is also priced against its own
+    bound in `per_kernel`: HBM bytes for the streaming kernels (1x1 convolutions, fused BN), MFMA FLOPs / 2.5 PFLOP/s for
+    the 3x3 implicit-GEMM kernels."""
+    fam = bn_family_roofline(model, batch, args, device)
+    pw = fam.pop("_pointwise", None)
+    fams = [f for f in (fam, pw) if f]
+    fams.sort(key=lambda f: -float(f.get("sum_launch_ms_per_step", 0.0)))
+    if fams:
+        fams[0]["dominant"] = True
+        fams[0]["family_sum_ms"] = {f["kernel"].split(" (")[0].split(",")[0][:48]: f.get("sum_launch_ms_per_step") for f in fams}
+    return fams
 
 
 def yolo_dense_grad_roofline(model, batch, args):
@@ -524,22 +599,138 @@ def roi_align_roofline(model, batch, args, device):
     return main
 
 
-def main():
-    args = parse()
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def run_leg(args, device, rank, world, log, steps, warmup, tag=""):
+    """One measured configuration under the bench contract: build the model + Trainer, `warmup` untimed steps (MIOpen's
+    solver search and the hipGraph capture happen there), then EXACTLY `steps` steps between barrier + synchronise pairs,
+    max over ranks.  The two hipGraph guards (finite loss; a replay reproduces the eager loss) re-time eagerly when they
+    trip.  Returns the numbers plus the live objects the roofline legs measure on."""
     from heltondetection_amd import ops
     from heltondetection_amd.detectors import build_detector
-    from heltondetection_amd.dist import init_distributed
     from heltondetection_amd.train import Trainer
+
+    model = build_detector(model_cfg(args)).to(device).to(memory_format=torch.channels_last).train()
+    # the hipGraph is captured after `graph_warmup` eager steps (the first one runs MIOpen's solver search, which
+    # cannot happen inside a capture); keep that inside the untimed warm-up whatever --warmup is
+    graph_warmup = min(3, max(1, warmup - 1))
+    lr = 1e-3 if args.model == "yolov5" else 2e-4
+    trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
+                      total_steps=steps + warmup + 8, warmup_steps=3, device=device,
+                      use_graph=not args.no_graph, graph_warmup=graph_warmup,
+                      graph_sync={"auto": None, "on": True, "off": False}[args.graph_sync],
+                      graph_split={"auto": True, "on": True, "off": False}[args.graph_split])
+    batches = make_batches(4 if args.model == "yolov5" else 2, args.batch, args.size, args.classes, 1234 + rank, device)
+
+    log(f"{tag}{model_name(args)} {args.size}^2 bs{args.batch} {'fp32' if args.fp32 else 'bf16'} + data ready on "
+        f"{torch.cuda.get_device_name(device)}; warm-up {warmup} steps (first steps include MIOpen kernel selection/compilation)")
+    eager_ms = []  # steady eager steps seen before the graph takes over (step 0 is MIOpen's search)
+    for i in range(warmup):
+        tw = time.perf_counter()
+        trainer.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - tw) * 1e3
+        if i >= 1 and trainer._graph is None:
+            eager_ms.append(dt)
+        log(f"{tag}warm-up step {i}: {dt:.1f} ms")
+    # --warmup too small for the capture to have happened: finish it as untimed set-up (reported in config), so the
+    # K timed steps are K steady-state steps and not (K-1) steps plus a graph capture
+    extra_setup = 0
+    while trainer.use_graph and trainer._graph is None and extra_setup < graph_warmup + 2:
+        trainer.step(*batches[extra_setup % len(batches)])
+        extra_setup += 1
+    if extra_setup:
+        log(f"{tag}{extra_setup} extra untimed set-up step(s) to finish the hipGraph capture (--warmup {warmup})")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    def timed_region():
+        graph_on_ = trainer._graph is not None
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for i in range(steps):
+            loss_, parts_ = trainer.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_, loss_, graph_on_
+
+    elapsed, loss, graph_on = timed_region()
+    ok = torch.isfinite(loss).all().to(torch.int32).reshape(1)
+    if graph_on and bool(ok.item()) and trainer._segments is None:
+        # second guard: one more replay (no optimizer step) must reproduce what an eager forward of the same
+        # weights computes on the same batch (bf16 convs + atomics: agree to ~1e-2, corruption is off by >>)
+        for dst, src in zip(trainer._static, batches[0]):
+            dst.copy_(src)
+        trainer._graph.replay()
+        torch.cuda.synchronize()
+        l_graph = float(trainer._static_out[0])
+        if args.model == "yolov5":  # FasterRCNN's loss samples RoIs at random: two evaluations are not comparable
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+                l_eager = float(model.forward_train(*batches[0])[0])
+            if not (abs(l_graph - l_eager) <= 0.05 * abs(l_eager) + 1e-3):
+                log(f"{tag}graph replay loss {l_graph} != eager loss {l_eager}")
+                ok.zero_()
+        elif not (l_graph == l_graph and abs(l_graph) < 1e4):
+            ok.zero_()
+    slow_replay = bool(graph_on and eager_ms and elapsed / steps * 1e3 > 1.5 * min(eager_ms))
+    if slow_replay:
+        # NOT a fallback (ADVICE r01): a stall between the replay and the collectives would show up exactly like this
+        # (DESIGN.md section 9); the slow number is reported as measured and flagged so a recurrence cannot hide
+        log(f"{tag}ERROR: graph-mode step {elapsed / steps * 1e3:.1f} ms is slower than the eager steps it replaces "
+            f"({min(eager_ms):.1f} ms); reporting it as measured with config.hip_graph_slow_replay = true")
+    if world > 1:  # every rank must take the same branch
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if graph_on and not bool(ok.item()):
+        # safety net for the hipGraph path (DESIGN.md §9): never report a number from a corrupted run
+        log(f"{tag}hipGraph guard tripped (non-finite / mismatching loss): rebuilding the trainer and re-timing eagerly")
+        ops.disable_timing()
+        model = build_detector(model_cfg(args)).to(device).to(memory_format=torch.channels_last).train()
+        trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
+                          total_steps=steps + warmup + 1, warmup_steps=3, device=device, use_graph=False)
+        trainer.graph_error = "hipGraph guard tripped (loss check); re-timed eagerly"
+        for i in range(warmup):
+            trainer.step(*batches[i % len(batches)])
+        elapsed, loss, graph_on = timed_region()
+        slow_replay = False
+    ops.disable_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"elapsed": elapsed, "loss": float(loss.item()), "model": model, "trainer": trainer, "batches": batches,
+            "slow_replay": slow_replay, "eager_ms": eager_ms, "extra_setup": extra_setup, "steps": steps, "warmup": warmup}
+
+
+def main():
+    args = parse()
+    ensure_world(args)  # before the first GPU call
+    from heltondetection_amd import ops
+    from heltondetection_amd.dist import init_distributed
 
     rank, local, world = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    if os.environ.get("HD_DIST_BACKEND") == "gloo":  # rehearsal: every rank on GPU 0
+    rehearsal = os.environ.get("HD_DIST_BACKEND") == "gloo"
+    if rehearsal:  # every rank on GPU 0
         local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.manual_seed(0)  # identical init on every rank (also broadcast by GradReducer)
     torch.backends.cudnn.benchmark = not args.no_miopen_find  # MIOpen find: +20% steady state, ~80 s first step
+    backend = dist.get_backend() if world > 1 else None
+    n_devices = 1 if (rehearsal or world == 1) else world  # one device per rank unless this is the one-GPU rehearsal
 
     def log(msg):
         if rank == 0:
@@ -557,103 +748,17 @@ def main():
                 log(f"heartbeat {int(time.time() - t0)} s")
         threading.Thread(target=_beat, daemon=True).start()
 
-    model = build_detector(model_cfg(args)).to(device).to(memory_format=torch.channels_last).train()
-    # the hipGraph is captured after `graph_warmup` eager steps (the first one runs MIOpen's solver search, which
-    # cannot happen inside a capture); keep that inside the untimed warm-up whatever --warmup is
-    graph_warmup = min(3, max(1, args.warmup - 1))
-    lr = 1e-3 if args.model == "yolov5" else 2e-4
-    trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
-                      total_steps=args.steps + args.warmup + 8, warmup_steps=3, device=device,
-                      use_graph=not args.no_graph, graph_warmup=graph_warmup,
-                      graph_sync={"auto": None, "on": True, "off": False}[args.graph_sync])
-    batches = make_batches(4 if args.model == "yolov5" else 2, args.batch, args.size, args.classes, 1234 + rank, device)
-
-    log(f"{model_name(args)} + data ready on {torch.cuda.get_device_name(device)}; warm-up {args.warmup} steps "
-        "(first steps include MIOpen kernel selection/compilation)")
-    eager_ms = []  # steady eager steps seen before the graph takes over (step 0 is MIOpen's search)
-    for i in range(args.warmup):
-        tw = time.perf_counter()
-        trainer.step(*batches[i % len(batches)])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - tw) * 1e3
-        if i >= 1 and trainer._graph is None:
-            eager_ms.append(dt)
-        log(f"warm-up step {i}: {dt:.1f} ms")
-    # --warmup too small for the capture to have happened: finish it as untimed set-up (reported in config), so the
-    # K timed steps are K steady-state steps and not (K-1) steps plus a graph capture
-    extra_setup = 0
-    while trainer.use_graph and trainer._graph is None and extra_setup < graph_warmup + 2:
-        trainer.step(*batches[extra_setup % len(batches)])
-        extra_setup += 1
-    if extra_setup:
-        log(f"{extra_setup} extra untimed set-up step(s) to finish the hipGraph capture (--warmup {args.warmup})")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-
-    def timed_region():
-        graph_on_ = trainer._graph is not None
-        torch.cuda.synchronize()
-        t0_ = time.perf_counter()
-        for i in range(args.steps):
-            loss_, parts_ = trainer.step(*batches[i % len(batches)])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0_, loss_, graph_on_
-
-    elapsed, loss, graph_on = timed_region()
-    ok = torch.isfinite(loss).all().to(torch.int32).reshape(1)
-    if graph_on and bool(ok.item()):
-        # second guard: one more replay (no optimizer step) must reproduce what an eager forward of the same
-        # weights computes on the same batch (bf16 convs + atomics: agree to ~1e-2, corruption is off by >>)
-        for dst, src in zip(trainer._static, batches[0]):
-            dst.copy_(src)
-        trainer._graph.replay()
-        torch.cuda.synchronize()
-        l_graph = float(trainer._static_out[0])
-        if args.model == "yolov5":  # FasterRCNN's loss samples RoIs at random: two evaluations are not comparable
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
-                l_eager = float(model.forward_train(*batches[0])[0])
-            if not (abs(l_graph - l_eager) <= 0.05 * abs(l_eager) + 1e-3):
-                log(f"graph replay loss {l_graph} != eager loss {l_eager}")
-                ok.zero_()
-        elif not (l_graph == l_graph and abs(l_graph) < 1e4):
-            ok.zero_()
-    slow_replay = bool(graph_on and eager_ms and elapsed / args.steps * 1e3 > 1.5 * min(eager_ms))
-    if slow_replay:
-        # NOT a fallback: a stall between the replay and the collectives would show up exactly like this
-        # (DESIGN.md section 9); the slow number is reported as measured and flagged so a recurrence cannot hide
-        log(f"ERROR: graph-mode step {elapsed / args.steps * 1e3:.1f} ms is slower than the eager steps it replaces "
-            f"({min(eager_ms):.1f} ms); reporting it as measured with config.hip_graph_slow_replay = true")
-    if world > 1:  # every rank must take the same branch
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if graph_on and not bool(ok.item()):
-        # safety net for the hipGraph path: never report a number from a corrupted run
-        log("hipGraph guard tripped (non-finite / mismatching loss): rebuilding the trainer and re-timing eagerly")
-        ops.disable_timing()
-        model = build_detector(model_cfg(args)).to(device).to(memory_format=torch.channels_last).train()
-        trainer = Trainer(model, lr=lr, amp_dtype=None if args.fp32 else torch.bfloat16,
-                          total_steps=args.steps + args.warmup + 1, warmup_steps=3, device=device, use_graph=False)
-        trainer.graph_error = "hipGraph guard tripped (loss check); re-timed eagerly"
-        for i in range(args.warmup):
-            trainer.step(*batches[i % len(batches)])
-        elapsed, loss, graph_on = timed_region()
-        slow_replay = False
-    ops.disable_timing()
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss.item())
+    leg = run_leg(args, device, rank, world, log, args.steps, args.warmup)
+    elapsed, model, trainer, batches = leg["elapsed"], leg["model"], leg["trainer"], leg["batches"]
 
     if rank == 0:
+        exchange = "no exchange (one rank)" if world == 1 else \
+            (f"{backend} all-reduce" + (" = RCCL over xGMI" if backend == "nccl" else " (REHEARSAL: ranks time-slice one GPU)"))
         out = {
             "metric": f"images/sec train step, {model_name(args)} {args.size}² bs={args.batch}/GPU",
             "value": round(world * args.batch * args.steps / elapsed, 2),
             "unit": "images/s",
-            "n_gpus": world,
+            "n_gpus": n_devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -663,19 +768,27 @@ def main():
             "dtype": "fp32" if args.fp32 else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{model_name(args)} {args.size}x{args.size} bs={args.batch}/GPU train step "
-                                   "(fwd + HIP assign/loss/RoI ops + bwd + RCCL all-reduce + AdamW), random-init weights",
+                                   f"(fwd + HIP assign/loss/RoI ops + bwd + {exchange} + AdamW), random-init weights",
                        "global_batch": world * args.batch, "img_size": args.size, "num_classes": args.classes,
-                       "parallelism": f"dp{world}"},
-            "final_loss": round(loss_val, 4),
+                       "parallelism": f"dp{world}", "ranks": world, "backend": backend},
+            "final_loss": round(leg["loss"], 4),
         }
+        if rehearsal and world > 1:
+            out["config"]["rehearsal"] = True  # `value` is NOT a multi-GPU figure: `ranks` processes shared one device
         out["config"]["hip_graph"] = trainer._graph is not None
         if getattr(trainer, "_segments", None) is not None:
             out["config"]["hip_graph_segments"] = len(trainer._segments)   # split replay: all-reduce k overlaps segment k + 1
-        if slow_replay:
+        if world > 1:
+            out["config"]["graph_sync"] = bool(trainer.graph_sync)
+            # overlapped split replay checks itself once against the drained form (train.Trainer._verify_overlap)
+            out["config"]["graph_overlap_check_rel_l2"] = trainer.graph_overlap_check
+            if trainer.graph_overlap_error:
+                out["config"]["graph_overlap_error"] = trainer.graph_overlap_error
+        if leg["slow_replay"]:
             out["config"]["hip_graph_slow_replay"] = True
-            out["config"]["eager_ms_per_step_seen_in_warmup"] = round(min(eager_ms), 3)
-        if extra_setup:
-            out["config"]["extra_untimed_setup_steps"] = extra_setup
+            out["config"]["eager_ms_per_step_seen_in_warmup"] = round(min(leg["eager_ms"]), 3)
+        if leg["extra_setup"]:
+            out["config"]["extra_untimed_setup_steps"] = leg["extra_setup"]
         if trainer.graph_error:
             out["config"]["hip_graph_error"] = trainer.graph_error[:200]
         log(f"timed region done: {out['value']} images/s (hipGraph={'on' if trainer._graph is not None else 'off'})")
@@ -685,14 +798,13 @@ def main():
             if args.no_roofline:
                 out["roofline"] = None
             elif args.model == "yolov5":
-                out["roofline"] = bn_family_roofline(model, batches[0], args, device)
-                pw_entry = out["roofline"].pop("_pointwise", None)
-                out["roofline_secondary"] = ([pw_entry] if pw_entry else []) + [yolo_dense_grad_roofline(model, batches[0], args)]
+                fams = family_rooflines(model, batches[0], args, device)
+                out["roofline"], rest = fams[0], fams[1:]
+                out["roofline_secondary"] = rest + [yolo_dense_grad_roofline(model, batches[0], args)]
             else:
-                out["roofline"] = roi_align_roofline(model, batches[0], args, device)
-                fam_ = bn_family_roofline(model, batches[0], args, device)
-                pw_entry = fam_.pop("_pointwise", None)
-                out["roofline_secondary"] = [fam_] + ([pw_entry] if pw_entry else [])
+                fams = family_rooflines(model, batches[0], args, device)
+                out["roofline"] = fams[0]
+                out["roofline_secondary"] = fams[1:] + [roi_align_roofline(model, batches[0], args, device)]
         except Exception as e:  # never lose the headline number to a secondary measurement
             out["roofline_error"] = repr(e)[:300]
         if world == 1 and not args.no_micro:
@@ -707,6 +819,31 @@ def main():
                                  pmc_traffic("pairwise_iou_cols_kernel", k["shape"]), "traffic_source": TRAFFIC_SOURCE})
             except Exception as e:  # the headline number must survive a micro-leg problem
                 out["kernels_error"] = repr(e)
+        # Companion legs (N = 1, default workload only): the same step without autocast, and at 832^2 (north_star names
+        # both sizes; BASELINE config 3's resolution) — short runs under the same timing contract, reported inside this line
+        if world == 1 and not args.no_legs and args.model == "yolov5" and not args.fp32 and args.size == 640:
+            import copy
+            import gc
+            del leg, model, trainer, batches
+            for name, over in (("fp32", {"fp32": True}), ("size_832", {"size": 832})):
+                gc.collect()
+                torch.cuda.empty_cache()
+                a2 = copy.copy(args)
+                for k, v in over.items():
+                    setattr(a2, k, v)
+                try:
+                    l2 = run_leg(a2, device, rank, world, log, args.leg_steps, 5, tag=f"[{name}] ")
+                    out[name] = {"ms_per_step": round(l2["elapsed"] / l2["steps"] * 1e3, 3),
+                                 "value": round(a2.batch * l2["steps"] / l2["elapsed"], 2), "unit": "images/s",
+                                 "steps": l2["steps"], "warmup": l2["warmup"], "dtype": "fp32" if a2.fp32 else "bf16",
+                                 "workload": f"{model_name(a2)} {a2.size}x{a2.size} bs={a2.batch}",
+                                 "hip_graph": l2["trainer"]._graph is not None, "final_loss": round(l2["loss"], 4)}
+                    if l2["trainer"].graph_error:
+                        out[name]["hip_graph_error"] = l2["trainer"].graph_error[:200]
+                    log(f"[{name}] {out[name]['ms_per_step']} ms/step, {out[name]['value']} images/s")
+                    del l2
+                except Exception as e:
+                    out[name] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             if args.model == "yolov5":
                 out["cpu_baseline"] = cpu_baseline(args)

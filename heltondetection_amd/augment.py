@@ -3,8 +3,9 @@
 `Mosaic(p)` recombines the images of a batch already resident in HBM: with probability `p` an output
 image is a 4-tile mosaic of itself and three other images of the batch around a random centre
 (README.md:76-77,129-130: "Mosaic p=0.5 / 1.0").  The random draws are made on the device with a
-torch.Generator, so a step containing it has no host round trip and stays hipGraph-capturable; the
-pixel / box work is csrc/mosaic.hip."""
+torch.Generator (no host round trip); train.Trainer makes them eagerly right before each step (`draw`) and the step itself
+— eager or replayed from a hipGraph — only runs `apply` on the drawn tensors (rng.py: nothing random inside a captured
+region); the pixel / box work is csrc/mosaic.hip."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -37,7 +38,11 @@ class Mosaic:
 
     def __call__(self, images, gt_boxes, gt_cls, m_valid):
         B, _, S, _ = images.shape
-        src, center, apply = self.draw(B, S, images.device)
+        return self.apply(images, gt_boxes, gt_cls, m_valid, *self.draw(B, S, images.device))
+
+    def apply(self, images, gt_boxes, gt_cls, m_valid, src, center, apply):
+        """The deterministic half: recombine the batch according to drawn (src, center, apply).  train.Trainer calls
+        `draw()` eagerly before every step and this inside the (possibly hipGraph-captured) step — see rng.py."""
         out, boxes, cls, cnt = ops.mosaic4(images, gt_boxes, gt_cls, m_valid, src, center, apply, self.fill,
                                            self.min_wh, self.min_area_ratio)
         if self.max_boxes is not None and boxes.shape[1] > self.max_boxes:  # fixed padded width for the assigners

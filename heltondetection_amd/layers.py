@@ -323,8 +323,9 @@ class SPPF(nn.Module):
 class DropBlock2d(nn.Module):
     """DropBlock regularisation (the "*_dropBlock0.5" rows of README.md:90,132-133): contiguous
     `block_size` x `block_size` squares of a feature map are zeroed with overall drop probability `p`,
-    and the survivors rescaled.  Identity in eval mode.  Device-side only (no host sync), so a step that
-    contains it still captures into a hipGraph."""
+    and the survivors rescaled.  Identity in eval mode.  Device-side only (no host sync); under train.Trainer the uniform
+    field comes from the step's StepRandom pool (rng.py), so a step that contains it captures into a hipGraph and still sees
+    fresh values at every replay, split or not."""
 
     def __init__(self, p: float = 0.1, block_size: int = 5):
         super().__init__()
@@ -340,7 +341,10 @@ class DropBlock2d(nn.Module):
         bs = max(bs, 1)
         # seed rate so that the expected dropped fraction is p (the public DropBlock formula)
         gamma = self.p / (bs * bs) * (H * W) / max((H - bs + 1) * (W - bs + 1), 1)
-        seeds = (torch.rand((B, C, H, W), device=x.device) < gamma).to(x.dtype)
+        from .rng import StepRandom
+        pool = StepRandom.active()   # train.Trainer: the field is refilled eagerly before every step (rng.py)
+        u = pool.uniform(self, (B, C, H, W)) if pool is not None else torch.rand((B, C, H, W), device=x.device)
+        seeds = (u < gamma).to(x.dtype)
         drop = torch.nn.functional.max_pool2d(seeds, bs, 1, bs // 2)
         keep = 1.0 - drop
         scale = keep.numel() / keep.float().sum().clamp(min=1.0)

@@ -934,7 +934,7 @@ def pointwise_conv_rows(x: torch.Tensor, w2: torch.Tensor, stats: Optional[torch
     ld_y = _cl_row_stride(out, 8)
     if ld_y is None or out.shape != (B, N, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_conv: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cout, H, W]")
-    _note_bytes(name, 2 * (B * H * W * (K + N) + N * K))
+    _note_bytes(name, 2 * (B * H * W * (K + N) + N * K), {"flops": 2 * B * H * W * K * N})
     with _ktimed(name):
         check(lib.hd_pointwise_conv(_ptr(x), int(ld_x), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_y), _ptr(stats), _stream(x)),
               "hd_pointwise_conv")
@@ -977,7 +977,7 @@ def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch
     ld_dx = _cl_row_stride(out, 8)
     if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
-    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K))
+    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K), {"flops": 2 * B * H * W * K * N})
     with _ktimed("pointwise_dgrad"):
         check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
               "hd_pointwise_conv_dgrad")
@@ -1003,7 +1003,7 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64")
     ws = _wgrad_workspace(dy.device, nbytes)
     dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
-    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K))
+    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K), {"flops": 2 * R * K * N})
     with _timed("pointwise_wgrad"):
         check(lib.hd_pointwise_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), R, K, N, _ptr(dw), _ptr(ws), ws.numel(),
                                      _stream(dy)), "hd_pointwise_wgrad")
@@ -1034,7 +1034,7 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> to
         raise _lib.HdError("conv3x3_wgrad: output W must be 20, 40 or 80, channel counts multiples of 64, stride 1 or 2")
     ws = _wgrad_workspace(dy.device, nbytes)
     dw = torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
-    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K))
+    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
     with _timed("conv3x3_wgrad"):
         check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
                                    ws.numel(), _stream(dy)), "hd_conv3x3_wgrad")
@@ -1059,7 +1059,7 @@ def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Ten
             or not w.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.HdError("conv3x3_fwd: needs bf16 channels-last rows and a channels-last bf16 [Cout, Cin, 3, 3] weight")
     y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    _note_bytes(name, 2 * (B * H * W * (K + N) + 9 * N * K))
+    _note_bytes(name, 2 * (B * H * W * (K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
     with _ktimed(name):
         check(lib.hd_conv3x3_fwd(_ptr(x), int(ld_x), _ptr(w), B, H, W, K, N, _ptr(y), N, _ptr(stats), _stream(x)), "hd_conv3x3_fwd")
     return y

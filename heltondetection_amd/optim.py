@@ -41,10 +41,24 @@ class HdAdamW(torch.optim.AdamW):
     def _key(self, group):
         return tuple((p.data_ptr(), p.grad.data_ptr()) for p in group["params"] if p.grad is not None)
 
+    def _step_of(self, p) -> float:
+        st = self.state.get(p)
+        return float(st["step"]) if st else 0.0
+
     def _build(self, group):
-        ps = [p for p in group["params"] if p.grad is not None]
-        if not ps:
+        """-> list of launch tables, one per distinct step count among the group's parameters (torch.optim.AdamW keeps a
+        step per parameter; they differ when a parameter started receiving gradients later or after a loaded state_dict with
+        mixed counts, and the bias corrections are per step count).  Parameters advance together afterwards, so the
+        partition stays valid until the gradient set changes (the key)."""
+        ps_all = [p for p in group["params"] if p.grad is not None]
+        if not ps_all:
             return None
+        by_step = {}
+        for p in ps_all:
+            by_step.setdefault(self._step_of(p), []).append(p)
+        return [self._build_one(group, ps) for _, ps in sorted(by_step.items())]
+
+    def _build_one(self, group, ps):
         dev = ps[0].device
         descs, ct, cs = (_Desc * len(ps))(), [], []
         for i, p in enumerate(ps):
@@ -77,23 +91,22 @@ class HdAdamW(torch.optim.AdamW):
         for gi, group in enumerate(self.param_groups):
             if group.get("amsgrad") or group.get("maximize"):
                 raise _lib.HdError("HdAdamW: amsgrad / maximize are not implemented")
-            tab = self._tables[gi]
-            if tab is None or tab[4] != self._key(group):   # first step, re-pointed gradients, loaded state
-                tab = self._tables[gi] = self._build(group)
-            if tab is None:
+            tabs = self._tables[gi]
+            if tabs is None or tabs[0][4] != self._key(group):   # first step, re-pointed gradients, loaded state
+                tabs = self._tables[gi] = self._build(group)
+            if tabs is None:
                 continue
-            raw, ct, cs, n_chunks, _, ps = tab
-            st0 = self.state[ps[0]]["step"]
-            t = float(st0) + 1.0
-            for p in ps:
-                self.state[p]["step"] += 1
             b1, b2 = group["betas"]
-            stream = torch.cuda.current_stream(raw.device).cuda_stream
-            rc = lib.hd_adamw_multi(C.c_void_p(raw.data_ptr()), C.c_void_p(ct.data_ptr()), C.c_void_p(cs.data_ptr()), n_chunks,
-                                    _CHUNK, float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t,
-                                    1.0 - b2 ** t, C.c_void_p(stream))
-            if rc != 0:
-                raise _lib.HdError(f"hd_adamw_multi failed ({rc})")
+            for raw, ct, cs, n_chunks, _, ps in tabs:   # one launch per distinct step count (normally one)
+                t = float(self.state[ps[0]]["step"]) + 1.0
+                for p in ps:
+                    self.state[p]["step"] += 1
+                stream = torch.cuda.current_stream(raw.device).cuda_stream
+                rc = lib.hd_adamw_multi(C.c_void_p(raw.data_ptr()), C.c_void_p(ct.data_ptr()), C.c_void_p(cs.data_ptr()), n_chunks,
+                                        _CHUNK, float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t,
+                                        1.0 - b2 ** t, C.c_void_p(stream))
+                if rc != 0:
+                    raise _lib.HdError(f"hd_adamw_multi failed ({rc})")
         return loss
 
 

@@ -158,6 +158,9 @@ def train(cfg: Dict[str, Any], work_dir: str, device: Optional[str] = None, resu
         g = torch.Generator().manual_seed(int(t["seed"]) * 1000003 + epoch)  # same permutation on every rank
         perm = torch.randperm(len(ds), generator=g).tolist()
         mine = [perm[k * world + rank] for k in range(steps_per_epoch * batch)]  # rank r takes every world-th image
+        if epoch == step0 // steps_per_epoch and step0 % steps_per_epoch:
+            # resumed in the middle of this epoch (a checkpoint written at max_steps): its first batches were already trained on
+            mine = mine[(step0 % steps_per_epoch) * batch:]
         model.train()
         for b in iter_batches(ds, mine, batch, ds.max_boxes, drop_last=True):
             if step >= total:

@@ -58,10 +58,17 @@ class Trainer:
                  use_graph: bool = False, graph_warmup: int = 3, graph_sync: Optional[bool] = None,
                  lowp_weights: bool = True, augment=None, graph_split: bool = True, hd_optimizer: bool = True):
         self.model = model
-        # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head
-        # of every step (e.g. augment.Mosaic).  It is part of the captured region in hipGraph mode, so it must
-        # draw its random numbers on the device with the default generator (graph-safe Philox offsets).
+        # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head of every step
+        # (e.g. augment.Mosaic).  A TWO-PHASE augment (has `draw(B, S, device) -> tensors` and `apply(images, gt_boxes,
+        # gt_cls, m_valid, *tensors)`) has its random draws made eagerly before each step into static tensors and only
+        # `apply` inside the step, which is what a hipGraph-replayed step needs (rng.py: a captured region must not draw
+        # random numbers — split replay never refreshes the captured generator state).  A plain callable runs whole inside
+        # the region and must be deterministic there.
         self.augment = augment
+        self._aug_two_phase = augment is not None and hasattr(augment, "draw") and hasattr(augment, "apply")
+        self._aug_params = None
+        from .rng import StepRandom
+        self.rand = StepRandom(device or next(model.parameters()).device)
         self.device = device or next(model.parameters()).device
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
@@ -80,6 +87,9 @@ class Trainer:
         # under hipGraph replay.  graph_split=False (or one rank) replays one graph and launches the collectives
         # behind it (`defer`).
         # graph_split="force": split replay even on one rank (no collectives then; tests compare it with the one-graph replay)
+        import os
+        if os.environ.get("HD_GRAPH_SPLIT") == "0" and graph_split != "force":
+            graph_split = False
         self.graph_split = bool(graph_split) and self.use_graph and (world > 1 or graph_split == "force")
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes,
                                    defer_collectives=self.use_graph and not self.graph_split,
@@ -90,6 +100,11 @@ class Trainer:
         # device that wait was observed to return seconds late on alternate replays (DESIGN.md section 9,
         # tools/graph_event_probe.py).  RCCL has no host-side wait on this path (its stream waits on an event
         # device-side), so the default is off for it.
+        # HD_GRAPH_SYNC=1 forces the drained form on any backend, HD_GRAPH_SPLIT=0 (read above) the one-graph replay with
+        # the collectives behind it: the two conservative forms, one environment variable away if a node misbehaves.
+        import os
+        if graph_sync is None and os.environ.get("HD_GRAPH_SYNC") in ("0", "1"):
+            graph_sync = os.environ["HD_GRAPH_SYNC"] == "1"
         if graph_sync is None:
             graph_sync = self.reducer.world > 1 and tdist.get_backend(self.reducer.group) != "nccl"
         self.graph_sync = bool(graph_sync)
@@ -117,6 +132,11 @@ class Trainer:
         self._graph_warmup = graph_warmup
         self.graph_error = None
         self.graph_nodes = self.graph_memsets_replaced = 0
+        # overlapped split replay is self-checking (see _verify_overlap); HD_GRAPH_VERIFY_OVERLAP=0 skips the two extra steps
+        import os
+        self.verify_overlap = os.environ.get("HD_GRAPH_VERIFY_OVERLAP", "1") != "0"
+        self.graph_overlap_check = None
+        self.graph_overlap_error = None
 
     def _fwd_bwd(self, images, gt_boxes, gt_cls, m_valid):
         self.reducer.prepare()
@@ -126,7 +146,10 @@ class Trainer:
         use_amp = self.amp_dtype is not None and self.device.type == "cuda"
         if self.augment is not None:
             with torch.no_grad():
-                images, gt_boxes, gt_cls, m_valid = self.augment(images, gt_boxes, gt_cls, m_valid)
+                if self._aug_two_phase:
+                    images, gt_boxes, gt_cls, m_valid = self.augment.apply(images, gt_boxes, gt_cls, m_valid, *self._aug_params)
+                else:
+                    images, gt_boxes, gt_cls, m_valid = self.augment(images, gt_boxes, gt_cls, m_valid)
         if self.shadows is not None:
             if not getattr(self.opt, "writes_shadows", False):
                 self.shadows.refresh()
@@ -136,7 +159,7 @@ class Trainer:
                 self._shadows_dirty = False
         LowpWeights.on = self.shadows is not None
         try:
-            with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
+            with self.rand, torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
                 loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
             loss.backward()
             # buckets autograd left incomplete (parameters without a gradient this step) are packed here, inside
@@ -200,6 +223,51 @@ class Trainer:
                     stream.synchronize()
                 red.bucket_replayed(seg.marker_of[k])
 
+    @torch.no_grad()
+    def _draw_randoms(self, images) -> None:
+        """Everything random in the coming step, drawn eagerly into static tensors (rng.py): the two-phase augment's
+        parameters and every StepRandom field a module asked for.  Same calls in eager, one-graph and split-graph mode."""
+        if self._aug_two_phase:
+            drawn = self.augment.draw(images.shape[0], images.shape[2], images.device)
+            if self._aug_params is None:
+                self._aug_params = [t.clone() for t in drawn]
+            else:
+                for dst, src in zip(self._aug_params, drawn):
+                    dst.copy_(src)
+        self.rand.refresh()
+
+    def _verify_overlap(self) -> None:
+        """Multi-rank split replay launches bucket k's all-reduce without draining the stream (graph_sync off).  Before the
+        first real replayed step this runs the captured step twice on the static batch, once DRAINED and once OVERLAPPED,
+        with no optimizer step in between, and compares the reduced gradient buckets: equal up to float-atomic summation
+        order if every collective consumed the finished bucket.  On a mismatch (any rank) the trainer falls back to the
+        drained form for the rest of the run and says so in `graph_overlap_error`.  Cost: two extra steps, once."""
+        import torch.distributed as tdist
+        red = self.reducer
+
+        def run(sync: bool):
+            keep, self.graph_sync = self.graph_sync, sync
+            try:
+                self._replay_split()
+            finally:
+                self.graph_sync = keep
+            red.finish()
+            torch.cuda.synchronize(self.device)
+            return [b.flat.clone() for b in red.buckets]
+
+        ref = run(True)
+        got = run(False)
+        num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(got, ref))
+        den = sum(float((b.double() ** 2).sum()) for b in ref)
+        err = (num / den) ** 0.5 if den > 0 else (0.0 if num == 0 else float("inf"))
+        bad = torch.tensor([err if err == err else float("inf")], dtype=torch.float32, device=self.device)
+        tdist.all_reduce(bad, op=tdist.ReduceOp.MAX, group=red.group)
+        self.graph_overlap_check = float(bad.item())
+        if not (self.graph_overlap_check < 2e-2):
+            self.graph_overlap_error = f"overlapped split replay differs from the drained one (rel. L2 {self.graph_overlap_check:.3g}); " \
+                                       "falling back to graph_sync"
+            self.graph_sync = True
+
     def weights_changed(self) -> None:
         """Tell the trainer that the float32 master weights were modified outside `step()` (a checkpoint was loaded):
         the bf16 shadows are re-cast before the next forward."""
@@ -207,6 +275,7 @@ class Trainer:
 
     def step(self, images, gt_boxes, gt_cls, m_valid):
         batch = (images, gt_boxes, gt_cls, m_valid)
+        self._draw_randoms(images)
         if self._shadows_dirty:
             if self.shadows is not None:
                 self.shadows.refresh()  # an ordinary launch ahead of the captured region / the replay
@@ -231,6 +300,8 @@ class Trainer:
                 self.reducer.defer = False
                 self._graph = self._static = self._static_out = self._segments = None
                 torch.cuda.synchronize(self.device)
+            elif self._segments is not None and self.reducer.world > 1 and not self.graph_sync and self.verify_overlap:
+                self._verify_overlap()
         if self._graph is not None:
             for dst, src in zip(self._static, batch):
                 dst.copy_(src, non_blocking=True)

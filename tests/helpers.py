@@ -57,3 +57,24 @@ def max_rel_elem(a, b, floor=1e-6):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float((np.abs(a - b) / (np.abs(b) + floor)).max()) if a.size else 0.0
+
+
+def elem_excess(a, b, rtol):
+    """Element-wise parity bound (north_star: "within 1e-4 rel for IoU/RoIAlign floats"): the largest value of
+    |a - b| / (rtol * |b| + floor) over all elements, with floor = rtol * median(|b| over the non-zero elements of b) —
+    so every element must match to `rtol` of its OWN magnitude, and an element much smaller than the typical one (a
+    near-cancelling sum) to `rtol` of the typical magnitude.  <= 1 passes.  Unlike rel_err (max-norm), a small bin that is
+    10 % wrong fails here."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nz = np.abs(b[b != 0])
+    floor = rtol * (float(np.median(nz)) if nz.size else 1.0)
+    return float((np.abs(a - b) / (rtol * np.abs(b) + floor)).max())
+
+
+def assert_elem_close(a, b, rtol, what=""):
+    ex = elem_excess(a, b, rtol)
+    assert ex <= 1.0, f"{what}: element-wise bound |a-b| <= {rtol}*|b| + {rtol}*median|b| exceeded by a factor {ex:.3g}"

@@ -114,3 +114,90 @@ def test_two_rank_split_graph_replay_matches_eager(gpu, tmp_path):
     assert all(abs(x - y) < 1e-3 * max(abs(y), 1.0) for x, y in zip(g0["losses"], e0["losses"]))
     # no multi-second stall on any replayed step (second hazard)
     assert max(g0["times"][3:]) < 2.0 and max(g1["times"][3:]) < 2.0, (g0["times"], g1["times"])
+
+
+def _worker_overlap(rank, world, port, tmp, use_graph):
+    """bf16 autocast + weight shadows + HdAdamW, graph_sync forced OFF (the RCCL default) on the gloo rehearsal backend:
+    the un-drained split replay — segment k, bucket k's all-reduce launched without a stream drain, segment k + 1 — is
+    what executes.  Steps 0-1 run at lr = 0 (nothing moves, the optimizer moments fill); step 2 is captured (graph run)
+    or eager (reference run) and is the ONE optimizer step with lr > 0, so no loss kink can be crossed between the runs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from heltondetection_amd import synthetic as syn
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.dist import init_distributed
+    from heltondetection_amd.optim import HdAdamW
+    from heltondetection_amd.train import Trainer
+    init_distributed("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = False
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=128)).to(dev)
+    model = model.to(memory_format=torch.channels_last).train()
+    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=40, warmup_steps=0, bucket_bytes=2 << 20, device=dev,
+                 use_graph=use_graph, graph_warmup=2, graph_sync=False)
+    assert isinstance(tr.opt, HdAdamW) and tr.shadows is not None and len(tr.reducer.buckets) >= 3
+
+    class _NoSched:   # the learning rate is set by hand below
+        def step(self):
+            pass
+    tr.sched = _NoSched()
+    g = syn.make_generator(200 + rank)   # each rank its own shard
+    img = syn.make_images(4, 128, g).to(dev).contiguous(memory_format=torch.channels_last)
+    gtb, gtc, mv = syn.make_targets(4, 128, g, "coco", 8, 8)
+    batch = (img, gtb.to(dev), gtc.to(dev), mv.to(dev))
+    times = []
+    for i in range(3):
+        for grp in tr.opt.param_groups:
+            grp["lr"] = 0.0 if i < 2 else 1e-3
+        if i == 2:
+            before = [p.detach().float().cpu().clone() for p in model.parameters()]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, _ = tr.step(*batch)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    info = {"graph": tr._graph is not None, "segments": None if tr._segments is None else len(tr._segments),
+            "graph_error": tr.graph_error, "graph_sync": tr.graph_sync, "overlap_check": tr.graph_overlap_check,
+            "overlap_error": tr.graph_overlap_error, "loss": float(loss), "times": times, "before": before,
+            "params": [p.detach().float().cpu() for p in model.parameters()],
+            "shadows": [s_.detach().float().cpu() for s_ in tr.shadows.shadows],
+            "grads": [p.grad.detach().float().cpu().clone() for p in model.parameters()]}
+    torch.save(info, os.path.join(tmp, f"o{'g' if use_graph else 'e'}{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path):
+    """VERDICT r02 #2a: the overlapped (graph_sync = False) multi-rank branch executes with a collective, under bf16
+    autocast + bf16 weight shadows + HdAdamW, with lr > 0 for exactly one graph-replayed optimizer step."""
+    world = 2
+    for use_graph in (True, False):
+        mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
+    g0, g1 = torch.load(tmp_path / "og0.pt"), torch.load(tmp_path / "og1.pt")
+    e0, e1 = torch.load(tmp_path / "oe0.pt"), torch.load(tmp_path / "oe1.pt")
+    assert g0["graph"] and g1["graph"], (g0["graph_error"], g1["graph_error"])
+    assert g0["segments"] >= 3
+    assert g0["graph_sync"] is False and g1["graph_sync"] is False           # the overlapped branch really ran ...
+    assert g0["overlap_error"] is None and g0["overlap_check"] is not None and g0["overlap_check"] < 2e-2, g0["overlap_check"]
+    for a, b in zip(g0["params"], g1["params"]):
+        assert torch.equal(a, b)                                             # ... and left both ranks bit-identical
+    for a, b in zip(g0["shadows"], g1["shadows"]):
+        assert torch.equal(a, b)
+    for a, b in zip(e0["params"], e1["params"]):
+        assert torch.equal(a, b)
+    moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["params"], g0["before"]))
+    assert moved > 0                                                         # lr > 0: the replayed step moved the weights
+    # the averaged gradients of the replayed step against the eager 2-rank step (bf16 convolutions + float atomics)
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["grads"], e0["grads"]))
+    den = sum(float((b ** 2).sum()) for b in e0["grads"])
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    # ... and the parameter UPDATE of that one step (AdamW normalises every gradient to ~ +-lr, so noise-level gradients may
+    # flip sign: a generous bound that a missing or stale bucket (error ~ 1.4) still fails)
+    dn = sum(float((((a - pa) - (b - pb)) ** 2).sum()) for a, pa, b, pb in zip(g0["params"], g0["before"], e0["params"], e0["before"]))
+    dd = sum(float(((b - pb) ** 2).sum()) for b, pb in zip(e0["params"], e0["before"]))
+    assert dd > 0 and (dn / dd) ** 0.5 < 0.3, (dn / dd) ** 0.5
+    assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"])
+    assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing

@@ -231,8 +231,9 @@ def test_graphed_detector_replays_match_eager(gpu):
 
 
 def test_training_step_with_device_mosaic_captures_and_varies(gpu):
-    """augment.Mosaic inside the hipGraph-replayed step: the draws come from the default device generator, so
-    replays see fresh mosaics (the loss sequence on a constant batch is not constant) and stay finite."""
+    """augment.Mosaic around the hipGraph-replayed step: the Trainer draws the mosaic parameters eagerly before every
+    step into static tensors the captured `apply` reads (rng.py), so replays see fresh mosaics (the loss sequence on a
+    constant batch is not constant) and stay finite."""
     from heltondetection_amd.augment import Mosaic
     from heltondetection_amd.detectors import build_detector
     from heltondetection_amd.train import Trainer
@@ -296,3 +297,104 @@ def test_yolov5l_640_bs16_graph_replayed_steps(gpu):
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     finally:
         torch.backends.cudnn.benchmark = was
+
+
+def test_split_graph_replay_draws_fresh_randoms_like_the_one_graph_replay(gpu):
+    """the multi-rank hipGraph mode launches the captured step as raw graph segments, which never
+    refresh a captured generator — random draws inside the region would freeze.  The Trainer therefore draws everything
+    random eagerly before each step (rng.py).  Checked with graph_split="force" (split replay on one rank), lr = 0 so only
+    the randomness moves the loss: consecutive replays differ, and the loss sequence equals the one-graph replay's and the
+    eager run's for the same generator seed (Mosaic p = 1 + DropBlock in the neck)."""
+    from heltondetection_amd.augment import Mosaic
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    batch = _batch(4, 160, 8, 3, gpu, m_pad=8)
+    seqs = {}
+    for mode in ("eager", "graph", "split"):
+        torch.manual_seed(0)
+        model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=160,
+                                    neck=dict(type="YOLOv5PAFPN", depth=0.33, drop_block=dict(p=0.2, block_size=3))))
+        model = model.to(gpu).to(memory_format=torch.channels_last).train()
+        gen = torch.Generator(device=gpu).manual_seed(77)
+        tr = Trainer(model, lr=0.0, total_steps=40, warmup_steps=1, device=gpu, use_graph=mode != "eager", graph_warmup=2,
+                     augment=Mosaic(p=1.0, max_boxes=16, generator=gen), graph_split="force" if mode == "split" else False)
+        tr.rand.generator = gen
+        seqs[mode] = [float(tr.step(*batch)[0]) for _ in range(10)]
+        if mode == "split":
+            assert tr._segments is not None and len(tr._segments) >= 1, tr.graph_error
+        elif mode == "graph":
+            assert tr._graph is not None and tr._segments is None, tr.graph_error
+        assert len(tr.rand) >= 1   # DropBlock took its field from the step's pool
+    assert np.isfinite(seqs["split"]).all()
+    assert len(set(round(v, 5) for v in seqs["split"][3:])) > 3            # replays are not frozen
+    for a, b, c in zip(seqs["eager"], seqs["graph"], seqs["split"]):        # same draws in all three modes
+        assert abs(a - b) < 2e-2 * abs(a) and abs(a - c) < 2e-2 * abs(a), seqs
+
+
+def test_config5_faster_rcnn_pafpn_1280_visdrone_graph_steps(gpu):
+    """BASELINE config 5 (README.md:105): FasterRCNN-R50-PAFPN at 1280x1280 with VisDrone-style ground truth (400-600
+    small boxes per image), bs 2, hipGraph-replayed train steps: captured, finite, every parameter reached."""
+    from heltondetection_amd import synthetic as syn
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    torch.manual_seed(0)
+    was = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False   # no solver search for ResNet50 at 1280^2 inside a test
+    try:
+        model = build_detector(dict(type="FasterRCNN", num_classes=10)).to(gpu).to(memory_format=torch.channels_last).train()
+        g = syn.make_generator(55)
+        img = syn.make_images(2, 1280, g).to(gpu).contiguous(memory_format=torch.channels_last)
+        gtb, gtc, mv = syn.make_targets(2, 1280, g, "visdrone", 10, 600)
+        assert int(mv.min()) >= 400
+        batch = (img, gtb.to(gpu), gtc.to(gpu), mv.to(gpu))
+        tr = Trainer(model, lr=2e-4, total_steps=20, warmup_steps=2, device=gpu, use_graph=True, graph_warmup=2)
+        losses, parts = [], None
+        for _ in range(6):
+            loss, parts = tr.step(*batch)
+            losses.append(float(loss))
+        assert tr._graph is not None, tr.graph_error
+        assert np.isfinite(losses).all() and torch.isfinite(parts).all(), losses
+        assert losses[-1] < 1.5 * losses[0]
+        n_with_grad = sum(1 for p in model.parameters() if p.grad is not None and torch.isfinite(p.grad).all())
+        assert n_with_grad == sum(1 for p in model.parameters() if p.requires_grad)
+        # the detector's own anchor set at this resolution is config 5's: 5 levels x 3 anchors over 1280^2
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            feats = model.extract(img)
+        anchors, level_sizes = model.rpn_head.anchors_for(feats)
+        assert anchors.shape[0] == 409200 and sum(level_sizes) == 409200
+    finally:
+        torch.backends.cudnn.benchmark = was
+
+
+def test_config5_assignment_and_proposals_at_1280_anchor_count_vs_oracle(gpu):
+    """The RPN stage of config 5 on ONE image at full size against the oracle: hd_iou_assign over the 409 200 anchors of a
+    1280^2 pyramid x 500 VisDrone-style boxes (max / argmax / per-gt argmax bit-exact) and hd_rpn_proposals over the same
+    anchors (kept anchor indices bit-exact)."""
+    import math
+    from heltondetection_amd import ops, synthetic as syn
+    from oracle import c_oracle as co
+    size, strides = 1280, [4, 8, 16, 32, 64]
+    hw = [(math.ceil(size / s), math.ceil(size / s)) for s in strides]
+    base = np.stack([co.anchor_base([8.0 * s], [0.5, 1.0, 2.0]) for s in strides])
+    anchors = co.anchor_grid([h for h, _ in hw], [w for _, w in hw], strides, base, 0.5)
+    level_sizes = [h * w * 3 for h, w in hw]
+    NA = anchors.shape[0]
+    assert NA == 409200
+    g = syn.make_generator(57)
+    gtb, _, mv = syn.make_targets(1, size, g, "visdrone", 10, 600)
+    M = int(mv[0])
+    a = torch.from_numpy(anchors)[None]
+    mx, am, gmx, gam = ops.iou_assign(a.to(gpu), gtb.to(gpu), mv.to(gpu))
+    r_mx, r_am, r_gmx, r_gam = co.iou_assign(a.numpy(), gtb.numpy(), mv.numpy())
+    assert 400 <= M <= 600 and float(r_mx.max()) > 0.3
+    assert np.array_equal(mx.cpu().numpy(), r_mx) and np.array_equal(am.cpu().numpy(), r_am)
+    assert np.array_equal(gmx.cpu().numpy(), r_gmx) and np.array_equal(gam.cpu().numpy(), r_gam)
+    logits = torch.randn((1, NA), generator=g)
+    deltas = torch.randn((1, NA, 4), generator=g) * 0.2
+    rois, sc, cnt, idx = ops.rpn_proposals(logits.to(gpu), deltas.to(gpu), torch.from_numpy(anchors).to(gpu), level_sizes,
+                                           2000, 1000, 0.7, 2.0, float(size), float(size), return_index=True)
+    r_rois, r_sc, r_cnt, r_idx = co.rpn_proposals(logits.numpy(), deltas.numpy(), anchors, level_sizes, 2000, 1000, 0.7, 2.0,
+                                                  float(size), float(size), return_index=True)
+    assert np.array_equal(cnt.cpu().numpy(), r_cnt) and int(r_cnt[0]) == 1000
+    assert np.array_equal(idx.cpu().numpy(), r_idx)
+    assert np.abs(rois.cpu().numpy() - r_rois).max() < 1e-4 * size + 1e-3

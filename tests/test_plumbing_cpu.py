@@ -120,3 +120,19 @@ def test_frozen_backbone_and_drop_block_configs():
     s = model_summary(model, lambda: model.extract(x))
     assert s["params_M"] > 1.0 and s["gflops"] > 0.01
     assert count_params(model, trainable_only=True) < count_params(model)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`bench.py --gpus N` must never print a line for a different number of ranks.  With a launcher
+    in the environment that disagrees it exits non-zero with the launch line; with no launcher and too few devices it
+    exits non-zero too (on a multi-GPU node it starts the N ranks itself) — all before the first GPU call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "--nproc-per-node 2" in r.stderr and r.stdout.strip() == ""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 8" in r.stderr
