@@ -181,23 +181,29 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     assert g0["graph"] and g1["graph"], (g0["graph_error"], g1["graph_error"])
     assert g0["segments"] >= 3
     assert g0["graph_sync"] is False and g1["graph_sync"] is False           # the overlapped branch really ran ...
-    assert g0["overlap_error"] is None and g0["overlap_check"] is not None and g0["overlap_check"] < 2e-2, g0["overlap_check"]
+    # the overlapped replay checks itself at capture (Trainer._verify_overlap): every bucket's overlapped all-reduce equals
+    # the drained all-reduce of a stream-ordered copy of the same packed gradients — exact up to float32 summation order,
+    # so a collective that ran ahead of its segment (stale or half-written bucket) cannot pass
+    assert g0["overlap_error"] is None and g1["overlap_error"] is None, (g0["overlap_error"], g1["overlap_error"])
+    assert g0["overlap_check"] is not None and g0["overlap_check"] < 1e-5, g0["overlap_check"]
     for a, b in zip(g0["params"], g1["params"]):
         assert torch.equal(a, b)                                             # ... and left both ranks bit-identical
     for a, b in zip(g0["shadows"], g1["shadows"]):
         assert torch.equal(a, b)
+    for a, b in zip(g0["grads"], g1["grads"]):
+        assert torch.equal(a, b)
     for a, b in zip(e0["params"], e1["params"]):
         assert torch.equal(a, b)
+    assert all(bool(torch.isfinite(a).all()) for a in g0["params"])
     moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["params"], g0["before"]))
     assert moved > 0                                                         # lr > 0: the replayed step moved the weights
-    # the averaged gradients of the replayed step against the eager 2-rank step (bf16 convolutions + float atomics)
+    # Against the eager 2-rank step only the forward is comparable sharply: at FIXED weights and data the bf16 step's
+    # gradients differ by 0.15-0.5 (relative L2) between two runs of the same program, eager or replayed, hand-written
+    # kernels on or off (tools/determinism_probe.py, profiles/r03_determinism.log, DESIGN.md section 9: bf16 storage of
+    # gradients with a large common-mode part that BatchNorm's backward cancels).  So: same loss to bf16 accuracy, and the
+    # averaged gradients no further from the eager run than two eager runs are from each other (a missing bucket is >= 1).
+    assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"]), (g0["loss"], e0["loss"])
     num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["grads"], e0["grads"]))
     den = sum(float((b ** 2).sum()) for b in e0["grads"])
-    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
-    # ... and the parameter UPDATE of that one step (AdamW normalises every gradient to ~ +-lr, so noise-level gradients may
-    # flip sign: a generous bound that a missing or stale bucket (error ~ 1.4) still fails)
-    dn = sum(float((((a - pa) - (b - pb)) ** 2).sum()) for a, pa, b, pb in zip(g0["params"], g0["before"], e0["params"], e0["before"]))
-    dd = sum(float(((b - pb) ** 2).sum()) for b, pb in zip(e0["params"], e0["before"]))
-    assert dd > 0 and (dn / dd) ** 0.5 < 0.3, (dn / dd) ** 0.5
-    assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"])
+    assert den > 0 and (num / den) ** 0.5 < 0.75, (num / den) ** 0.5
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing
