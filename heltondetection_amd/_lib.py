@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -37,6 +37,18 @@ class RoiLevels(C.Structure):
 class Rows2(C.Structure):
     """hd_rows2: optional second place of a [R, C] operand of the fused BN kernels."""
     _fields_ = [("p2", C.c_void_p), ("ld2", C.c_int64), ("split", C.c_int)]
+
+
+class BnBwd(C.Structure):
+    """hd_bn_bwd: the fused BatchNorm + activation backward folded into a convolution gradient call."""
+    _fields_ = [("y", C.c_void_p), ("y_row_stride", C.c_int64), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dsums", C.c_void_p), ("rows", C.c_int64), ("act", C.c_int),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class WgradJob(C.Structure):
+    """hd_wgrad_job: row-sliced partial products of a weight gradient waiting for their summation."""
+    _fields_ = [("slab", C.c_void_p), ("slices", C.c_int), ("count", C.c_int64), ("dw", C.c_void_p)]
 
 
 class YoloLevels(C.Structure):
@@ -113,6 +125,9 @@ SIGNATURES = {
     "hd_pointwise_wgrad_supported": (_I, [_L, _I, _I]),
     "hd_pointwise_wgrad_workspace_bytes": (_Z, [_L, _I, _I]),
     "hd_pointwise_wgrad": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _Z, _P]),
+    "hd_wgrad_reduce": (_I, [_P, _P]),
+    "hd_pointwise_conv_dgrad_bn": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "hd_pointwise_wgrad_partial": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _P, _P, _Z, _P, _P, _P]),
     "hd_upsample2x_cat_fwd": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_upsample2x_cat_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_conv3x3_fwd_supported": (_I, [_I, _I, _I, _I, _I]),

@@ -24,6 +24,7 @@
 // XCD and hit in its L2.
 #include <hip/hip_bf16.h>
 
+#include "hd_bn_fuse.h"
 #include "hd_common.h"
 
 namespace {
@@ -238,14 +239,19 @@ struct StreamLds {
   static constexpr int TOTAL = SLAB_BYTES + 4 * WAVE_BYTES;
 };
 
-template <int K, int TN, int TM, bool STATS, bool TRB>
+// BNB: the A operand is dy of a fused BatchNorm + activation, formed on the fly from d(out) (= A, possibly in two places)
+// and the BatchNorm's input y (hd_bn_fuse.h): each 16-byte chunk is transformed between its global load and its LDS
+// store, with the 8 channels' coefficients in registers (a lane's chunk index is fixed: K / 8 divides 64).
+template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false>
 __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
                                                                const unsigned short* __restrict__ Bw,
                                                                unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
-                                                               float* __restrict__ stats) {
+                                                               float* __restrict__ stats, const hdfuse::BnBwd bn) {
   using L = StreamLds<K, TN, TM, TRB>;
   constexpr int BN = TN * 32, KS = K / 16, CPR = K / 8;
   constexpr int NLD = TM * KS;  // 16-byte loads per lane per row block: 32 TM rows x CPR chunks over 64 lanes
+  static_assert(64 % CPR == 0, "a lane's chunk index must not depend on the load index");
+  __shared__ float s_bn[BNB ? 4 * K : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [slab | 4 wave areas]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fh = lane >> 5;
@@ -257,17 +263,23 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   const int my = gw < RT ? (RT - 1 - gw) / GW + 1 : 0;
 
   // coalesced: instruction p of a lane takes chunk (p * 64 + lane) of the row block, i.e. 64 / CPR whole rows at a time
-  u32x4 nxt[NLD];
+  u32x4 nxt[NLD], nyy[BNB ? NLD : 1];
+  hdfuse::Place pa;
+  pa.base = A + (lane % CPR) * 8;
+  pa.ld = lda;
+  if (BNB) pa.set(A, lda, bn, (lane % CPR) * 8);
   auto load_rows = [&](int rt) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int id = p * 64 + lane;
       int m = rt * (32 * TM) + id / CPR;
       m = m < M ? m : M - 1;  // rows past the end re-read the last row; their results are never stored
-      nxt[p] = *reinterpret_cast<const u32x4*>(A + (long long)m * lda + (id % CPR) * 8);
+      nxt[p] = *reinterpret_cast<const u32x4*>(pa.base + (long long)m * pa.ld);
+      if (BNB) nyy[p] = *reinterpret_cast<const u32x4*>(bn.y + (long long)m * bn.ld_y + (id % CPR) * 8);
     }
   };
   if (my > 0) load_rows(gw);  // in flight while the weight slab is staged
+  if (BNB) hdfuse::fill_coefs(bn, 0, K, s_bn, false);
   if (TRB) {
     for (int id = tid; id < K * (BN / 8); id += 256) {
       const int row = id / (BN / 8), c = id % (BN / 8);
@@ -287,13 +299,15 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   float s_sum[TN], s_sq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s_sum[j] = s_sq[j] = 0.0f;
+  hdfuse::Coef8 cf;
+  if (BNB) cf.load(s_bn, K, (lane % CPR) * 8);  // behind the barrier above
 
   for (int it = 0; it < my; ++it) {
     const int rt = gw + it * GW;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int id = p * 64 + lane;
-      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = nxt[p];
+      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = BNB ? hdfuse::chunk(nxt[p], nyy[p], cf, bn.act) : nxt[p];
     }
     if (it + 1 < my) load_rows(rt + GW);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before its lanes read each other's
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
 
 template <int K, int TN, int TM, bool TRB>
 hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats,
-                        hipStream_t s) {
+                        hipStream_t s, const hdfuse::BnBwd* bn = nullptr) {
   constexpr int BN = TN * 32;
   const int NT = N / BN;
   const long long RT = ((long long)M + 32 * TM - 1) / (32 * TM);
@@ -382,12 +396,19 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   const auto* a = static_cast<const unsigned short*>(A);
   const auto* b = static_cast<const unsigned short*>(Bw);
   auto* c = static_cast<unsigned short*>(Cmat);
-  if (stats && !TRB)
+  const hdfuse::BnBwd none = {};
+  if (bn) {
+    if constexpr (TRB)
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c,
+                      ldc, M, N, (float*)nullptr, *bn);
+    else
+      return HD_ERR_SHAPE;
+  } else if (stats && !TRB)
     (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, stats);
+                    N, stats, none);
   else
     (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, (float*)nullptr);
+                    N, (float*)nullptr, none);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -395,21 +416,21 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
 // -> true when the streaming form took the call
 template <int K, bool TRB = false>
 bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
-                hd_status* st) {
+                hd_status* st, const hdfuse::BnBwd* bnb = nullptr) {
   constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
   const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > 8) return false;
   if (bn == 128) {
-    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s); return true; }
+    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb); return true; }
     return false;
   }
   if (bn == 64) {
-    if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
-    else *st = launch_stream<K, 2, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+    if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
+    else *st = launch_stream<K, 2, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
     return true;
   }
-  if constexpr (K <= 64) *st = launch_stream<K, 1, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
-  else *st = launch_stream<K, 1, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s);
+  if constexpr (K <= 64) *st = launch_stream<K, 1, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
+  else *st = launch_stream<K, 1, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
   return true;
 }
 
@@ -458,15 +479,28 @@ hd_status launch_bk(const void* A, int64_t lda, const void* Bw, void* Cmat, int6
 // are in flight while the current one is multiplied.  Partial tiles go to a float32 slab [S][Cout][Cin] with plain
 // stores (no zero-fill, no atomics) and wgrad_reduce_kernel sums the S slabs into the bf16 gradient — two launches where
 // the library's split-K path takes a zero-fill, the convolution and a cast.
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+// BNB: dY is formed on the fly from d(out) and the BatchNorm input y (hd_bn_fuse.h) while the tile is staged; the
+// workgroups of the first row slice and first k-tile also publish dgamma / dbeta of their channels.
+// Workgroups with blockIdx.y >= n_splits do not multiply at all: they sum the row-sliced partials of the PREVIOUS weight
+// gradient launch (`job`), which rides along instead of costing a launch of its own (5.9 us each, 45 per YOLOv5s step).
+template <int TM, int TN, bool BNB>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                               const unsigned short* __restrict__ X, long long ld_x, int M, int N,
-                                                              int K, int rows_per_split, float* __restrict__ slab) {
+                                                              int K, int rows_per_split, float* __restrict__ slab, int n_splits,
+                                                              const hdfuse::BnBwd bn, const hdfuse::ReduceJob job) {
   constexpr int BNT = 64 * TM, BKT = 64 * TN, ROWS = 64;
   constexpr int SN = BNT * 2 + 64, SK = BKT * 2 + 64;  // padded row strides (bytes)
   constexpr int CN = BNT / 8, CK = BKT / 8;             // 16-byte chunks per row
   constexpr int IT_N = ROWS * CN / 256, IT_K = ROWS * CK / 256;
+  static_assert(256 % CN == 0, "a thread's chunk index must not depend on the load index");
+  __shared__ float4 s_part[16][17];
+  __shared__ float s_bn[BNB ? 4 * BNT : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [64 rows of dY tile | 64 rows of X tile]
+  if ((int)blockIdx.y >= n_splits) {  // the reduction of the previous launch's partials
+    const long long blk = (long long)(blockIdx.y - n_splits) * gridDim.x + blockIdx.x;
+    if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
+    return;
+  }
   unsigned char* tY = smem;
   unsigned char* tX = smem + ROWS * SN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -478,15 +512,27 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned sho
   const int m_end = min(M, m_begin + rows_per_split);
   const int steps = m_end > m_begin ? (m_end - m_begin + ROWS - 1) / ROWS : 0;
 
-  u32x4 ry[2][IT_N], rx[2][IT_K];
-  auto issue = [&](int t, u32x4* py, u32x4* px) {
+  hdfuse::Place pa;
+  pa.base = dY + n0 + (tid % CN) * 8;
+  pa.ld = ld_dy;
+  hdfuse::Coef8 cf;
+  if (BNB) {
+    pa.set(dY, ld_dy, bn, n0 + (tid % CN) * 8);
+    hdfuse::fill_coefs(bn, n0, BNT, s_bn, split == 0 && blockIdx.x % tiles_k == 0);
+    __syncthreads();
+    cf.load(s_bn, BNT, (tid % CN) * 8);
+  }
+
+  u32x4 ry[2][IT_N], rx[2][IT_K], rz[BNB ? 2 : 1][BNB ? IT_N : 1];
+  auto issue = [&](int t, u32x4* py, u32x4* px, u32x4* pz) {
     const int mb = m_begin + t * ROWS;
 #pragma unroll
     for (int i = 0; i < IT_N; ++i) {
       const int id = i * 256 + tid;
       int m = mb + id / CN;
       m = m < M ? m : M - 1;
-      py[i] = *reinterpret_cast<const u32x4*>(dY + (long long)m * ld_dy + n0 + (id % CN) * 8);
+      py[i] = *reinterpret_cast<const u32x4*>(pa.base + (long long)m * pa.ld);
+      if (BNB) pz[i] = *reinterpret_cast<const u32x4*>(bn.y + (long long)m * bn.ld_y + n0 + (id % CN) * 8);
     }
 #pragma unroll
     for (int i = 0; i < IT_K; ++i) {
@@ -496,13 +542,14 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned sho
       px[i] = *reinterpret_cast<const u32x4*>(X + (long long)m * ld_x + k0 + (id % CK) * 8);
     }
   };
-  auto stash = [&](int t, const u32x4* py, const u32x4* px) {  // rows past the slice end count as zero
+  auto stash = [&](int t, const u32x4* py, const u32x4* px, const u32x4* pz) {  // rows past the slice end count as zero
     const int mb = m_begin + t * ROWS;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < IT_N; ++i) {
       const int id = i * 256 + tid, row = id / CN;
-      *reinterpret_cast<u32x4*>(tY + row * SN + (id % CN) * 16) = (mb + row < m_end) ? py[i] : zero;
+      const u32x4 v = BNB ? hdfuse::chunk(py[i], pz[i], cf, bn.act) : py[i];
+      *reinterpret_cast<u32x4*>(tY + row * SN + (id % CN) * 16) = (mb + row < m_end) ? v : zero;
     }
 #pragma unroll
     for (int i = 0; i < IT_K; ++i) {
@@ -534,17 +581,19 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned sho
     }
   };
 
-  if (steps > 0) issue(0, ry[0], rx[0]);
-  if (steps > 1) issue(1, ry[1], rx[1]);
+  u32x4* const rz0 = rz[0];
+  u32x4* const rz1 = rz[BNB ? 1 : 0];
+  if (steps > 0) issue(0, ry[0], rx[0], rz0);
+  if (steps > 1) issue(1, ry[1], rx[1], rz1);
   for (int t = 0; t < steps; t += 2) {
-    stash(t, ry[0], rx[0]);
-    if (t + 2 < steps) issue(t + 2, ry[0], rx[0]);
+    stash(t, ry[0], rx[0], rz0);
+    if (t + 2 < steps) issue(t + 2, ry[0], rx[0], rz0);
     __syncthreads();
     multiply();
     __syncthreads();
     if (t + 1 < steps) {
-      stash(t + 1, ry[1], rx[1]);
-      if (t + 3 < steps) issue(t + 3, ry[1], rx[1]);
+      stash(t + 1, ry[1], rx[1], rz1);
+      if (t + 3 < steps) issue(t + 3, ry[1], rx[1], rz1);
       __syncthreads();
       multiply();
       __syncthreads();
@@ -564,43 +613,10 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const unsigned sho
     }
 }
 
-// dW[q] (4 consecutive elements) = sum over the S slabs; 16 quads x 16 slab lanes per workgroup
-__global__ __launch_bounds__(256) void pointwise_wgrad_reduce_kernel(const float* __restrict__ slab, int S, long long NK,
-                                                                     unsigned short* __restrict__ dW) {
-  __shared__ float4 part[16][17];
-  const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long quad = (long long)blockIdx.x * 16 + ql;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (quad * 4 < NK) {
-    int s = sl;
-    for (; s + 48 < S; s += 64) {  // four independent loads in flight
-      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)s * NK + quad * 4);
-      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 16) * NK + quad * 4);
-      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 32) * NK + quad * 4);
-      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 48) * NK + quad * 4);
-      a.x += (v0.x + v1.x) + (v2.x + v3.x);
-      a.y += (v0.y + v1.y) + (v2.y + v3.y);
-      a.z += (v0.z + v1.z) + (v2.z + v3.z);
-      a.w += (v0.w + v1.w) + (v2.w + v3.w);
-    }
-    for (; s < S; s += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * NK + quad * 4);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-  }
-  part[sl][ql] = a;
-  __syncthreads();
-  if (sl == 0 && quad * 4 < NK) {
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-      const float4 v = part[i][ql];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    const f32x4 f = {a.x, a.y, a.z, a.w};
-    *reinterpret_cast<bf16x4*>(dW + quad * 4) = __builtin_convertvector(f, bf16x4);
-  }
+// Sum over the row slices on its own launch (the last weight gradient of a backward pass, or a caller that does not chain).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hdfuse::ReduceJob job) {
+  __shared__ float4 s_part[16][17];
+  hdfuse::reduce_block(job, blockIdx.x, s_part);
 }
 
 // ---- 3x3 / stride 1 / pad 1 weight gradient -------------------------------------------------------------------
@@ -1129,42 +1145,122 @@ extern "C" size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cou
   return (size_t)p.splits * Cin * Cout * sizeof(float);
 }
 
-extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R,
-                                        int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
-                                        hd_stream stream) {
-  if (!dy || !x || !dw || !workspace) return HD_ERR_NULL;
+// hd_bn_bwd (+ the second place of d(out)) -> the kernels' by-value view; checks what the kernels assume
+static hd_status make_bn_view(const hd_bn_bwd* bn, const hd_rows2* tail, int C, int64_t R, hdfuse::BnBwd* out) {
+  *out = hdfuse::BnBwd{};
+  if (!bn) return tail && tail->p2 ? HD_ERR_SHAPE : HD_OK;  // two places only exist for a fused-BN operand
+  if (!bn->y || !bn->save_mean || !bn->save_invstd || !bn->gamma || !bn->beta || !bn->dsums) return HD_ERR_NULL;
+  if ((bn->dgamma == nullptr) != (bn->dbeta == nullptr)) return HD_ERR_NULL;
+  if (bn->act < 0 || bn->act > 2 || bn->rows <= 0) return HD_ERR_SHAPE;
+  const int64_t ld_y = bn->y_row_stride == 0 ? C : bn->y_row_stride;
+  if (ld_y < C || ld_y % 8 || !hd_aligned16(bn->y)) return HD_ERR_SHAPE;
+  if (hd_bn_act_replicas() != hdfuse::kRep) return HD_ERR_SHAPE;
+  out->y = static_cast<const unsigned short*>(bn->y);
+  out->ld_y = ld_y;
+  if (tail && tail->p2) {
+    if (tail->split <= 0 || tail->split >= C || tail->split % 8) return HD_ERR_SHAPE;
+    const int64_t ld2 = tail->ld2 == 0 ? (C - tail->split) : tail->ld2;
+    if (ld2 < C - tail->split || ld2 % 8 || !hd_aligned16(tail->p2)) return HD_ERR_SHAPE;
+    out->dout2 = static_cast<const unsigned short*>(tail->p2);
+    out->ld2 = ld2;
+    out->split = tail->split;
+  }
+  out->mean = bn->save_mean;
+  out->invstd = bn->save_invstd;
+  out->gamma = bn->gamma;
+  out->beta = bn->beta;
+  out->dsums = bn->dsums;
+  out->inv_rows = 1.0f / (float)bn->rows;
+  out->act = bn->act;
+  out->C = C;
+  out->dgamma = bn->dgamma;
+  out->dbeta = bn->dbeta;
+  (void)R;
+  return HD_OK;
+}
+
+static hd_status make_job_view(const hd_wgrad_job* j, hdfuse::ReduceJob* out) {
+  *out = hdfuse::ReduceJob{};
+  if (!j) return HD_OK;
+  if (!j->slab || !j->dw) return HD_ERR_NULL;
+  if (j->slices < 1 || j->count < 4 || j->count % 4) return HD_ERR_SHAPE;
+  if (!hd_aligned16(j->slab) || (reinterpret_cast<uintptr_t>(j->dw) & 7u)) return HD_ERR_ALIGN;
+  out->slab = j->slab;
+  out->slices = j->slices;
+  out->count = j->count;
+  out->dw = static_cast<unsigned short*>(j->dw);
+  return HD_OK;
+}
+
+// extra grid rows that hold the reduction blocks of a job riding along (0 without one)
+static unsigned piggyback_rows(const hdfuse::ReduceJob& job, unsigned grid_x) {
+  if (!job.slab) return 0;
+  const long long blocks = hdfuse::reduce_blocks(job.count);
+  return (unsigned)((blocks + grid_x - 1) / grid_x);
+}
+
+extern "C" hd_status hd_wgrad_reduce(const hd_wgrad_job* job, hd_stream stream) {
+  if (!job) return HD_ERR_NULL;
+  hdfuse::ReduceJob j;
+  const hd_status st = make_job_view(job, &j);
+  if (st != HD_OK) return st;
+  (void)hd_launch(wgrad_reduce_kernel, dim3((unsigned)hdfuse::reduce_blocks(j.count)), dim3(256), 0, (hipStream_t)stream, j);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const hd_rows2* dy_tail,
+                                                const hd_bn_bwd* bn, const void* x, int64_t x_row_stride, int64_t R, int Cin,
+                                                int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                                const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream) {
+  if (!dy || !x || !dw || !workspace || !job_out) return HD_ERR_NULL;
   if (!hd_pointwise_wgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
-  if (dy_row_stride == 0) dy_row_stride = Cout;
+  if (dy_row_stride == 0) dy_row_stride = (dy_tail && dy_tail->p2) ? dy_tail->split : Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
-  if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
+  if (dy_row_stride % 8 || x_row_stride < Cin || x_row_stride % 8) return HD_ERR_SHAPE;
+  if (dy_row_stride < ((dy_tail && dy_tail->p2) ? dy_tail->split : Cout)) return HD_ERR_SHAPE;
   if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
   const WgradPlan p = wgrad_plan(R, Cin, Cout);
   if (workspace_bytes < (size_t)p.splits * Cin * Cout * sizeof(float)) return HD_ERR_WORKSPACE;
+  hdfuse::BnBwd bv;
+  hdfuse::ReduceJob jv;
+  hd_status st = make_bn_view(bn, dy_tail, Cout, R, &bv);
+  if (st != HD_OK) return st;
+  if ((st = make_job_view(piggyback, &jv)) != HD_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   const auto* a = static_cast<const unsigned short*>(dy);
   const auto* b = static_cast<const unsigned short*>(x);
   float* slab = static_cast<float*>(workspace);
-  const dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.splits + piggyback_rows(jv, (unsigned)p.tiles));
   const size_t lds = 64u * ((64u * p.tm * 2u + 64u) + (64u * p.tn * 2u + 64u));
   const int M = (int)R;
-  if (p.tm == 2 && p.tn == 2)
-    (void)hd_launch(pointwise_wgrad_kernel<2, 2>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                    p.rows_per_split, slab);
-  else if (p.tm == 2)
-    (void)hd_launch(pointwise_wgrad_kernel<2, 1>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                    p.rows_per_split, slab);
-  else if (p.tn == 2)
-    (void)hd_launch(pointwise_wgrad_kernel<1, 2>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                    p.rows_per_split, slab);
-  else
-    (void)hd_launch(pointwise_wgrad_kernel<1, 1>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                    p.rows_per_split, slab);
+#define HD_WG_LAUNCH(TMM, TNN)                                                                                             \
+  do {                                                                                                                     \
+    if (bn) (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, true>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, \
+                            M, Cout, Cin, p.rows_per_split, slab, p.splits, bv, jv);                                       \
+    else (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, false>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride,  \
+                         M, Cout, Cin, p.rows_per_split, slab, p.splits, bv, jv);                                          \
+  } while (0)
+  if (p.tm == 2 && p.tn == 2) HD_WG_LAUNCH(2, 2);
+  else if (p.tm == 2) HD_WG_LAUNCH(2, 1);
+  else if (p.tn == 2) HD_WG_LAUNCH(1, 2);
+  else HD_WG_LAUNCH(1, 1);
+#undef HD_WG_LAUNCH
   HD_RETURN_IF_LAUNCH_FAILED();
-  const long long NK = (long long)Cin * Cout;
-  (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
-                  p.splits, NK, static_cast<unsigned short*>(dw));
-  HD_RETURN_IF_LAUNCH_FAILED();
+  job_out->slab = slab;
+  job_out->slices = p.splits;
+  job_out->count = (int64_t)Cin * Cout;
+  job_out->dw = dw;
   return HD_OK;
+}
+
+extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R,
+                                        int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                        hd_stream stream) {
+  hd_wgrad_job job;
+  const hd_status st = hd_pointwise_wgrad_partial(dy, dy_row_stride, nullptr, nullptr, x, x_row_stride, R, Cin, Cout, dw,
+                                                  workspace, workspace_bytes, nullptr, &job, stream);
+  return st != HD_OK ? st : hd_wgrad_reduce(&job, stream);
 }
 
 extern "C" int hd_pointwise_conv_resident(int64_t R, int Cin, int Cout) {
@@ -1197,6 +1293,29 @@ extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stri
   if (Cout == 64 && try_stream<64, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   if (Cout == 128 && try_stream<128, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   if (Cout == 256 && try_stream<256, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  return HD_ERR_SHAPE;
+}
+
+extern "C" hd_status hd_pointwise_conv_dgrad_bn(const void* dout, int64_t dout_row_stride, const hd_rows2* dout_tail,
+                                                const hd_bn_bwd* bn, const void* w, int64_t R, int Cin, int Cout, void* dx,
+                                                int64_t dx_row_stride, hd_stream stream) {
+  if (!dout || !w || !dx || !bn) return HD_ERR_NULL;
+  if (!hd_pointwise_conv_dgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;  // the reduction runs over Cout
+  const bool two = dout_tail && dout_tail->p2;
+  if (dout_row_stride == 0) dout_row_stride = two ? dout_tail->split : Cout;
+  if (dx_row_stride == 0) dx_row_stride = Cin;
+  if (dout_row_stride < (two ? dout_tail->split : Cout) || dx_row_stride < Cin || dout_row_stride % 8 || dx_row_stride % 8)
+    return HD_ERR_SHAPE;
+  if (!hd_aligned16(dout) || !hd_aligned16(w) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
+  hdfuse::BnBwd bv;
+  hd_status st = make_bn_view(bn, dout_tail, Cout, R, &bv);
+  if (st != HD_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  const int M = (int)R;
+  if (Cout == 32 && try_stream<32, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
+  if (Cout == 64 && try_stream<64, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
+  if (Cout == 128 && try_stream<128, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
+  if (Cout == 256 && try_stream<256, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
   return HD_ERR_SHAPE;
 }
 
@@ -1248,11 +1367,8 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   }
 #undef HD_WGRAD3_CASE
   HD_RETURN_IF_LAUNCH_FAILED();
-  const long long NK = (long long)Cout * 9 * Cin;
-  (void)hd_launch(pointwise_wgrad_reduce_kernel, dim3((unsigned)((NK / 4 + 15) / 16)), dim3(256), 0, s, (const float*)slab,
-                  p.slices, NK, static_cast<unsigned short*>(dw));
-  HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
+  hd_wgrad_job job = {slab, p.slices, (int64_t)Cout * 9 * Cin, dw};
+  return hd_wgrad_reduce(&job, stream);
 }
 
 extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {

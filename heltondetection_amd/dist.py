@@ -123,6 +123,9 @@ class GradReducer:
         parameters, bf16 from weight shadows — _foreach_copy_ keeps its single-launch path only for
         dtype-homogeneous lists), zero-fills the slots of parameters that received no gradient this step, and
         re-points .grad at the views.  Never launches a collective: that is _flush()'s job, in bucket order."""
+        if b.flat.is_cuda:
+            from . import ops
+            ops.flush_wgrad()   # a chained weight gradient is complete only once its slice sum has been launched
         groups: Dict[torch.dtype, Tuple[list, list]] = {}
         for p, v in zip(b.params, b.views):
             g = self._grad_of(p)

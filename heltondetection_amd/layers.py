@@ -163,6 +163,12 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
         w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
         w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        if FusedBNAct.sync_group is None and ops.bn_act_supported(_like_conv_out(xb, w)):
+            # one autograd node for convolution + BatchNorm + activation: its backward folds the BatchNorm's elementwise
+            # half into the convolution's gradient kernels (ops._PwConvBNActFn); mode 2 also takes the statistics in the
+            # forward kernel's epilogue
+            return ops.pointwise_conv_bn_act(xb, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act,
+                                             FusedBNAct.slot_of(bn, x.device), residual, residual_after_act, out, mode == 2)
         if mode == 2:  # the convolution's epilogue leaves the batch statistics in the BatchNorm's slot: 3 fused-BN launches
             y = ops.pointwise_conv(xb, w, FusedBNAct.slot_of(bn, x.device))
             return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
@@ -179,6 +185,20 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
         return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0], None, ConvBNAct.conv3x3_forward), act, residual,
                                 residual_after_act, out)
     return FusedBNAct.apply(bn, conv(x), act, residual, residual_after_act, out)
+
+
+class _like_conv_out:
+    """Shape / dtype / layout stand-in for the output of a 1x1 convolution of x (what ops.bn_act_supported looks at)."""
+
+    def __init__(self, x, w):
+        self.shape = (x.shape[0], w.shape[0], x.shape[2], x.shape[3])
+        self.dtype, self.is_cuda = x.dtype, x.is_cuda
+
+    def dim(self):
+        return 4
+
+    def is_contiguous(self, memory_format=None):
+        return True
 
 
 def _conv3x3_ours(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:

@@ -12,6 +12,7 @@ CIoU, per-class NMS, WBF.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -951,36 +952,130 @@ def _fwd_sums(slot: "_StatSlot", channels: int) -> torch.Tensor:
     return sums
 
 
-_WGRAD_WS: dict = {}
+class _WgradChain:
+    """Weight gradients are computed as row-sliced float32 partial products (a slab) plus their sum over the slices.  Inside
+    a training step (`enabled`, set by train.Trainer around backward) the sum of layer L does not get a launch of its own:
+    it rides in extra workgroups of the NEXT weight-gradient launch (hd_wgrad_job `piggyback`), and only the last one of a
+    backward pass is launched by itself (`flush`, called by dist.GradReducer before it reads any gradient and by the Trainer
+    after backward).  Outside a step every weight gradient is summed at once, as before.
+
+    Slabs: two per device, used alternately — the pending job's slab must survive until the next launch has consumed it, and
+    that launch writes the other one.  A slab that has to grow is replaced, never released (a captured hipGraph may still
+    point at the old one: ADVICE r02), so the superseded buffers stay referenced for the life of the process."""
+
+    enabled = False
+    _slabs: dict = {}      # device key -> [buf0, buf1]
+    _retired: list = []    # superseded slabs, kept alive
+    _pending: dict = {}    # device key -> (WgradJob, keep-alive tensors)
+    _handed: list = []     # (weakref to the weight leaf, dw.data_ptr()) of the chained gradients since the last flush
+
+    @staticmethod
+    def _key(device):
+        return (device.type, device.index if device.index is not None else torch.cuda.current_device())
+
+    @classmethod
+    def slab(cls, device, nbytes: int) -> torch.Tensor:
+        """A slab of >= nbytes that is NOT the one the pending job's partial products live in."""
+        key = cls._key(device)
+        pair = cls._slabs.setdefault(key, [None, None])
+        pend = cls._pending.get(key)
+        busy = pend[1][0] if pend is not None else None
+        t = 1 if (busy is not None and pair[0] is busy) else 0
+        buf = pair[t]
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                cls._retired.append(buf)
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            pair[t] = buf
+        return buf
+
+    @classmethod
+    def piggyback(cls, device):
+        """The pending job of `device` (to ride in the launch being prepared), or None."""
+        pend = cls._pending.pop(cls._key(device), None)
+        return pend
+
+    @classmethod
+    def submit(cls, device, job, keep, leaf=None) -> None:
+        """`job` (a filled WgradJob) has been launched: chain it, or sum it right away outside a training step."""
+        if cls.enabled:
+            cls._pending[cls._key(device)] = (job, keep)
+            if leaf is not None:
+                import weakref
+                cls._handed.append((weakref.ref(leaf), int(job.dw)))
+        else:
+            check(_lib.load().hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "hd_wgrad_reduce")
+
+    @classmethod
+    def flush(cls) -> None:
+        lib = _lib.load()
+        for key, (job, keep) in list(cls._pending.items()):
+            dev = torch.device(key[0], key[1])
+            check(lib.hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "hd_wgrad_reduce")
+        cls._pending.clear()
+        # a chained gradient is complete only after the launch that carried its sum: autograd must have taken the returned
+        # tensor as it is (AccumulateGrad steals a fresh dense gradient); a copy taken earlier would hold unsummed bytes
+        for ref, ptr in cls._handed:
+            leaf = ref()
+            if leaf is not None and leaf.grad is not None and leaf.grad.data_ptr() != ptr:
+                cls._handed.clear()
+                raise _lib.HdError("a chained weight gradient was copied before its slices were summed (autograd did not take "
+                                   "the tensor as returned); run with ops._WgradChain.enabled = False")
+        cls._handed.clear()
+
+
+def flush_wgrad() -> None:
+    """Sum the partial products of the last weight-gradient launch (no-op when nothing is pending): after this call every
+    weight gradient handed out so far is complete for the current stream."""
+    _WgradChain.flush()
 
 
 def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
-    """One float32 slab per device, grown on demand and shared by every layer (launches on one stream run in order)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    ws = _WGRAD_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WGRAD_WS[key] = ws
-    return ws
+    """One of the device's two float32 slabs (see _WgradChain), at least `nbytes` long."""
+    return _WgradChain.slab(device, nbytes)
 
 
-def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dx[B, Cin, H, W] = dy[B, Cout, H, W] . w2[Cout, Cin] on channels-last rows, no autograd; Cout in {32, 64, 128, 256}."""
+def _bn_bwd_struct(st: "_BNState", y_raw: torch.Tensor, g_: "_BNGrad", dg: Optional[torch.Tensor]):
+    """hd_bn_bwd for the gradient entry points that fold the BatchNorm backward into their operand load."""
+    bn = _lib.BnBwd()
+    bn.y = y_raw.data_ptr()
+    bn.y_row_stride = int(_cl_row_stride(y_raw, 8))
+    bn.save_mean, bn.save_invstd = st.save[0].data_ptr(), st.save[1].data_ptr()
+    bn.gamma, bn.beta = st.w.data_ptr(), st.b.data_ptr()
+    bn.dsums = g_.dsums.data_ptr()
+    bn.rows = int(st.stat_rows) if st.stat_rows else int(st.R)
+    bn.act = int(st.act)
+    bn.dgamma = dg[1].data_ptr() if dg is not None else None
+    bn.dbeta = dg[0].data_ptr() if dg is not None else None
+    return bn
+
+
+def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None, bn=None, dy_tail=None) -> torch.Tensor:
+    """dx[B, Cin, H, W] = dy[B, Cout, H, W] . w2[Cout, Cin] on channels-last rows, no autograd; Cout in {32, 64, 128, 256}.
+    bn / dy_tail: as for pointwise_wgrad_rows (dy is d(out) of a fused BatchNorm + activation, possibly in two places)."""
     lib = _lib.load()
-    B, N, H, W = dy.shape
+    B, _, H, W = dy.shape
+    N = w2.shape[0]
     K = w2.shape[1]
     ld_dy = _cl_row_stride(dy, 8)
-    if ld_dy is None or dy.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or w2.shape[0] != N or not w2.is_contiguous():
+    if ld_dy is None or dy.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or not w2.is_contiguous() \
+            or (dy_tail is None and dy.shape[1] != N):
         raise _lib.HdError("pointwise_dgrad: needs bf16 channels-last rows and the dense bf16 [Cout, Cin] forward weight")
     if out is None:
         out = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     ld_dx = _cl_row_stride(out, 8)
     if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
-    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K), {"flops": 2 * B * H * W * K * N})
+    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K) + (2 * B * H * W * N if bn is not None else 0),
+                {"flops": 2 * B * H * W * K * N})
     with _ktimed("pointwise_dgrad"):
-        check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
-              "hd_pointwise_conv_dgrad")
+        if bn is not None:
+            check(lib.hd_pointwise_conv_dgrad_bn(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
+                                                 C.byref(bn), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
+                  "hd_pointwise_conv_dgrad_bn")
+        else:
+            check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
+                  "hd_pointwise_conv_dgrad")
     return out
 
 
@@ -988,25 +1083,38 @@ def pointwise_wgrad_supported(R: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().hd_pointwise_wgrad_supported(int(R), int(cin), int(cout)))
 
 
-def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dw[Cout, Cin] (bf16) = sum over rows of dy[B, Cout, H, W]^T x[B, Cin, H, W], channels-last rows, no autograd."""
+def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=None, cout: Optional[int] = None,
+                         leaf: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw[Cout, Cin] (bf16) = sum over rows of dy[B, Cout, H, W]^T x[B, Cin, H, W], channels-last rows, no autograd.
+    bn (hd_bn_bwd; dy_tail = the second place of dy, cout = the channels of both places together): dy is d(out) of a fused
+    BatchNorm + activation and the kernel forms the convolution's dy itself (csrc/hd_bn_fuse.h).
+    leaf: the tensor autograd will hand the result to (checked by the chain, see _WgradChain).  Inside a training step the
+    returned tensor is complete only after the next weight-gradient launch or flush_wgrad()."""
     lib = _lib.load()
-    B, N, H, W = dy.shape
-    K = x.shape[1]
+    B, K, H, W = x.shape
+    N = int(cout) if cout is not None else int(dy.shape[1])
     ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
     if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
-            or x.shape[0] != B or x.shape[2:] != dy.shape[2:]):
+            or x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]):
         raise _lib.HdError("pointwise_wgrad: needs bf16 channels-last rows of equal batch and spatial size")
     R = B * H * W
     nbytes = lib.hd_pointwise_wgrad_workspace_bytes(R, K, N)
     if nbytes == 0:
         raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64")
     ws = _wgrad_workspace(dy.device, nbytes)
-    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
-    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K), {"flops": 2 * R * K * N})
+    dw = out if out is not None else torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+    if dw.dtype != torch.bfloat16 or dw.numel() != N * K or not dw.is_contiguous():
+        raise _lib.HdError("pointwise_wgrad: `out` must be a dense bf16 tensor of Cout x Cin elements")
+    pend = _WgradChain.piggyback(dy.device)
+    job = _lib.WgradJob()
+    # fused: d(out) and y are read where dy was
+    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K) + (2 * R * N if bn is not None else 0), {"flops": 2 * R * K * N})
     with _timed("pointwise_wgrad"):
-        check(lib.hd_pointwise_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), R, K, N, _ptr(dw), _ptr(ws), ws.numel(),
-                                     _stream(dy)), "hd_pointwise_wgrad")
+        check(lib.hd_pointwise_wgrad_partial(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
+                                             C.byref(bn) if bn is not None else None, _ptr(x), int(ld_x), R, K, N, _ptr(dw),
+                                             _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
+                                             _stream(dy)), "hd_pointwise_wgrad_partial")
+        _WgradChain.submit(dy.device, job, (ws, dw), leaf)
     return dw
 
 
@@ -1019,7 +1127,7 @@ def conv3x3_wgrad_supported(x: torch.Tensor, cout: int, stride: int = 1) -> bool
     return bool(_lib.load().hd_conv3x3_wgrad_supported(B, H // stride, W // stride, K, int(cout), int(stride)))
 
 
-def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2: dy [B, Cout, H, W], x [B, Cin, stride H, stride W]
     bf16 channels-last rows -> dw [Cout, Cin, 3, 3] bf16 in channels-last memory ([Cout][ky][kx][Cin]); no autograd."""
     lib = _lib.load()
@@ -1032,8 +1140,10 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> to
     nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N, int(stride))
     if nbytes == 0:
         raise _lib.HdError("conv3x3_wgrad: output W must be 20, 40 or 80, channel counts multiples of 64, stride 1 or 2")
-    ws = _wgrad_workspace(dy.device, nbytes)
-    dw = torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    ws = _wgrad_workspace(dy.device, nbytes)   # the other slab of the pair: a pending chained job stays intact
+    dw = out if out is not None else torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    if dw.dtype != torch.bfloat16 or tuple(dw.shape) != (N, K, 3, 3) or not dw.is_contiguous(memory_format=torch.channels_last):
+        raise _lib.HdError("conv3x3_wgrad: `out` must be a channels-last bf16 [Cout, Cin, 3, 3] tensor")
     _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
     with _timed("conv3x3_wgrad"):
         check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
@@ -1151,7 +1261,7 @@ class _PointwiseConvFn(torch.autograd.Function):
         R = x.shape[0] * x.shape[2] * x.shape[3]
         ours_w = need_dw and pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
         if ours_w:
-            dw = pointwise_wgrad_rows(dy, x).view(N, K, 1, 1)
+            dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
         lib_w, lib_x = need_dw and not ours_w, need_dx and not ours
         if lib_w or lib_x:
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
@@ -1188,127 +1298,244 @@ def pointwise_backward_usable(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return pointwise_wgrad_supported(B * H * W, K, weight.shape[0]) and _cl_row_stride(x, 8) is not None
 
 
+class _BNState:
+    """What the fused BatchNorm + activation forward leaves for its backward (shared by _BNActFn and _ConvBNActFn)."""
+    __slots__ = ("dt", "R", "C", "act", "slot", "sync_group", "stat_rows", "res_mode", "split", "tag", "w", "b", "save", "res")
+
+
+def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group, res, res_mode, out_slot,
+                stats_done):
+    """Statistics (unless the producer of x already left them in the slot) + apply.  -> (y, y2 | None, _BNState)."""
+    lib = _lib.load()
+    if res is not None:
+        if res.shape != x.shape or res.dtype != x.dtype or res.stride() != x.stride():
+            res = res.to(x.dtype).contiguous(memory_format=torch.channels_last)
+            if res.shape != x.shape:
+                raise _lib.HdError("bn_act: the residual must have the shape of the normalised tensor")
+    B, Cc, H, W = x.shape
+    R = B * H * W
+    dt = 0 if x.dtype == torch.float32 else 1
+    sums = slot.buf[: lib.hd_bn_act_replicas() * 2 * Cc] if stats_done else _fwd_sums(slot, Cc)
+    vec = 4 if dt == 0 else 8
+    split = 0
+    y2, tail = None, None
+    if out_slot is not None and isinstance(out_slot.t, tuple):
+        # two destinations (merged C3 branch convolutions): channels [0, split) -> y, [split, C) -> y2
+        y, y2 = out_slot.t
+        split = y.shape[1]
+        ld_y, ld_y2 = _cl_row_stride(y, vec), _cl_row_stride(y2, vec)
+        if (ld_y is None or ld_y2 is None or y.shape[1] + y2.shape[1] != Cc or y.dtype != x.dtype or y2.dtype != x.dtype
+                or split % vec or y.shape[0] != B or y.shape[2:] != x.shape[2:] or y2.shape[2:] != x.shape[2:]):
+            raise _lib.HdError("bn_act: split outputs must be channels-last tensors / channel slices covering x's channels")
+        tail = Rows2(y2.data_ptr(), int(ld_y2), int(split))
+    else:
+        y = out_slot.t if out_slot is not None else torch.empty_like(x)
+        ld_y = _cl_row_stride(y, vec)
+        if ld_y is None or y.shape != x.shape or y.dtype != x.dtype:
+            raise _lib.HdError("bn_act: `out` must be a channels-last tensor (or channel slice) of x's shape and dtype")
+    save = torch.empty((2, Cc), dtype=_F32, device=x.device)
+    st = _stream(x)
+    w, b = weight.detach().float(), bias.detach().float()
+    tb = x.numel() * x.element_size()
+    tag = (tuple(x.shape), int(act), int(res_mode) if res is not None else 0, bool(stats_done))
+    if not stats_done:
+        _note_bytes("bn_stats_kernel", tb, tag)
+        with _ktimed("bn_stats_kernel"):
+            check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
+    stat_rows = 0
+    if sync_group is not None:
+        # synchronised BatchNorm: the per-channel (sum, sum of squares) of every rank are added between the
+        # statistics kernel and the apply kernel; ranks hold equal shards, so the sums cover R * world rows
+        import torch.distributed as dist
+        dist.all_reduce(sums, group=sync_group)
+        stat_rows = R * dist.get_world_size(sync_group)
+    _note_bytes("bn_apply_kernel", (3 if res is not None else 2) * tb, tag)
+    with _ktimed("bn_apply_kernel"):
+        check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
+                                  _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
+                                  _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y),
+                                  C.byref(tail) if tail is not None else None, st), "hd_bn_act_apply")
+    s_ = _BNState()
+    s_.dt, s_.R, s_.C, s_.act, s_.slot, s_.sync_group, s_.stat_rows = dt, R, Cc, int(act), slot, sync_group, stat_rows
+    s_.res_mode, s_.split, s_.tag = (0 if res is None else int(res_mode)), split, tag
+    # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
+    s_.w, s_.b, s_.save, s_.res = w, b, save, (res if (res is not None and int(res_mode) == 1) else None)
+    return y, y2, s_
+
+
+class _BNGrad:
+    """The incoming gradient of a fused BatchNorm + activation as the kernels take it: (a channel slice of) a channels-last
+    tensor, possibly in two places (the merged C3 branch convolutions)."""
+    __slots__ = ("dy", "ld", "dy2", "tail", "dsums")
+
+
+def _bn_backward_reduce(st: "_BNState", x, dy, dy2) -> "_BNGrad":
+    """Per-channel sums of the backward (bn_bwd_reduce_kernel) into the slot's accumulators."""
+    lib = _lib.load()
+    vec = 4 if st.dt == 0 else 8
+    Cc = st.C
+
+    def prep(g, channels):
+        """-> (tensor kept alive, row stride): a (channel slice of a) channels-last tensor, copied once otherwise."""
+        if g is None:  # an unused half: zero gradient
+            g = torch.zeros((x.shape[0], channels, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
+                            memory_format=torch.channels_last)
+        if g.dtype != x.dtype:
+            g = g.to(x.dtype)
+        ld_ = _cl_row_stride(g, vec)
+        if ld_ is None:
+            g = g.contiguous(memory_format=torch.channels_last)
+            ld_ = channels
+        return g, ld_
+
+    g_ = _BNGrad()
+    g_.tail, g_.dy2 = None, None
+    if st.split:
+        g_.dy, g_.ld = prep(dy, st.split)
+        g_.dy2, ld2 = prep(dy2, Cc - st.split)
+        g_.tail = Rows2(g_.dy2.data_ptr(), int(ld2), int(st.split))
+    else:
+        g_.dy, g_.ld = prep(dy, Cc)
+    tail_ref = C.byref(g_.tail) if g_.tail is not None else None
+    rep = lib.hd_bn_act_replicas()
+    slot = st.slot
+    dsums = slot.buf[rep * 2 * Cc: rep * 4 * Cc]
+    if slot.bwd_gen == slot.arena.gen:
+        dsums.zero_()
+    slot.bwd_gen = slot.arena.gen
+    g_.dsums = dsums
+    tb = x.numel() * x.element_size()
+    _note_bytes("bn_bwd_reduce_kernel", (3 if st.res is not None else 2) * tb, st.tag)  # x, dy (+ the pre-activation residual)
+    with _ktimed("bn_bwd_reduce_kernel"):
+        check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(g_.dy), int(g_.ld), st.dt, st.R, Cc, _ptr(st.save[0]), _ptr(st.save[1]),
+                                       _ptr(st.w), _ptr(st.b), st.act, _ptr(st.res), _ptr(dsums), tail_ref, _stream(x)),
+              "hd_bn_act_bwd_reduce")
+    return g_
+
+
+def _bn_backward_dx(st: "_BNState", x, g_: "_BNGrad"):
+    """The elementwise half (bn_bwd_dx_kernel): -> (dx, dgamma, dbeta, d(residual) | None)."""
+    lib = _lib.load()
+    Cc = st.C
+    rep = lib.hd_bn_act_replicas()
+    local = None
+    if st.sync_group is not None:
+        # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
+        # parameter gradient); dx needs the sums over the whole synchronised batch
+        import torch.distributed as dist
+        local = g_.dsums.view(rep, 2, Cc).sum(0)
+        dist.all_reduce(g_.dsums, group=st.sync_group)
+    dx = torch.empty_like(x)
+    dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
+    dres = torch.empty_like(x) if st.res is not None else None
+    tb = x.numel() * x.element_size()
+    _note_bytes("bn_bwd_dx_kernel", (5 if st.res is not None else 3) * tb, st.tag)  # x, dy -> dx (+ residual in, d(res) out)
+    with _ktimed("bn_bwd_dx_kernel"):
+        check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(g_.dy), int(g_.ld), st.dt, st.R, st.stat_rows, Cc, _ptr(st.save[0]),
+                                   _ptr(st.save[1]), _ptr(st.w), _ptr(st.b), st.act, _ptr(st.res), _ptr(g_.dsums), _ptr(dx),
+                                   _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), C.byref(g_.tail) if g_.tail is not None else None,
+                                   _stream(x)), "hd_bn_act_bwd_dx")
+    # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
+    gres = dres if st.res_mode == 1 else (g_.dy if st.res_mode == 2 else None)
+    if local is not None:
+        return dx, local[1], local[0], gres
+    return dx, dg[0], dg[1], gres
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group=None, res=None,
                 res_mode=0, out_slot=None, stats_done=False):
         """stats_done: the producer of x (pointwise_conv) already added x's per-channel sums into the slot."""
-        lib = _lib.load()
-        if res is not None:
-            if res.shape != x.shape or res.dtype != x.dtype or res.stride() != x.stride():
-                res = res.to(x.dtype).contiguous(memory_format=torch.channels_last)
-                if res.shape != x.shape:
-                    raise _lib.HdError("bn_act: the residual must have the shape of the normalised tensor")
-        B, Cc, H, W = x.shape
-        R = B * H * W
-        dt = 0 if x.dtype == torch.float32 else 1
-        sums = slot.buf[: lib.hd_bn_act_replicas() * 2 * Cc] if stats_done else _fwd_sums(slot, Cc)
-        vec = 4 if dt == 0 else 8
-        split = 0
-        y2, tail = None, None
-        if out_slot is not None and isinstance(out_slot.t, tuple):
-            # two destinations (merged C3 branch convolutions): channels [0, split) -> y, [split, C) -> y2
-            y, y2 = out_slot.t
-            split = y.shape[1]
-            ld_y, ld_y2 = _cl_row_stride(y, vec), _cl_row_stride(y2, vec)
-            if (ld_y is None or ld_y2 is None or y.shape[1] + y2.shape[1] != Cc or y.dtype != x.dtype or y2.dtype != x.dtype
-                    or split % vec or y.shape[0] != B or y.shape[2:] != x.shape[2:] or y2.shape[2:] != x.shape[2:]):
-                raise _lib.HdError("bn_act: split outputs must be channels-last tensors / channel slices covering x's channels")
-            tail = Rows2(y2.data_ptr(), int(ld_y2), int(split))
-        else:
-            y = out_slot.t if out_slot is not None else torch.empty_like(x)
-            ld_y = _cl_row_stride(y, vec)
-            if ld_y is None or y.shape != x.shape or y.dtype != x.dtype:
-                raise _lib.HdError("bn_act: `out` must be a channels-last tensor (or channel slice) of x's shape and dtype")
-        save = torch.empty((2, Cc), dtype=_F32, device=x.device)
-        st = _stream(x)
-        w, b = weight.detach().float(), bias.detach().float()
-        tb = x.numel() * x.element_size()
-        tag = (tuple(x.shape), int(act), int(res_mode) if res is not None else 0, bool(stats_done))
-        if not stats_done:
-            _note_bytes("bn_stats_kernel", tb, tag)
-            with _ktimed("bn_stats_kernel"):
-                check(lib.hd_bn_act_stats(_ptr(x), dt, R, Cc, _ptr(sums), st), "hd_bn_act_stats")
-        stat_rows = 0
-        if sync_group is not None:
-            # synchronised BatchNorm: the per-channel (sum, sum of squares) of every rank are added between the
-            # statistics kernel and the apply kernel; ranks hold equal shards, so the sums cover R * world rows
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=sync_group)
-            stat_rows = R * dist.get_world_size(sync_group)
-        _note_bytes("bn_apply_kernel", (3 if res is not None else 2) * tb, tag)
-        with _ktimed("bn_apply_kernel"):
-            check(lib.hd_bn_act_apply(_ptr(x), dt, R, stat_rows, Cc, _ptr(sums), _ptr(w), _ptr(b), float(eps), float(momentum),
-                                      _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), int(act),
-                                      _ptr(res), int(res_mode) if res is not None else 0, _ptr(y), int(ld_y),
-                                      C.byref(tail) if tail is not None else None, st), "hd_bn_act_apply")
-        # the backward kernels need the residual only when it was added BEFORE the activation (mode 1)
-        keep_res = res if (res is not None and int(res_mode) == 1) else None
-        ctx.save_for_backward(x, w, b, save, *([keep_res] if keep_res is not None else []))
-        ctx.meta = (dt, R, Cc, int(act), slot, sync_group, stat_rows, 0 if res is None else int(res_mode), split)
-        ctx.tag = tag
+        y, y2, st = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, act, slot, sync_group, res, res_mode,
+                                out_slot, stats_done)
+        ctx.save_for_backward(x)
+        ctx.st = st
         return y if y2 is None else (y, y2)
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
+        (x,) = ctx.saved_tensors
+        st = ctx.st
+        g_ = _bn_backward_reduce(st, x, dy, dy2)
+        dx, dgamma, dbeta, gres = _bn_backward_dx(st, x, g_)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, gres, None, None, None
+
+
+class FuseSwitch:
+    """Class-wide switches of the layer-level fusions (tests flip them to compare against the unfused chain)."""
+    # fold bn_bwd_dx into the convolution's data / weight gradient kernels (csrc/hd_bn_fuse.h).  OFF by default: bit-exact,
+    # but slower — the SiLU' transform (~14 VALU slots per element, two transcendentals) runs inside kernels that hold one or
+    # two waves per SIMD for their LDS slabs and is repeated by every column tile: YOLOv5s 640^2 bs16 dgrad family 0.39 ->
+    # 0.89 ms per step for 0.27 ms of bn_bwd_dx launches saved (profiles/r03_fused_bn_backward.md).  HD_FUSE_BN_BACKWARD=1.
+    bn_backward = os.environ.get("HD_FUSE_BN_BACKWARD", "0") == "1"
+
+
+class _PwConvBNActFn(torch.autograd.Function):
+    """1x1 convolution -> BatchNorm (batch statistics) -> activation [-> + residual] as ONE autograd node, so that the
+    backward can fold the elementwise half of the BatchNorm backward into the convolution's gradient kernels:
+        bn_bwd_reduce (per-channel sums)  ->  hd_pointwise_conv_dgrad_bn + hd_pointwise_wgrad_partial(bn)
+    instead of bn_bwd_reduce, bn_bwd_dx (writes dy), dgrad (reads dy), wgrad (reads dy), wgrad reduce.  Same bits as that
+    chain (the kernels apply bn_bwd_dx's arithmetic to every chunk they stage).  Shapes / modes the fused kernels do not
+    take (pre-activation residual, SyncBN, channel counts outside the kernels' range) run the unfused chain in here."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, slot, res, res_mode, out_slot, ours_fwd):
+        N, K = weight.shape[0], weight.shape[1]
+        if ours_fwd:   # the epilogue leaves the batch statistics in the slot
+            y_raw = pointwise_conv_rows(x, weight.view(N, K), _fwd_sums(slot, N))
+        else:          # a reduction too long for the resident-weight kernel: the library's forward
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            y_raw = torch.nn.functional.conv2d(xd, weight)
+        y, y2, st = _bn_forward(y_raw, gamma, beta, running_mean, running_var, eps, momentum, act, slot, None, res, res_mode,
+                                out_slot, bool(ours_fwd))
+        ctx.save_for_backward(x, weight, y_raw)
+        ctx.st = st
+        return y if y2 is None else (y, y2)
+
+    @staticmethod
+    def backward(ctx, dout, dout2=None):
+        x, weight, y_raw = ctx.saved_tensors
+        st = ctx.st
+        N, K = weight.shape[0], weight.shape[1]
+        R = x.shape[0] * x.shape[2] * x.shape[3]
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lib = _lib.load()
-        x, w, b, save, *rest = ctx.saved_tensors
-        dt, R, Cc, act, slot, sync_group, stat_rows, res_mode, split = ctx.meta
-        res = rest[0] if rest else None
-        vec = 4 if dt == 0 else 8
+        g_ = _bn_backward_reduce(st, y_raw, dout, dout2)
+        ours_dx = bool(lib.hd_pointwise_conv_dgrad_supported(R, K, N))
+        ours_dw = pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
+        fused = (FuseSwitch.bn_backward and st.dt == 1 and st.res is None and st.sync_group is None and need_dw and ours_dw
+                 and (ours_dx or not need_dx) and _cl_row_stride(y_raw, 8) is not None)
+        if fused:
+            dg = torch.empty((2, N), dtype=_F32, device=x.device)
+            bn = _bn_bwd_struct(st, y_raw, g_, dg)
+            dw = pointwise_wgrad_rows(g_.dy, x, bn, g_.tail, N, weight).view(N, K, 1, 1)
+            dx = pointwise_dgrad_rows(g_.dy, weight.view(N, K), None, bn, g_.tail) if need_dx else None
+            gres = g_.dy if st.res_mode == 2 else None
+            return dx, dw, dg[1], dg[0], None, None, None, None, None, None, gres, None, None, None
+        dy, dgamma, dbeta, gres = _bn_backward_dx(st, y_raw, g_)
+        dx = dw = None
+        if need_dw and ours_dw:
+            dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
+        if need_dx and ours_dx:
+            dx = pointwise_dgrad_rows(dy, weight.view(N, K))
+        lib_w, lib_x = need_dw and dw is None, need_dx and dx is None
+        if lib_w or lib_x:
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            gi, gw, _ = torch.ops.aten.convolution_backward(dy, xd, weight, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                            (lib_x, lib_w, False))
+            dw = gw if lib_w else dw
+            dx = gi if lib_x else dx
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, gres, None, None, None
 
-        def prep(g, channels):
-            """-> (tensor kept alive, row stride): a (channel slice of a) channels-last tensor, copied once otherwise."""
-            if g is None:  # an unused half: zero gradient
-                g = torch.zeros((x.shape[0], channels, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
-                                memory_format=torch.channels_last)
-            if g.dtype != x.dtype:
-                g = g.to(x.dtype)
-            ld_ = _cl_row_stride(g, vec)
-            if ld_ is None:
-                g = g.contiguous(memory_format=torch.channels_last)
-                ld_ = channels
-            return g, ld_
 
-        tail = None
-        if split:
-            dy, ld = prep(dy, split)
-            dy2, ld2 = prep(dy2, Cc - split)
-            tail = Rows2(dy2.data_ptr(), int(ld2), int(split))
-        else:
-            dy, ld = prep(dy, Cc)
-        tail_ref = C.byref(tail) if tail is not None else None
-        rep = lib.hd_bn_act_replicas()
-        dsums = slot.buf[rep * 2 * Cc: rep * 4 * Cc]
-        if slot.bwd_gen == slot.arena.gen:
-            dsums.zero_()
-        slot.bwd_gen = slot.arena.gen
-        dx = torch.empty_like(x)
-        dg = torch.empty((2, Cc), dtype=_F32, device=x.device)
-        st = _stream(x)
-        dres = torch.empty_like(x) if res is not None else None
-        tb = x.numel() * x.element_size()
-        _note_bytes("bn_bwd_reduce_kernel", (3 if res is not None else 2) * tb, ctx.tag)  # x, dy (+ the pre-activation residual)
-        _note_bytes("bn_bwd_dx_kernel", (5 if res is not None else 3) * tb, ctx.tag)      # x, dy -> dx (+ residual in, d(res) out)
-        with _ktimed("bn_bwd_reduce_kernel"):
-            check(lib.hd_bn_act_bwd_reduce(_ptr(x), _ptr(dy), int(ld), dt, R, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w), _ptr(b),
-                                           act, _ptr(res), _ptr(dsums), tail_ref, st), "hd_bn_act_bwd_reduce")
-        local = None
-        if sync_group is not None:
-            # dgamma / dbeta stay this rank's own sums (the gradient all-reduce averages them like every other
-            # parameter gradient); dx needs the sums over the whole synchronised batch
-            import torch.distributed as dist
-            local = dsums.view(rep, 2, Cc).sum(0)
-            dist.all_reduce(dsums, group=sync_group)
-        with _ktimed("bn_bwd_dx_kernel"):
-            check(lib.hd_bn_act_bwd_dx(_ptr(x), _ptr(dy), int(ld), dt, R, stat_rows, Cc, _ptr(save[0]), _ptr(save[1]), _ptr(w),
-                                       _ptr(b), act, _ptr(res), _ptr(dsums), _ptr(dx), _ptr(dres), _ptr(dg[0]), _ptr(dg[1]), tail_ref,
-                                       st), "hd_bn_act_bwd_dx")
-        # d(residual): dz (written by the dx kernel) in mode 1, the incoming gradient itself in mode 2
-        gres = dres if res_mode == 1 else (dy if res_mode == 2 else None)
-        if local is not None:
-            return dx, local[1], local[0], None, None, None, None, None, None, None, gres, None, None, None
-        return dx, dg[0], dg[1], None, None, None, None, None, None, None, gres, None, None, None
+def pointwise_conv_bn_act(x, weight, gamma, beta, running_mean, running_var, eps: float, momentum: float, act: str,
+                          slot: "_StatSlot", residual=None, residual_after_act: bool = False, out=None, ours_forward: bool = True):
+    """conv1x1(x, weight) -> BatchNorm2d (training) -> activation [+ residual] on the HIP kernels, one autograd node (see
+    _PwConvBNActFn).  x: bf16 channels-last rows, weight: bf16 [Cout, Cin, 1, 1]; out as for bn_act."""
+    return _PwConvBNActFn.apply(x, weight, gamma, beta, running_mean, running_var, eps, momentum, _ACT_CODE[act], slot, residual,
+                                (2 if residual_after_act else 1) if residual is not None else 0,
+                                _OutSlot(out) if out is not None else None, bool(ours_forward))
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:

@@ -4,6 +4,7 @@ LR schedule: linear warmup + cosine (reference README.md:13,61)."""
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -87,7 +88,6 @@ class Trainer:
         # under hipGraph replay.  graph_split=False (or one rank) replays one graph and launches the collectives
         # behind it (`defer`).
         # graph_split="force": split replay even on one rank (no collectives then; tests compare it with the one-graph replay)
-        import os
         if os.environ.get("HD_GRAPH_SPLIT") == "0" and graph_split != "force":
             graph_split = False
         self.graph_split = bool(graph_split) and self.use_graph and (world > 1 or graph_split == "force")
@@ -102,7 +102,6 @@ class Trainer:
         # device-side), so the default is off for it.
         # HD_GRAPH_SYNC=1 forces the drained form on any backend, HD_GRAPH_SPLIT=0 (read above) the one-graph replay with
         # the collectives behind it: the two conservative forms, one environment variable away if a node misbehaves.
-        import os
         if graph_sync is None and os.environ.get("HD_GRAPH_SYNC") in ("0", "1"):
             graph_sync = os.environ["HD_GRAPH_SYNC"] == "1"
         if graph_sync is None:
@@ -133,7 +132,6 @@ class Trainer:
         self.graph_error = None
         self.graph_nodes = self.graph_memsets_replaced = 0
         # overlapped split replay is self-checking (see _verify_overlap); HD_GRAPH_VERIFY_OVERLAP=0 skips the two extra steps
-        import os
         self.verify_overlap = os.environ.get("HD_GRAPH_VERIFY_OVERLAP", "1") != "0"
         self.graph_overlap_check = None
         self.graph_overlap_error = None
@@ -158,15 +156,24 @@ class Trainer:
                 self.shadows.refresh()
                 self._shadows_dirty = False
         LowpWeights.on = self.shadows is not None
+        chain = None
+        if self.device.type == "cuda":
+            from . import ops
+            chain = ops._WgradChain   # weight-gradient slice sums ride in the next weight-gradient launch (ops._WgradChain)
+            chain.enabled = True
         try:
             with self.rand, torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
                 loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
             loss.backward()
+            if chain is not None:
+                ops.flush_wgrad()
             # buckets autograd left incomplete (parameters without a gradient this step) are packed here, inside
             # the captured region in hipGraph mode, so their packing copies replay with the graph
             self.reducer.pack_incomplete()
         finally:
             LowpWeights.on = False
+            if chain is not None:
+                chain.enabled = False
         return loss.detach(), parts
 
     def _capture(self, batch):

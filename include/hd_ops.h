@@ -430,6 +430,52 @@ hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const v
 hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout, void* y,
                             int64_t y_row_stride, float* stats, hd_stream stream);
 
+/* BatchNorm + activation backward folded into a convolution gradient (csrc/hd_bn_fuse.h).  A layer is
+ * y = conv(x, w), out = act(bn(y)) [+ r]; after hd_bn_act_bwd_reduce(y, d(out), ...) has left the per-channel sums in
+ * `dsums`, the gradient entry points with the `_bn` / `bn` argument take d(out) where they otherwise take dy and form
+ *     dy = A dz + (P y + Q),   dz = d(out) act'(z),   z = bn(y)
+ * while they stage the operand — the arithmetic, operation order and bf16 rounding of hd_bn_act_bwd_dx, whose launch (and
+ * the dy tensor) they replace.  y: bfloat16 rows [R, C] (y_row_stride elements, 0 = dense); save_mean / save_invstd /
+ * gamma / beta: float32 [C] as for hd_bn_act_bwd_dx; rows: the row count the batch statistics were taken over (R, or
+ * R x replicas under SyncBN); act: 0 none, 1 SiLU, 2 ReLU (no pre-activation residual); dgamma / dbeta (both or
+ * neither): written by the weight-gradient call.  d(out) may live in two places (hd_rows2, as for hd_bn_act_bwd_*). */
+typedef struct hd_bn_bwd {
+  const void* y;
+  int64_t y_row_stride;
+  const float* save_mean;
+  const float* save_invstd;
+  const float* gamma;
+  const float* beta;
+  const float* dsums;
+  int64_t rows;
+  int act;
+  float* dgamma;
+  float* dbeta;
+} hd_bn_bwd;
+
+/* The row-sliced float32 partial products of a weight gradient that still have to be summed into dw (bfloat16, `count`
+ * elements, a multiple of 4): hd_*_wgrad_partial fills one; it is consumed either by hd_wgrad_reduce (a launch of its
+ * own) or as the `piggyback` argument of the NEXT hd_*_wgrad_partial call on the same stream, whose launch then carries
+ * the summation in extra workgroups — one launch per layer instead of two.  The slab must stay untouched until then. */
+typedef struct hd_wgrad_job {
+  const float* slab;
+  int slices;
+  int64_t count;
+  void* dw;
+} hd_wgrad_job;
+hd_status hd_wgrad_reduce(const hd_wgrad_job* job, hd_stream stream);
+
+/* hd_pointwise_conv_dgrad with the fused BatchNorm backward: dx[R, Cin] = dy[R, Cout] . w, dy formed from dout / bn. */
+hd_status hd_pointwise_conv_dgrad_bn(const void* dout, int64_t dout_row_stride, const hd_rows2* dout_tail, const hd_bn_bwd* bn,
+                                     const void* w, int64_t R, int Cin, int Cout, void* dx, int64_t dx_row_stride,
+                                     hd_stream stream);
+/* hd_pointwise_wgrad split in its two halves: this call launches the partial products (bn nullable: dy is then taken as
+ * it is; piggyback nullable) and describes the pending summation in *job_out (dw is written by whoever runs the job). */
+hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const hd_rows2* dy_tail, const hd_bn_bwd* bn,
+                                     const void* x, int64_t x_row_stride, int64_t R, int Cin, int Cout, void* dw,
+                                     void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback,
+                                     hd_wgrad_job* job_out, hd_stream stream);
+
 /* Weight gradient of the same convolution: dw[Cout, Cin] (bfloat16) = dy[R, Cout]^T . x[R, Cin], float32 accumulate.
  * Two launches (row-sliced partial products into a float32 slab in `workspace`, then the sum over slices), no zero-fill.
  * Cin, Cout multiples of 64.  workspace: hd_pointwise_wgrad_workspace_bytes(R, Cin, Cout), 16-byte aligned, contents

@@ -216,3 +216,185 @@ def test_resnet_width_layers_train_through_conv_bn_act(cin, cout):
     for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)
+
+
+# ---- conv1x1 + BatchNorm + activation as one autograd node: BatchNorm backward folded into the gradient kernels ----------
+def _layer_run(m, x0, gy, res_in, out_pair, dev):
+    """One forward + backward of a ConvBNAct layer under bf16 autocast -> the tensors a parity check looks at."""
+    from heltondetection_amd import ops
+    m.zero_grad(set_to_none=True)
+    m.bn.running_mean.zero_(); m.bn.running_var.fill_(1.0)
+    ops.bn_arena_reset(dev)
+    x = x0.clone().requires_grad_(True)
+    r = res_in.clone().requires_grad_(True) if res_in is not None else None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x, r, out_pair)
+    if isinstance(y, tuple):
+        loss = sum((t.float() * g).sum() for t, g in zip(y, gy))
+        y = torch.cat([t.float() for t in y], 1)
+    else:
+        loss = (y.float() * gy).sum()
+    loss.backward()
+    ops.flush_wgrad()
+    return {"y": y.float().clone(), "dx": x.grad.float().clone(), "dw": m.conv.weight.grad.float().clone(),
+            "dgamma": m.bn.weight.grad.float().clone(), "dbeta": m.bn.bias.grad.float().clone(),
+            "dres": r.grad.float().clone() if r is not None else None,
+            "running_mean": m.bn.running_mean.clone(), "running_var": m.bn.running_var.clone()}
+
+
+FUSED_CASES = [(64, 64, 24, "silu", False, False), (128, 128, 13, "silu", True, False), (128, 256, 10, "silu", False, True),
+               (256, 128, 12, "relu", False, False), (256, 256, 9, None, False, False), (512, 256, 6, "silu", False, False),
+               (64, 128, 40, "silu", False, True), (1024, 512, 5, "silu", False, False)]
+
+
+@pytest.mark.parametrize("cin,cout,hw,act,residual,two_place", FUSED_CASES)
+def test_fused_bn_backward_kernels_are_bit_identical_to_bn_bwd_dx_then_gradients(cin, cout, hw, act, residual, two_place):
+    """hd_pointwise_conv_dgrad_bn / hd_pointwise_wgrad_partial(bn) against hd_bn_act_bwd_dx -> hd_pointwise_conv_dgrad /
+    hd_pointwise_wgrad on the SAME per-channel sums (one bn_bwd_reduce launch feeds both; its float atomics are the only
+    run-to-run freedom): the fused kernels apply bn_bwd_dx's arithmetic to every chunk they stage, so dx, dw, dgamma and
+    dbeta must come out with the same bits — ragged rows, post-activation residual, d(out) in two places (the merged C3
+    branch convolutions), a Cin > 256 layer."""
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    B = 3
+    x = torch.randn((B, cin, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 1, 1), generator=g) * cin ** -0.5).to(dev).to(torch.bfloat16)
+    gamma = (torch.rand((cout,), generator=g) + 0.5).to(dev)
+    beta = (torch.rand((cout,), generator=g) - 0.5).to(dev)
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    res = torch.randn((B, cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    ops.bn_arena_reset(dev)
+    slot = ops.bn_act_slot(dev, cout)
+    y_raw = torch.nn.functional.conv2d(x.float(), w.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _, _, st = ops._bn_forward(y_raw, gamma, beta, rm, rv, 1e-3, 0.03, ops._ACT_CODE[act], slot, None, res, 2 if residual else 0,
+                               None, False)
+    if two_place:
+        c1 = cout // 2
+        d1 = torch.randn((B, c1, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wide = torch.randn((B, 2 * cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dout, dout2 = d1, wide[:, cout:cout + (cout - c1)]
+        st.split = c1
+    else:
+        dout = torch.randn((B, cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dout2 = None
+    g_ = ops._bn_backward_reduce(st, y_raw, dout, dout2)
+    dy, dgamma, dbeta, _ = ops._bn_backward_dx(st, y_raw, g_)
+    R = B * hw * hw
+    lib = _lib.load()
+    dg = torch.zeros((2, cout), dtype=torch.float32, device=dev)
+    bn = ops._bn_bwd_struct(st, y_raw, g_, dg)
+    dw = ops.pointwise_wgrad_rows(g_.dy, x, bn, g_.tail, cout)
+    dw_ref = ops.pointwise_wgrad_rows(dy, x)
+    assert torch.equal(dw, dw_ref), float((dw.float() - dw_ref.float()).abs().max())
+    assert torch.equal(dg[1], dgamma) and torch.equal(dg[0], dbeta)
+    if lib.hd_pointwise_conv_dgrad_supported(R, cin, cout):
+        dx = ops.pointwise_dgrad_rows(g_.dy, w.view(cout, cin), None, bn, g_.tail)
+        dx_ref = ops.pointwise_dgrad_rows(dy, w.view(cout, cin))
+        assert torch.equal(dx, dx_ref), float((dx.float() - dx_ref.float()).abs().max())
+    else:
+        assert cout > 256   # the data gradient's reduction must fit the resident-weight kernel
+
+
+@pytest.mark.parametrize("cin,cout,hw,act,residual,two_place", FUSED_CASES)
+def test_fused_conv_bn_act_node_matches_the_unfused_chain(cin, cout, hw, act, residual, two_place):
+    """ops._PwConvBNActFn with ops.FuseSwitch.bn_backward on and off, through layers.ConvBNAct under autocast: two runs, so
+    the float atomics of the statistics / reduce kernels differ in their last bits — equal up to one bf16 rounding."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = layers.ConvBNAct(cin, cout, 1, 1, act=act).to(dev).to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.uniform_(-0.5, 0.5)
+    B = 3
+    x0 = torch.randn((B, cin, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
+    res_in = torch.randn((B, cout, hw, hw), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    if two_place:
+        c1 = cout // 2
+        gy = (torch.randn((B, c1, hw, hw), device=dev), torch.randn((B, cout - c1, hw, hw), device=dev))
+    else:
+        gy = torch.randn((B, cout, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
+    runs = {}
+    was = ops.FuseSwitch.bn_backward
+    for fused in (True, False):
+        ops.FuseSwitch.bn_backward = fused
+        try:
+            out_pair = None
+            if two_place:   # first half dense, second half a slice of a wider concatenation buffer
+                y1 = torch.empty((B, c1, hw, hw), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+                cat = torch.zeros((B, 2 * cout, hw, hw), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+                out_pair = (y1, cat[:, cout:cout + (cout - c1)])
+            runs[fused] = _layer_run(m, x0, gy, res_in, out_pair, dev)
+        finally:
+            ops.FuseSwitch.bn_backward = was
+    for k in runs[True]:
+        a, b = runs[True][k], runs[False][k]
+        if a is None:
+            continue
+        tol = 2.0 ** -7 * b.abs() + 2.0 ** -9 * b.abs().mean() + 1e-7
+        assert bool(((a - b).abs() <= tol).all()), (k, float(((a - b).abs() / tol).max()))
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 64, 20), (128, 256, 10), (256, 128, 8)])
+def test_fused_conv_bn_act_matches_fp32_pytorch(cin, cout, hw):
+    """The fused node against plain float32 PyTorch conv -> BatchNorm2d -> SiLU on the same bf16-rounded x and w: forward,
+    dx, dw, dgamma, dbeta and the running statistics, element-wise with the bf16 tolerance of the kernels above."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = layers.ConvBNAct(cin, cout, 1, 1).to(dev).to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        m.conv.weight.copy_(m.conv.weight.to(torch.bfloat16).float())   # the reference sees the same weights
+        m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn((4, cin, hw, hw), device=dev).to(torch.bfloat16).float().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((4, cout, hw, hw), device=dev).to(torch.bfloat16).float().contiguous(memory_format=torch.channels_last)
+    got = _layer_run(m, x0, gy, None, None, dev)
+    ref_conv = torch.nn.Conv2d(cin, cout, 1, bias=False).to(dev)
+    ref_bn = torch.nn.BatchNorm2d(cout, eps=m.bn.eps, momentum=m.bn.momentum).to(dev).train()
+    with torch.no_grad():
+        ref_conv.weight.copy_(m.conv.weight); ref_bn.weight.copy_(m.bn.weight); ref_bn.bias.copy_(m.bn.bias)
+    xr = x0.clone().requires_grad_(True)
+    yr = torch.nn.functional.silu(ref_bn(ref_conv(xr)))
+    (yr * gy).sum().backward()
+    want = {"y": yr.detach(), "dx": xr.grad, "dw": ref_conv.weight.grad, "dgamma": ref_bn.weight.grad, "dbeta": ref_bn.bias.grad,
+            "running_mean": ref_bn.running_mean, "running_var": ref_bn.running_var}
+    # bf16 stores on the way: conv output (2^-9), activation output (2^-9), dy (2^-9) and the gradient itself; the
+    # element-wise bound is a few bf16 roundings of the element plus a floor for elements that are sums of many terms
+    for k, ref in want.items():
+        a = got[k]
+        tol = 2.0 ** -6 * ref.abs() + 2.0 ** -6 * ref.abs().mean() + 1e-6
+        bad = float(((a - ref).abs() / tol).max())
+        assert bad <= 1.0, (k, bad, float((a - ref).abs().max()), float(ref.abs().max()))
+
+
+def test_chained_weight_gradient_sums_ride_in_the_next_launch():
+    """Inside a training step (ops._WgradChain.enabled) the sum over the row slices of weight gradient i rides in the
+    launch of weight gradient i + 1 and the last one is flushed: the results equal the immediately summed ones bit for bit,
+    across different shapes in one chain and with a 3x3 weight gradient (its own two launches) in between."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 64, 20, 20, 64), (2, 128, 10, 10, 256), (1, 256, 9, 7, 128), (2, 64, 40, 40, 128), (2, 512, 5, 5, 256)]
+    ops_in = []
+    for B, K, H, W, N in shapes:
+        x = torch.randn((B, K, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn((B, N, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ops_in.append((dy, x))
+    x3 = torch.randn((2, 64, 20, 20), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy3 = torch.randn((2, 64, 20, 20), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref = [ops.pointwise_wgrad_rows(dy, x).clone() for dy, x in ops_in]
+    ref3 = ops.conv3x3_wgrad_rows(dy3, x3).clone()
+    ops._WgradChain.enabled = True
+    try:
+        got = []
+        for i, (dy, x) in enumerate(ops_in):
+            got.append(ops.pointwise_wgrad_rows(dy, x))
+            if i == 1:
+                got3 = ops.conv3x3_wgrad_rows(dy3, x3)
+        ops.flush_wgrad()
+    finally:
+        ops._WgradChain.enabled = False
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert torch.equal(got3, ref3)
