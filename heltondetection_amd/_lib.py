@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -128,6 +128,10 @@ SIGNATURES = {
     "hd_wgrad_reduce": (_I, [_P, _P]),
     "hd_pointwise_conv_dgrad_bn": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "hd_pointwise_wgrad_partial": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _P, _P, _Z, _P, _P, _P]),
+    "hd_stem_conv_supported": (_I, [_I, _I, _I, _I, _I]),
+    "hd_stem_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "hd_stem_conv_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P]),
+    "hd_stem_conv_wgrad_partial": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _P]),
     "hd_upsample2x_cat_fwd": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_upsample2x_cat_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_conv3x3_fwd_supported": (_I, [_I, _I, _I, _I, _I]),

@@ -113,6 +113,7 @@ class ConvBNAct(nn.Module):
     # layer in the step against 25-38 us (+ a 6 us statistics launch) for the library's kernels.  The 3x3 WEIGHT gradient
     # (hd_conv3x3_wgrad) does not depend on this switch.
     conv3x3_forward = True
+    stem = True  # the 6x6 / stride 2 stem on csrc/stem_conv.hip (forward + statistics, weight gradient)
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
@@ -184,7 +185,25 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
             return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
         return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0], None, ConvBNAct.conv3x3_forward), act, residual,
                                 residual_after_act, out)
+    if _stem_ours(conv, bn, x):
+        from . import ops
+        w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+        w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        w = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        if ops.stem_conv_supported(x, w):
+            # the 6x6 / stride 2 stem on 3-channel images: float32 pixels read directly (no cast pass), statistics in the epilogue
+            y = ops.stem_conv(x, w, FusedBNAct.slot_of(bn, x.device))
+            return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
     return FusedBNAct.apply(bn, conv(x), act, residual, residual_after_act, out)
+
+
+def _stem_ours(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
+    """The YOLOv5 v6.x stem (Conv2d(3, 32 | 64, 6, 2, 2), no bias) in bf16 training on HIP images that need no gradient."""
+    return (ConvBNAct.stem and conv.kernel_size == (6, 6) and conv.stride == (2, 2) and conv.padding == (2, 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels == 3
+            and conv.out_channels in (32, 64) and x.is_cuda and not x.requires_grad and bn.training and bn.momentum is not None
+            and FusedBNAct.enabled and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and conv.weight.requires_grad)
 
 
 class _like_conv_out:

@@ -1007,6 +1007,14 @@ class _WgradChain:
             check(_lib.load().hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "hd_wgrad_reduce")
 
     @classmethod
+    def flush_device(cls, device) -> None:
+        """Sum the pending job of one device now (a launch that cannot carry it is about to use the stream)."""
+        pend = cls._pending.pop(cls._key(device), None)
+        if pend is not None:
+            check(_lib.load().hd_wgrad_reduce(C.byref(pend[0]), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                  "hd_wgrad_reduce")
+
+    @classmethod
     def flush(cls) -> None:
         lib = _lib.load()
         for key, (job, keep) in list(cls._pending.items()):
@@ -1114,7 +1122,7 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
                                              C.byref(bn) if bn is not None else None, _ptr(x), int(ld_x), R, K, N, _ptr(dw),
                                              _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
                                              _stream(dy)), "hd_pointwise_wgrad_partial")
-        _WgradChain.submit(dy.device, job, (ws, dw), leaf)
+        _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
     return dw
 
 
@@ -1224,6 +1232,88 @@ def conv3x3_takes_stats(x: torch.Tensor, weight: torch.Tensor, stride: int) -> b
     """True when conv3x3(x, weight, stride, slot) runs the hand-written forward (and so can fill a BatchNorm slot)."""
     return (stride == 1 and weight.dtype == torch.bfloat16 and weight.is_contiguous(memory_format=torch.channels_last)
             and conv3x3_fwd_supported(x, weight.shape[0]))
+
+
+# ------------------------------------------------------------------------------- the 6x6 / stride 2 stem (3 input channels)
+def stem_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """x: [B, 3, H, W] float32 or bf16, dense channels-last; weight: [Cout, 3, 6, 6] bf16 in channels-last memory."""
+    if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype in (torch.float32, torch.bfloat16)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0):
+        return False
+    if not (weight.dim() == 4 and tuple(weight.shape[1:]) == (3, 6, 6) and weight.dtype == torch.bfloat16
+            and weight.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    B, _, H, W = x.shape
+    return bool(_lib.load().hd_stem_conv_supported(B, H, W, int(weight.shape[0]), 0 if x.dtype == torch.float32 else 1))
+
+
+def stem_conv_rows(x: torch.Tensor, weight: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y [B, Cout, H/2, W/2] bf16 channels-last = Conv2d(3, Cout, 6, 2, 2)(x) on hd_stem_conv_fwd, no autograd; stats as for
+    pointwise_conv_rows."""
+    lib = _lib.load()
+    if not stem_conv_supported(x, weight):
+        raise _lib.HdError("stem_conv: needs dense channels-last [B, 3, H, W] images (H even, W % 4 == 0) and a channels-last bf16 "
+                           "[Cout in {32, 64}, 3, 6, 6] weight")
+    B, _, H, W = x.shape
+    N = weight.shape[0]
+    y = torch.empty((B, N, H // 2, W // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _note_bytes("stem_conv_fwd", x.numel() * x.element_size() + y.numel() * 2 + weight.numel() * 2,
+                {"flops": 2 * B * (H // 2) * (W // 2) * N * 108})
+    with _ktimed("stem_conv_fwd"):
+        check(lib.hd_stem_conv_fwd(_ptr(x), 0 if x.dtype == torch.float32 else 1, _ptr(weight), B, H, W, N, _ptr(y), N, _ptr(stats),
+                                   _stream(x)), "hd_stem_conv_fwd")
+    return y
+
+
+def stem_conv_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, leaf: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw [Cout, 3, 6, 6] bf16 (channels-last memory) of the stem from dy [B, Cout, H/2, W/2] bf16 channels-last rows and the
+    images x; completes like every chained weight gradient (_WgradChain)."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    N = dy.shape[1]
+    ld_dy = _cl_row_stride(dy, 8)
+    if ld_dy is None or dy.dtype != torch.bfloat16 or tuple(dy.shape) != (B, N, H // 2, W // 2):
+        raise _lib.HdError("stem_conv_wgrad: dy must be bf16 channels-last rows [B, Cout, H/2, W/2]")
+    nbytes = lib.hd_stem_conv_wgrad_workspace_bytes(B, H, W, N)
+    if nbytes == 0:
+        raise _lib.HdError("stem_conv_wgrad: unsupported shape")
+    _WgradChain.flush_device(dy.device)   # this launch carries no piggyback: sum what is pending first
+    ws = _wgrad_workspace(dy.device, nbytes)
+    dw = torch.empty((N, 3, 6, 6), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    job = _lib.WgradJob()
+    _note_bytes("stem_conv_wgrad", x.numel() * x.element_size() + dy.numel() * 2, {"flops": 2 * B * (H // 2) * (W // 2) * N * 108})
+    with _timed("stem_conv_wgrad"):
+        check(lib.hd_stem_conv_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), 0 if x.dtype == torch.float32 else 1, B, H, W, N,
+                                             _ptr(dw), _ptr(ws), ws.numel(), C.byref(job), _stream(dy)),
+              "hd_stem_conv_wgrad_partial")
+        _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
+    return dw
+
+
+class _StemConvFn(torch.autograd.Function):
+    """The stem convolution on hd_stem_conv_fwd (BatchNorm statistics into `slot` from its epilogue) / hd_stem_conv_wgrad_partial;
+    the images get no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, slot):
+        ctx.save_for_backward(x, weight)
+        return stem_conv_rows(x, weight, _fwd_sums(slot, weight.shape[0]) if slot is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.HdError("stem_conv: the input images must not require a gradient")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            g = dy if (dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None) else \
+                dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = stem_conv_wgrad_rows(g, x, weight)
+        return None, dw, None
+
+
+def stem_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatSlot"] = None) -> torch.Tensor:
+    return _StemConvFn.apply(x, weight, slot)
 
 
 POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen

@@ -476,6 +476,20 @@ hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, cons
                                      void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback,
                                      hd_wgrad_job* job_out, hd_stream stream);
 
+/* The YOLOv5 v6.x stem, Conv2d(3, Cout, kernel 6, stride 2, padding 2, no bias), on channels-last images (csrc/stem_conv.hip;
+ * the reference's backbone list, README.md:9).  x: [B, H, W, 3] float32 (x_dtype 0) or bfloat16 (1), dense, H even,
+ * W % 4 == 0; w: bfloat16 [Cout][6][6][3] (the channels-last memory of a [Cout, 3, 6, 6] weight); Cout 32 or 64;
+ * y: bfloat16 rows [B H/2 W/2, Cout] (y_row_stride elements, 0 = dense).  stats as for hd_pointwise_conv.
+ * The weight gradient comes as row-sliced partial products + a pending hd_wgrad_job (dw: bfloat16 [Cout][6][6][3]);
+ * workspace: hd_stem_conv_wgrad_workspace_bytes(...).  The images need no gradient. */
+int hd_stem_conv_supported(int B, int H, int W, int Cout, int x_dtype);
+size_t hd_stem_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout);
+hd_status hd_stem_conv_fwd(const void* x, int x_dtype, const void* w, int B, int H, int W, int Cout, void* y,
+                           int64_t y_row_stride, float* stats, hd_stream stream);
+hd_status hd_stem_conv_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int x_dtype, int B, int H, int W,
+                                     int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_wgrad_job* job_out,
+                                     hd_stream stream);
+
 /* Weight gradient of the same convolution: dw[Cout, Cin] (bfloat16) = dy[R, Cout]^T . x[R, Cin], float32 accumulate.
  * Two launches (row-sliced partial products into a float32 slab in `workspace`, then the sum over slices), no zero-fill.
  * Cin, Cout multiples of 64.  workspace: hd_pointwise_wgrad_workspace_bytes(R, Cin, Cout), 16-byte aligned, contents
