@@ -413,7 +413,8 @@ def bn_family_roofline(model, batch, args, device):
     the ops note each launch's algorithmic bytes and shape themselves (ops._note_bytes), in launch order."""
     from heltondetection_amd import ops
     names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
-    pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")
+    pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad",
+                "stem_conv_fwd", "stem_conv_wgrad")
     passes, per_pass, notes, tags = 3, [], None, None
     try:
         for it in range(passes + 1):  # the first pass warms up
@@ -478,14 +479,16 @@ def bn_family_roofline(model, batch, args, device):
         pby = {k: sum(notes[k]) for k in pw_names}
         pn = {k: len(per_pass[0][k]) for k in pw_names}
         pw = _hbm_entry("hand-written convolution family (1x1: pointwise_conv fwd + BN statistics / pointwise_dgrad / "
-                        "pointwise_wgrad + reduce; 3x3: conv3x3_fwd + BN statistics / conv3x3_dgrad / conv3x3_wgrad + reduce), "
-                        "step-weighted over the model's layers that take them", sum(pms.values()), sum(pby.values()),
+                        "pointwise_wgrad; 3x3: conv3x3_fwd + BN statistics / conv3x3_dgrad / conv3x3_wgrad + slice sum; 6x6 stem: "
+                        "stem_conv_fwd + BN statistics / stem_conv_wgrad), step-weighted over the model's layers that take them",
+                        sum(pms.values()), sum(pby.values()),
                         sum(pn.values()),
                         {"sum_launch_ms_per_step": round(sum(pms.values()), 4), "algorithmic_bytes_per_step": int(sum(pby.values())),
                          "algorithmic_bytes": "2 (R (Cin + Cout) + taps Cin Cout) per call: each operand once, bf16 (the 3x3 "
                                               "kernels are MFMA / LDS bound, their HBM fraction is reported for completeness)",
-                         "timed": "same passes and event mechanism as the BN family; the two weight-gradient entries are event pairs "
-                                  "around their two launches (row-sliced partial products, slab reduction)",
+                         "timed": "same passes and event mechanism as the BN family; the weight-gradient entries are event pairs "
+                                  "around their launches (row-sliced partial products + slice sum; outside the Trainer's step the sum "
+                                  "is launched at once, inside it rides in the next weight-gradient launch)",
                          "per_kernel": {k: _conv_kernel_entry(k, pms[k], pby[k], pn[k], sum((t or {}).get("flops", 0) for t in tags[k]))
                                         for k in pw_names}})
     fam["_pointwise"] = pw

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -126,6 +126,7 @@ SIGNATURES = {
     "hd_pointwise_wgrad_workspace_bytes": (_Z, [_L, _I, _I]),
     "hd_pointwise_wgrad": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _Z, _P]),
     "hd_wgrad_reduce": (_I, [_P, _P]),
+    "hd_pointwise_conv_dgrad_add": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "hd_pointwise_conv_dgrad_bn": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "hd_pointwise_wgrad_partial": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _P, _P, _Z, _P, _P, _P]),
     "hd_stem_conv_supported": (_I, [_I, _I, _I, _I, _I]),

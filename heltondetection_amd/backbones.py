@@ -72,12 +72,16 @@ class _ResBottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # the 1x1 convolutions (conv1, conv3, a stride-1 downsample) take the MFMA kernels of csrc/pointwise_conv.hip; the
+        # identity shortcut's gradient is added inside conv1's data-gradient kernel (`fork`)
         if self.downsample is None:
-            idt = x
+            if ConvBNAct.fork_shortcut:
+                y, idt = conv_bn_act(self.conv1, self.bn1, "relu", x, fork=True)
+            else:
+                y, idt = conv_bn_act(self.conv1, self.bn1, "relu", x), x
         else:
             idt = conv_bn_act(self.downsample[0], self.downsample[1], None, x)
-        # the 1x1 convolutions (conv1, conv3, a stride-1 downsample) take the MFMA kernels of csrc/pointwise_conv.hip
-        y = conv_bn_act(self.conv1, self.bn1, "relu", x)
+            y = conv_bn_act(self.conv1, self.bn1, "relu", x)
         y = conv_bn_act(self.conv2, self.bn2, "relu", y)
         # relu(bn3(conv3) + identity) in one fused kernel (residual added before the activation)
         return conv_bn_act(self.conv3, self.bn3, "relu", y, idt, False)

@@ -242,11 +242,15 @@ struct StreamLds {
 // BNB: the A operand is dy of a fused BatchNorm + activation, formed on the fly from d(out) (= A, possibly in two places)
 // and the BatchNorm's input y (hd_bn_fuse.h): each 16-byte chunk is transformed between its global load and its LDS
 // store, with the 8 channels' coefficients in registers (a lane's chunk index is fixed: K / 8 divides 64).
-template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false>
+// ACC: the result is added to the rows of `radd` (bf16, row stride ld_r) before it is stored — the data gradient of a layer
+// whose input also feeds a shortcut: dx = dy . w + d(shortcut) in one pass (float32 add of the two bf16 values, one rounding:
+// what the separate bf16 add kernel of the autograd engine computes), instead of a launch that reads both and writes the sum.
+template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false, bool ACC = false>
 __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
                                                                const unsigned short* __restrict__ Bw,
                                                                unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
-                                                               float* __restrict__ stats, const hdfuse::BnBwd bn) {
+                                                               float* __restrict__ stats, const hdfuse::BnBwd bn,
+                                                               const unsigned short* __restrict__ radd, long long ld_r) {
   using L = StreamLds<K, TN, TM, TRB>;
   constexpr int BN = TN * 32, KS = K / 16, CPR = K / 8;
   constexpr int NLD = TM * KS;  // 16-byte loads per lane per row block: 32 TM rows x CPR chunks over 64 lanes
@@ -353,8 +357,24 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
 #pragma unroll
       for (int q = 0; q < BN / 16; ++q) {  // 32 rows x BN/8 chunks of 16 bytes over 64 lanes
         const int id = q * 64 + lane, row = id / (BN / 8), c = id % (BN / 8);
-        const uint4 v = *reinterpret_cast<const uint4*>(area + row * L::PATCH_ROW + c * 16);
-        if (m0 + row < M) *reinterpret_cast<uint4*>(Cmat + (long long)(m0 + row) * ldc + n0 + c * 8) = v;
+        uint4 v = *reinterpret_cast<const uint4*>(area + row * L::PATCH_ROW + c * 16);
+        if (m0 + row < M) {
+          if (ACC) {
+            const uint4 r = *reinterpret_cast<const uint4*>(radd + (long long)(m0 + row) * ld_r + n0 + c * 8);
+            const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
+            unsigned oo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              const f32x2 f = {__uint_as_float(vv[e] << 16) + __uint_as_float(rr[e] << 16),
+                               __uint_as_float(vv[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u)};
+              oo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+            }
+            v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+          }
+          *reinterpret_cast<uint4*>(Cmat + (long long)(m0 + row) * ldc + n0 + c * 8) = v;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before it is overwritten
     }
@@ -382,7 +402,7 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
 
 template <int K, int TN, int TM, bool TRB>
 hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats,
-                        hipStream_t s, const hdfuse::BnBwd* bn = nullptr) {
+                        hipStream_t s, const hdfuse::BnBwd* bn = nullptr, const void* radd = nullptr, int64_t ld_r = 0) {
   constexpr int BN = TN * 32;
   const int NT = N / BN;
   const long long RT = ((long long)M + 32 * TM - 1) / (32 * TM);
@@ -397,18 +417,25 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   const auto* b = static_cast<const unsigned short*>(Bw);
   auto* c = static_cast<unsigned short*>(Cmat);
   const hdfuse::BnBwd none = {};
+  const unsigned short* no_add = nullptr;
   if (bn) {
     if constexpr (TRB)
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c,
-                      ldc, M, N, (float*)nullptr, *bn);
+                      ldc, M, N, (float*)nullptr, *bn, no_add, 0ll);
+    else
+      return HD_ERR_SHAPE;
+  } else if (radd) {
+    if constexpr (TRB)
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda,
+                      b, c, ldc, M, N, (float*)nullptr, none, static_cast<const unsigned short*>(radd), (long long)ld_r);
     else
       return HD_ERR_SHAPE;
   } else if (stats && !TRB)
     (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, stats, none);
+                    N, stats, none, no_add, 0ll);
   else
     (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, (float*)nullptr, none);
+                    N, (float*)nullptr, none, no_add, 0ll);
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -416,21 +443,21 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
 // -> true when the streaming form took the call
 template <int K, bool TRB = false>
 bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
-                hd_status* st, const hdfuse::BnBwd* bnb = nullptr) {
+                hd_status* st, const hdfuse::BnBwd* bnb = nullptr, const void* radd = nullptr, int64_t ld_r = 0) {
   constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
   const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > 8) return false;
   if (bn == 128) {
-    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb); return true; }
+    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r); return true; }
     return false;
   }
   if (bn == 64) {
-    if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
-    else *st = launch_stream<K, 2, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
+    if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
+    else *st = launch_stream<K, 2, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
     return true;
   }
-  if constexpr (K <= 64) *st = launch_stream<K, 1, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
-  else *st = launch_stream<K, 1, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb);
+  if constexpr (K <= 64) *st = launch_stream<K, 1, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
+  else *st = launch_stream<K, 1, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
   return true;
 }
 
@@ -1293,6 +1320,28 @@ extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stri
   if (Cout == 64 && try_stream<64, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   if (Cout == 128 && try_stream<128, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
   if (Cout == 256 && try_stream<256, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st)) return st;
+  return HD_ERR_SHAPE;
+}
+
+extern "C" hd_status hd_pointwise_conv_dgrad_add(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin,
+                                                 int Cout, const void* add, int64_t add_row_stride, void* dx,
+                                                 int64_t dx_row_stride, hd_stream stream) {
+  if (!dy || !w || !dx || !add) return HD_ERR_NULL;
+  if (!hd_pointwise_conv_dgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
+  if (dy_row_stride == 0) dy_row_stride = Cout;
+  if (dx_row_stride == 0) dx_row_stride = Cin;
+  if (add_row_stride == 0) add_row_stride = Cin;
+  if (dy_row_stride < Cout || dx_row_stride < Cin || add_row_stride < Cin || dy_row_stride % 8 || dx_row_stride % 8 ||
+      add_row_stride % 8)
+    return HD_ERR_SHAPE;
+  if (!hd_aligned16(dy) || !hd_aligned16(w) || !hd_aligned16(dx) || !hd_aligned16(add)) return HD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  hd_status st = HD_OK;
+  const int M = (int)R;
+  if (Cout == 32 && try_stream<32, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, nullptr, add, add_row_stride)) return st;
+  if (Cout == 64 && try_stream<64, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, nullptr, add, add_row_stride)) return st;
+  if (Cout == 128 && try_stream<128, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, nullptr, add, add_row_stride)) return st;
+  if (Cout == 256 && try_stream<256, true>(dy, dy_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, nullptr, add, add_row_stride)) return st;
   return HD_ERR_SHAPE;
 }
 

@@ -41,7 +41,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 
-__host__ __device__ inline int ring_row_bytes(int W) { return ((W + kPadPx + 4) * 6 + 15) / 16 * 16; }
+// left pad kPadPx pixels, right pad 4 pixels + slack for the output pixels past the row end that a 32-pixel tile still
+// touches (the weight gradient reads them unclamped: their dY rows are zero, the slack is zero-filled and never written)
+__host__ __device__ inline int ring_row_bytes(int W) { return ((W + kPadPx + 4 + 64) * 6 + 15) / 16 * 16; }
 
 // k (0..143) -> index into the real [6][6][3] kernel (0..107), or -1 for the zero-weight padding slots
 __device__ __forceinline__ int real_k(int k) {
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void stem6x6_wgrad_kernel(c
   constexpr int COUT = NT * 32;
   constexpr int MAXV = 4;
   constexpr int KT = 5;                    // k tiles of 32: 144 -> 160
-  constexpr int SY = COUT * 2 + 64;        // dY row stride in LDS (bytes), padded for the transpose reads
+  // dY row stride in LDS (bytes): the four 64-byte rows a half-wave's transpose read touches must fall on disjoint bank
+  // quarters, i.e. stride = 64 or 192 (mod 256): dense for 32 channels, 64 bytes of padding for 64
+  constexpr int SY = COUT == 32 ? 64 : COUT * 2 + 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [ring | dY row: Wo16 pixels x SY]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fh = lane >> 5;
@@ -334,17 +338,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void stem6x6_wgrad_kernel(c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.0f;
 
-  // this lane's patch column per k tile: kk = 32 t + frow -> (kernel row, byte offset inside the row's 18 elements)
+  // this lane's patch column per k tile: kk = 32 t + frow -> (kernel row, byte offset inside the row's 18 elements) + the
+  // lane half's 8-pixel offset; padding slots read neighbouring pixels' data: their dW entries are never written out
   int ky_[KT], ob_[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     const int k = min(32 * t + frow, KP - 1);
     ky_[t] = k / 24;
-    ob_[t] = (k % 24) * 2;  // padding slots read neighbouring pixels' data: their dW entries are never written out
+    ob_[t] = (k % 24) * 2 + (kPadPx - 2) * 6 + 8 * fh * 12;
   }
   const int steps = Wo16 / 16;  // 16 pixels per k-step
   for (int oy = oy0; oy < oy1; ++oy) {
     __syncthreads();
+    const unsigned char* rowp_[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) rowp_[t] = smem + ((2 * oy - 2 + ky_[t] + 2) & (kRing - 1)) * row_bytes + ob_[t];
     for (int st = wave; st < steps; st += 4) {
       const int px0 = st * 16;
       bf16x8 a[NT];
@@ -352,12 +360,14 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void stem6x6_wgrad_kernel(c
       for (int j = 0; j < NT; ++j) a[j] = tr_fragment(ys, SY, j * 32, px0, lane);
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        const unsigned char* rowp = smem + ((2 * oy - 2 + ky_[t] + 2) & (kRing - 1)) * row_bytes + ob_[t] + (kPadPx - 2) * 6;
+        // eight 2-byte reads 12 bytes apart from one base address (immediate offsets); pixels past the row end fall into
+        // the zero slack of the ring row, and their dY rows are zero anyway
+        const unsigned char* base = rowp_[t] + px0 * 12;
         u32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // pixels past the row end are clamped: their dY rows are zero
-          const unsigned lo = *reinterpret_cast<const unsigned short*>(rowp + min(px0 + 8 * fh + 2 * q, Wo - 1) * 12);
-          const unsigned hi = *reinterpret_cast<const unsigned short*>(rowp + min(px0 + 8 * fh + 2 * q + 1, Wo - 1) * 12);
+        for (int q = 0; q < 4; ++q) {
+          const unsigned lo = *reinterpret_cast<const unsigned short*>(base + (2 * q) * 12);
+          const unsigned hi = *reinterpret_cast<const unsigned short*>(base + (2 * q + 1) * 12);
           v[q] = lo | (hi << 16);
         }
         const bf16x8 bq = __builtin_bit_cast(bf16x8, v);
@@ -472,7 +482,7 @@ extern "C" hd_status hd_stem_conv_wgrad_partial(const void* dy, int64_t dy_row_s
   if (workspace_bytes < (size_t)p.wgs * Cout * 108 * sizeof(float)) return HD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int Wo16 = (W / 2 + 31) / 32 * 32;
-  size_t lds = (size_t)kRing * ring_row_bytes(W) + (size_t)Wo16 * (Cout * 2 + 64);
+  size_t lds = (size_t)kRing * ring_row_bytes(W) + (size_t)Wo16 * (Cout == 32 ? 64 : Cout * 2 + 64);
   if (lds < (size_t)Cout * 160 * sizeof(float)) lds = (size_t)Cout * 160 * sizeof(float);  // the fold area
   const auto* g = static_cast<const unsigned short*>(dy);
   float* slab = static_cast<float*>(workspace);

@@ -114,6 +114,7 @@ class ConvBNAct(nn.Module):
     # (hd_conv3x3_wgrad) does not depend on this switch.
     conv3x3_forward = True
     stem = True  # the 6x6 / stride 2 stem on csrc/stem_conv.hip (forward + statistics, weight gradient)
+    fork_shortcut = True  # a shortcut's gradient is added inside the bypassed 1x1 convolution's data-gradient kernel
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act="silu"):
         super().__init__()
@@ -126,13 +127,14 @@ class ConvBNAct(nn.Module):
         """How this layer's convolution runs on `x` in training (see pointwise_mode below)."""
         return pointwise_mode(self.conv, self.bn, x) if self.fused else 0
 
-    def forward(self, x, residual=None, out=None):
+    def forward(self, x, residual=None, out=None, fork=False):
         """residual: added after the activation inside the fused kernel (the YOLOv5 bottleneck shortcut).
-        out: a CatBuffer slot for the result (see FusedBNAct.apply)."""
+        out: a CatBuffer slot for the result (see FusedBNAct.apply).  fork: see conv_bn_act."""
         if self.fused:
-            return conv_bn_act(self.conv, self.bn, self.act_name, x, residual, True, out)
+            return conv_bn_act(self.conv, self.bn, self.act_name, x, residual, True, out, fork)
         y = self.act(self.bn(self.conv(x)))
-        return y if residual is None else y + residual
+        y = y if residual is None else y + residual
+        return (y, x) if fork else y
 
 
 def pointwise_mode(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> int:
@@ -155,9 +157,22 @@ def pointwise_mode(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> int:
     return 1 if ops.pointwise_backward_usable(x, w) else 0
 
 
-def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, residual_after_act: bool = False, out=None):
+def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, residual_after_act: bool = False, out=None,
+                fork: bool = False):
     """Conv2d(bias=False) -> BatchNorm2d -> activation [-> / <- residual] on the fused HIP kernels: the 1x1 convolutions on
-    csrc/pointwise_conv.hip where pointwise_mode says so, the BatchNorm + activation always (FusedBNAct.apply)."""
+    csrc/pointwise_conv.hip where pointwise_mode says so, the BatchNorm + activation always (FusedBNAct.apply).
+    fork: return (result, x') where x' stands for x in a shortcut around this layer: on the one-node 1x1 path x' is an alias
+    whose gradient is added inside the layer's data-gradient kernel (ops._PwConvBNActFn), elsewhere it is x itself."""
+    if fork:
+        if pointwise_mode(conv, bn, x) and FusedBNAct.sync_group is None and x.dtype == torch.bfloat16 and x.requires_grad:
+            from . import ops
+            w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+            w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+            if ops.bn_act_supported(_like_conv_out(x, w)):
+                return ops.pointwise_conv_bn_act(x, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act,
+                                                 FusedBNAct.slot_of(bn, x.device), residual, residual_after_act, out,
+                                                 pointwise_mode(conv, bn, x) == 2, True)
+        return conv_bn_act(conv, bn, act, x, residual, residual_after_act, out), x
     mode = pointwise_mode(conv, bn, x)
     if mode:
         from . import ops
@@ -241,7 +256,11 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x, out=None):
-        # the shortcut add rides in the second conv's fused BN+activation kernel
+        # the shortcut add rides in the second conv's fused BN+activation kernel, and (backward) the shortcut's gradient in
+        # the first convolution's data-gradient kernel
+        if self.add and ConvBNAct.fork_shortcut:
+            h, xs = self.cv1(x, None, None, True)
+            return self.cv2(h, xs, out)
         return self.cv2(self.cv1(x), x if self.add else None, out)
 
 
@@ -321,9 +340,20 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, e=1.0) for _ in range(n))
 
     def forward(self, x):
-        y = list(self.cv1(x).chunk(2, 1))
-        y.extend(m(y[-1]) for m in self.m)
-        return self.cv2(torch.cat(y, 1))
+        c, n = self.c, len(self.m)
+        cb = cat_buffer(x, (c,) * (2 + n), x.shape[2:])
+        if cb is None:
+            y = list(self.cv1(x).chunk(2, 1))
+            y.extend(m(y[-1]) for m in self.m)
+            return self.cv2(torch.cat(y, 1))
+        # every part is written straight into its slice of the concatenation: cv1's fused BN+act puts its two halves into
+        # slots 0 and 1 (one launch, an output in two places), bottleneck k's last kernel writes slot 2 + k, and join() copies
+        # nothing — a torch.cat of a 384-channel 208 x 208 map is a 1 GB read + write at 832^2 bs16 (FasterRCNN PAFPN)
+        y = self.cv1(x, None, (cb.slot(0), cb.slot(1)))
+        parts = list(y) if isinstance(y, tuple) else list(y.chunk(2, 1))
+        for k, m in enumerate(self.m):
+            parts.append(m(parts[-1], cb.slot(2 + k)))
+        return self.cv2(cb.join(parts))
 
 
 class SPPF(nn.Module):

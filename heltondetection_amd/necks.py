@@ -12,6 +12,16 @@ from .layers import C2f, C3, ConvBNAct, ShadowConv2d, cat_buffer, make_drop_bloc
 from .registry import NECKS
 
 
+def up_cat(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+    """cat(upsample2x(small), big) along channels: one HIP gather into the bf16 concatenation (ops.upsample2x_cat) instead
+    of a float32 nearest upsample, a promoting torch.cat and the casts back; other shapes / devices take the torch ops."""
+    if ConvBNAct.fused and small.is_cuda:
+        from . import ops
+        if ops.upsample2x_cat_supported(small, big):
+            return ops.upsample2x_cat(small, big)
+    return torch.cat((F.interpolate(small, size=big.shape[-2:], mode="nearest"), big), 1)
+
+
 @NECKS.register()
 class YOLOv5PAFPN(nn.Module):
     """v6.1 head layers 10-23: top-down + bottom-up over (P3, P4, P5)."""
@@ -40,15 +50,7 @@ class YOLOv5PAFPN(nn.Module):
             return torch.cat((down(x), lateral), 1)
         return cb.join((down(x, None, cb.slot(0)), lateral))
 
-    @staticmethod
-    def _up_cat(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
-        """cat(upsample2x(small), big): one HIP gather into the bf16 concatenation (ops.upsample2x_cat) instead of a
-        float32 upsample, a promoting torch.cat and the casts back."""
-        if ConvBNAct.fused and small.is_cuda:
-            from . import ops
-            if ops.upsample2x_cat_supported(small, big):
-                return ops.upsample2x_cat(small, big)
-        return torch.cat((F.interpolate(small, scale_factor=2.0, mode="nearest"), big), 1)
+    _up_cat = staticmethod(lambda small, big: up_cat(small, big))
 
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         p3, p4, p5 = feats
@@ -111,11 +113,11 @@ class PAFPN(nn.Module):
         td = [None] * L
         td[L - 1] = lat[L - 1]
         for i in range(L - 2, -1, -1):
-            up = F.interpolate(td[i + 1], size=lat[i].shape[-2:], mode="nearest")
-            td[i] = self.td[i](torch.cat((up, lat[i]), 1))
+            td[i] = self.td[i](up_cat(td[i + 1], lat[i]))   # upsample + concatenation as one gather
         outs = [td[0]]
         for i in range(1, L):
-            outs.append(self.bu[i - 1](torch.cat((self.down[i - 1](outs[-1]), td[i]), 1)))
+            # the strided convolution's fused BN+act writes its half of the concatenation in place
+            outs.append(self.bu[i - 1](YOLOv5PAFPN._down_cat(self.down[i - 1], outs[-1], td[i])))
         outs = [self.drop(o) for o in outs]
         if self.p2_only:
             return outs[:1]

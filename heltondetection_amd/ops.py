@@ -1058,9 +1058,12 @@ def _bn_bwd_struct(st: "_BNState", y_raw: torch.Tensor, g_: "_BNGrad", dg: Optio
     return bn
 
 
-def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None, bn=None, dy_tail=None) -> torch.Tensor:
+def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None, bn=None, dy_tail=None,
+                         add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx[B, Cin, H, W] = dy[B, Cout, H, W] . w2[Cout, Cin] on channels-last rows, no autograd; Cout in {32, 64, 128, 256}.
-    bn / dy_tail: as for pointwise_wgrad_rows (dy is d(out) of a fused BatchNorm + activation, possibly in two places)."""
+    bn / dy_tail: as for pointwise_wgrad_rows (dy is d(out) of a fused BatchNorm + activation, possibly in two places).
+    add: bf16 channels-last rows [B, Cin, H, W] summed into the result in the kernel's epilogue (the gradient that reaches
+    the same input through a shortcut) — float32 add of the two bf16 values, one rounding, like a separate bf16 add."""
     lib = _lib.load()
     B, _, H, W = dy.shape
     N = w2.shape[0]
@@ -1076,6 +1079,14 @@ def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
     _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K) + (2 * B * H * W * N if bn is not None else 0),
                 {"flops": 2 * B * H * W * K * N})
+    if add is not None:
+        ld_add = _cl_row_stride(add, 8)
+        if bn is not None or ld_add is None or add.dtype != torch.bfloat16 or tuple(add.shape) != (B, K, H, W):
+            raise _lib.HdError("pointwise_dgrad: `add` must be bf16 channels-last rows of the result's shape (not with bn)")
+        with _ktimed("pointwise_dgrad"):
+            check(lib.hd_pointwise_conv_dgrad_add(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(add), int(ld_add), _ptr(out),
+                                                  int(ld_dx), _stream(dy)), "hd_pointwise_conv_dgrad_add")
+        return out
     with _ktimed("pointwise_dgrad"):
         if bn is not None:
             check(lib.hd_pointwise_conv_dgrad_bn(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
@@ -1570,7 +1581,11 @@ class _PwConvBNActFn(torch.autograd.Function):
     take (pre-activation residual, SyncBN, channel counts outside the kernels' range) run the unfused chain in here."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, slot, res, res_mode, out_slot, ours_fwd):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, slot, res, res_mode, out_slot, ours_fwd,
+                fork):
+        """fork: also return an alias of x (last output).  A shortcut that takes THAT tensor instead of x sends its gradient
+        through this node, whose data-gradient kernel adds it in its epilogue (hd_pointwise_conv_dgrad_add) — otherwise the
+        autograd engine sums the two gradients of x with a launch of its own."""
         N, K = weight.shape[0], weight.shape[1]
         if ours_fwd:   # the epilogue leaves the batch statistics in the slot
             y_raw = pointwise_conv_rows(x, weight.view(N, K), _fwd_sums(slot, N))
@@ -1581,12 +1596,22 @@ class _PwConvBNActFn(torch.autograd.Function):
                                 out_slot, bool(ours_fwd))
         ctx.save_for_backward(x, weight, y_raw)
         ctx.st = st
-        return y if y2 is None else (y, y2)
+        ctx.fork = bool(fork)
+        outs = (y,) if y2 is None else (y, y2)
+        if fork:
+            outs = outs + (x.view_as(x),)
+        return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
-    def backward(ctx, dout, dout2=None):
+    def backward(ctx, *grads):
         x, weight, y_raw = ctx.saved_tensors
         st = ctx.st
+        d_skip = None
+        if ctx.fork:
+            grads, d_skip = grads[:-1], grads[-1]
+        dout, dout2 = grads[0], (grads[1] if len(grads) > 1 else None)
+        if d_skip is not None and (d_skip.dtype != torch.bfloat16 or _cl_row_stride(d_skip, 8) is None or d_skip.shape != x.shape):
+            d_skip = d_skip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, K = weight.shape[0], weight.shape[1]
         R = x.shape[0] * x.shape[2] * x.shape[3]
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -1601,14 +1626,17 @@ class _PwConvBNActFn(torch.autograd.Function):
             bn = _bn_bwd_struct(st, y_raw, g_, dg)
             dw = pointwise_wgrad_rows(g_.dy, x, bn, g_.tail, N, weight).view(N, K, 1, 1)
             dx = pointwise_dgrad_rows(g_.dy, weight.view(N, K), None, bn, g_.tail) if need_dx else None
+            if dx is not None and d_skip is not None:
+                dx = dx + d_skip
             gres = g_.dy if st.res_mode == 2 else None
-            return dx, dw, dg[1], dg[0], None, None, None, None, None, None, gres, None, None, None
+            return dx, dw, dg[1], dg[0], None, None, None, None, None, None, gres, None, None, None, None
         dy, dgamma, dbeta, gres = _bn_backward_dx(st, y_raw, g_)
         dx = dw = None
         if need_dw and ours_dw:
             dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
         if need_dx and ours_dx:
-            dx = pointwise_dgrad_rows(dy, weight.view(N, K))
+            dx = pointwise_dgrad_rows(dy, weight.view(N, K), add=d_skip)   # the shortcut's gradient rides in the epilogue
+            d_skip = None
         lib_w, lib_x = need_dw and dw is None, need_dx and dx is None
         if lib_w or lib_x:
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
@@ -1616,16 +1644,20 @@ class _PwConvBNActFn(torch.autograd.Function):
                                                             (lib_x, lib_w, False))
             dw = gw if lib_w else dw
             dx = gi if lib_x else dx
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, gres, None, None, None
+        if dx is not None and d_skip is not None:
+            dx = dx + d_skip
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, gres, None, None, None, None
 
 
 def pointwise_conv_bn_act(x, weight, gamma, beta, running_mean, running_var, eps: float, momentum: float, act: str,
-                          slot: "_StatSlot", residual=None, residual_after_act: bool = False, out=None, ours_forward: bool = True):
+                          slot: "_StatSlot", residual=None, residual_after_act: bool = False, out=None, ours_forward: bool = True,
+                          fork: bool = False):
     """conv1x1(x, weight) -> BatchNorm2d (training) -> activation [+ residual] on the HIP kernels, one autograd node (see
-    _PwConvBNActFn).  x: bf16 channels-last rows, weight: bf16 [Cout, Cin, 1, 1]; out as for bn_act."""
+    _PwConvBNActFn).  x: bf16 channels-last rows, weight: bf16 [Cout, Cin, 1, 1]; out as for bn_act.
+    fork: returns (result, x_alias) — hand x_alias to the shortcut that bypasses this layer."""
     return _PwConvBNActFn.apply(x, weight, gamma, beta, running_mean, running_var, eps, momentum, _ACT_CODE[act], slot, residual,
                                 (2 if residual_after_act else 1) if residual is not None else 0,
-                                _OutSlot(out) if out is not None else None, bool(ours_forward))
+                                _OutSlot(out) if out is not None else None, bool(ours_forward), bool(fork))
 
 
 def bn_act_slot(device, channels: int) -> _StatSlot:

@@ -465,6 +465,12 @@ typedef struct hd_wgrad_job {
 } hd_wgrad_job;
 hd_status hd_wgrad_reduce(const hd_wgrad_job* job, hd_stream stream);
 
+/* hd_pointwise_conv_dgrad whose result is ADDED to `add` (bfloat16 rows [R, Cin], add_row_stride elements, 0 = dense)
+ * before it is stored: dx = dy . w + add, the two bfloat16 values summed in float32 and rounded once — the gradient of a
+ * layer input that also feeds a shortcut, without the separate add launch.  dx may alias add. */
+hd_status hd_pointwise_conv_dgrad_add(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout,
+                                      const void* add, int64_t add_row_stride, void* dx, int64_t dx_row_stride,
+                                      hd_stream stream);
 /* hd_pointwise_conv_dgrad with the fused BatchNorm backward: dx[R, Cin] = dy[R, Cout] . w, dy formed from dout / bn. */
 hd_status hd_pointwise_conv_dgrad_bn(const void* dout, int64_t dout_row_stride, const hd_rows2* dout_tail, const hd_bn_bwd* bn,
                                      const void* w, int64_t R, int Cin, int Cout, void* dx, int64_t dx_row_stride,

@@ -398,3 +398,53 @@ def test_chained_weight_gradient_sums_ride_in_the_next_launch():
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert torch.equal(got3, ref3)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (3, 128, 13, 11, 128), (2, 256, 10, 10, 64), (1, 64, 40, 40, 256)])
+def test_pointwise_dgrad_with_the_shortcut_gradient_added_in_the_epilogue(shape):
+    """hd_pointwise_conv_dgrad_add == hd_pointwise_conv_dgrad followed by a bf16 add (float32 sum of the two bf16 values, one
+    rounding), bit for bit; also with the result written over the addend."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K * N + H)
+    dy = torch.randn((B, N, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((N, K), generator=g) * N ** -0.5).to(dev).to(torch.bfloat16)
+    r = torch.randn((B, K, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    plain = ops.pointwise_dgrad_rows(dy, w)
+    want = (plain.float() + r.float()).to(torch.bfloat16)
+    got = ops.pointwise_dgrad_rows(dy, w, add=r)
+    assert torch.equal(got, want)
+    r2 = r.clone()
+    ops.pointwise_dgrad_rows(dy, w, out=r2, add=r2)
+    assert torch.equal(r2, want)
+
+
+@pytest.mark.parametrize("c,hw", [(64, 20), (128, 13)])
+def test_bottleneck_shortcut_gradient_through_the_fork_matches_autograd_add(c, hw):
+    """layers.Bottleneck with the shortcut: the gradient of the block input is cv1's data gradient + the shortcut's gradient,
+    summed inside the data-gradient kernel (fork) or by the autograd engine — same values up to the float atomics of the
+    BatchNorm sums."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = layers.Bottleneck(c, c, True, e=1.0).to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((3, c, hw, hw), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((3, c, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.fork_shortcut = on
+        try:
+            m.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            (y.float() * gy).sum().backward()
+            ops.flush_wgrad()
+            res[on] = (y.detach().float(), x.grad.float(), m.cv1.conv.weight.grad.float().clone(), m.cv2.conv.weight.grad.float().clone())
+        finally:
+            layers.ConvBNAct.fork_shortcut = True
+    for a, b in zip(res[True], res[False]):   # two runs: the BatchNorm sums' float atomics differ in their last bits
+        tol = 2.0 ** -6 * b.abs() + 2.0 ** -8 * b.abs().mean() + 1e-7
+        assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
