@@ -144,20 +144,39 @@ def loss_bwd_bytes(B, size, no, na=3, strides=(8, 16, 32)):
     return 4 * B * n * no + 4 * B * n
 
 
-def pmc_traffic(kernel, shape: str):
-    """HBM bytes per launch of `kernel` from the committed counter run of this round (profiles/r02_pmc_traffic.json,
-    made by tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled for 16-byte
-    streams as MI355X_MICROARCH.md prescribes) when it was taken on exactly `shape`; None otherwise.  PMC counters
-    cannot be read from inside this process, so this is a look-up, and the JSON line says so (traffic_source)."""
+def pmc_traffic(kernel, shape: str = ""):
+    """HBM bytes from the committed counter run of this round (profiles/r03_pmc_traffic.json, made by tools/prof_r03.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager train steps of the final build, FETCH doubled for
+    16-byte streams as MI355X_MICROARCH.md prescribes).  `kernel`: a family name of that file ("hand-written convolutions",
+    "fused BN+act") -> bytes per train step; or a kernel-name fragment -> bytes per launch of the first kernel whose name
+    contains it.  None when the file has no such entry (other model / size: the counter run is YOLOv5s 640^2 bs16).  PMC
+    counters cannot be read from inside this process, so this is a look-up, and the JSON line says so (traffic_source)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        fam = rec.get("families_per_step", {}).get(kernel)
+        if fam is not None:
+            return int(fam["traffic_bytes_per_step"])
+        for name, v in rec.get("kernels", {}).items():
+            if kernel in name:
+                return int(v["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager YOLOv5s 640x640 " \
+                 "bs16 train steps of this build, tools/prof_r03.sh; families: bytes per train step, single kernels: bytes per launch; " \
+                 "null = no entry for this workload)"
+
+
+def pmc_traffic_r02(kernel, shape: str):
+    """Round-2 counter run (profiles/r02_pmc_traffic.json), for the kernels that have not changed since: bytes per launch
+    when it was taken on exactly `shape`."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[kernel]
         return rec["traffic_bytes"] if rec.get("shape") == shape else None
     except Exception:
         return None
-
-
-TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json (committed rocprofv3 --pmc run of tools/pmc_traffic.sh on this shape; " \
-                 "null = no committed counter run for this shape)"
 
 
 def usable_cores() -> int:
@@ -404,7 +423,7 @@ def _conv_kernel_entry(name, ms, nbytes, calls, flops):
             "frac": round(tfs / MFMA_PEAK_TFLOPS, 4) if mfma else round(gbs / HBM_PEAK_GBS, 4)}
 
 
-def bn_family_roofline(model, batch, args, device):
+def bn_family_roofline(model, batch, args, device, trainer=None):
     """Step-weighted roofline of the fused BN+act kernels, measured IN the train step: three eager forward + loss +
     backward passes of this workload with every fused-BN launch stamping its own HIP event pair (kernel begin / end,
     hd_debug_time_next_launch), so each kernel is timed on its real tensors in its real cache state (x fresh from the
@@ -414,7 +433,7 @@ def bn_family_roofline(model, batch, args, device):
     from heltondetection_amd import ops
     names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
     pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad",
-                "stem_conv_fwd", "stem_conv_wgrad")
+                "stem_conv_fwd", "stem_conv_wgrad", "wgrad_reduce")
     passes, per_pass, notes, tags = 3, [], None, None
     try:
         for it in range(passes + 1):  # the first pass warms up
@@ -422,9 +441,15 @@ def bn_family_roofline(model, batch, args, device):
             ops.bn_arena_reset(device)
             if it >= 1:
                 ops.enable_timing(*names, *pw_names)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
-                loss, _ = model.forward_train(*batch)
-            loss.backward()
+            if trainer is not None:
+                # exactly the step's forward + loss + backward (bf16 weight shadows, slice sums riding in the next
+                # weight-gradient launch), run eagerly so that every launch can stamp its event pair
+                trainer._fwd_bwd(*batch)
+            else:
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+                    loss, _ = model.forward_train(*batch)
+                loss.backward()
+                ops.flush_wgrad()
             torch.cuda.synchronize()
             if it >= 1:
                 per_pass.append({k: v for k, v in ops.collect_timing().items()})
@@ -471,7 +496,8 @@ def bn_family_roofline(model, batch, args, device):
                                      "us_per_launch": {k.replace("bn_", "").replace("_kernel", ""):
                                                        (round(e["us"][k] / e["n"][k], 2) if e["n"][k] else None) for k in names}}
                                     for tag, e in by_shape.items()]},
-                     traffic=pmc_traffic("bn_family_step", f"{model_name(args)} {args.size} bs{args.batch}"))
+                     traffic=pmc_traffic("fused BN+act") if (args.model == "yolov5" and args.size == 640 and args.batch == 16
+                                                             and args.variant == "s" and not args.fp32) else None)
     # the hand-written 1x1 convolution kernels of the same passes (csrc/pointwise_conv.hip), step-weighted likewise
     pw = None
     if any(len(per_pass[0].get(k, ())) for k in pw_names):
@@ -486,11 +512,16 @@ def bn_family_roofline(model, batch, args, device):
                         {"sum_launch_ms_per_step": round(sum(pms.values()), 4), "algorithmic_bytes_per_step": int(sum(pby.values())),
                          "algorithmic_bytes": "2 (R (Cin + Cout) + taps Cin Cout) per call: each operand once, bf16 (the 3x3 "
                                               "kernels are MFMA / LDS bound, their HBM fraction is reported for completeness)",
-                         "timed": "same passes and event mechanism as the BN family; the weight-gradient entries are event pairs "
-                                  "around their launches (row-sliced partial products + slice sum; outside the Trainer's step the sum "
-                                  "is launched at once, inside it rides in the next weight-gradient launch)",
+                         "timed": "same passes and event mechanism as the BN family (kernel begin / end per launch); the weight-gradient "
+                                  "launches carry the slice sum of the previous one as in the Trainer's step, `wgrad_reduce` = the "
+                                  "few slice sums launched on their own",
                          "per_kernel": {k: _conv_kernel_entry(k, pms[k], pby[k], pn[k], sum((t or {}).get("flops", 0) for t in tags[k]))
                                         for k in pw_names}})
+    if pw is not None and args.model == "yolov5" and args.size == 640 and args.batch == 16 and args.variant == "s" and not args.fp32:
+        pw["traffic"] = pmc_traffic("hand-written convolutions")
+    for f_ in (fam, pw):
+        if f_ is not None:
+            f_["traffic_unit"] = "bytes per train step (compare with algorithmic_bytes_per_step)"
     fam["_pointwise"] = pw
     return fam
 
@@ -498,12 +529,12 @@ def bn_family_roofline(model, batch, args, device):
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec)
 
 
-def family_rooflines(model, batch, args, device):
+def family_rooflines(model, batch, args, device, trainer=None):
     """The hand-written kernel families of the step, largest summed launch time first: element 0 is the line's `roofline`
     (the DOMINANT family), the rest ride in `roofline_secondary`.  Every kernel of a family is also priced against its own
     bound in `per_kernel`: HBM bytes for the streaming kernels (1x1 convolutions, fused BN), MFMA FLOPs / 2.5 PFLOP/s for
     the 3x3 implicit-GEMM kernels."""
-    fam = bn_family_roofline(model, batch, args, device)
+    fam = bn_family_roofline(model, batch, args, device, trainer)
     pw = fam.pop("_pointwise", None)
     fams = [f for f in (fam, pw) if f]
     fams.sort(key=lambda f: -float(f.get("sum_launch_ms_per_step", 0.0)))
@@ -526,7 +557,7 @@ def yolo_dense_grad_roofline(model, batch, args):
     nbytes = loss_bwd_bytes(args.batch, args.size, args.classes + 5)
     return _hbm_entry("yolo_grad_dense_kernel (hd_yolo_loss_bwd_dense)", k_ms * len(ms_list), nbytes * len(ms_list), len(ms_list),
                       {"timed": "every launch stamps its own HIP event pair (kernel begin / end) on this workload's head outputs"},
-                      traffic=pmc_traffic("yolo_grad_dense_kernel", f"bs{args.batch} {args.size} no{args.classes + 5}"))
+                      traffic=pmc_traffic("yolo_grad_dense_kernel") if (args.size == 640 and args.batch == 16 and args.classes == 80) else None)
 
 
 def roi_touched_elements(rois5, feats, scales, k_min, n_levels):
@@ -598,7 +629,7 @@ def roi_align_roofline(model, batch, args, device):
                                       "roi_align_bwd_cl_kernel": {"ms": round(b_ms, 4), "GB/s": round(b_bytes / b_ms / 1e6, 1),
                                                                   "frac": round(b_bytes / b_ms / 1e6 / HBM_PEAK_GBS, 4),
                                                                   "bound": "float-atomic rate (~1.3 TB/s of added bytes chip-wide)"}}},
-                      traffic=pmc_traffic("roi_align_step", shape))
+                      traffic=pmc_traffic_r02("roi_align_step", shape))
     return main
 
 
@@ -801,11 +832,11 @@ def main():
             if args.no_roofline:
                 out["roofline"] = None
             elif args.model == "yolov5":
-                fams = family_rooflines(model, batches[0], args, device)
+                fams = family_rooflines(model, batches[0], args, device, trainer)
                 out["roofline"], rest = fams[0], fams[1:]
                 out["roofline_secondary"] = rest + [yolo_dense_grad_roofline(model, batches[0], args)]
             else:
-                fams = family_rooflines(model, batches[0], args, device)
+                fams = family_rooflines(model, batches[0], args, device, trainer)
                 out["roofline"] = fams[0]
                 out["roofline_secondary"] = fams[1:] + [roi_align_roofline(model, batches[0], args, device)]
         except Exception as e:  # never lose the headline number to a secondary measurement
@@ -819,7 +850,8 @@ def main():
                             {"kernel": k["kernel"], "bound": "hbm", "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": k["frac_of_8TB/s"], "shape": k["shape"], "avg_launch_ms": k["ms"],
                              "algorithmic_bytes_per_launch": int(k["algorithmic_MB"] * 1e6), "traffic":
-                                 pmc_traffic("pairwise_iou_cols_kernel", k["shape"]), "traffic_source": TRAFFIC_SOURCE})
+                                 pmc_traffic_r02("pairwise_iou_cols_kernel", k["shape"]),
+                             "traffic_source": "profiles/r02_pmc_traffic.json (the kernel is unchanged since that counter run)"})
             except Exception as e:  # the headline number must survive a micro-leg problem
                 out["kernels_error"] = repr(e)
         # Companion legs (N = 1, default workload only): the same step without autocast, and at 832^2 (north_star names

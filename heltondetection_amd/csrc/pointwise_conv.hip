@@ -658,13 +658,19 @@ template <int W>
 __global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                             const unsigned short* __restrict__ X, long long ld_x, int B, int H,
                                                             int N, int K, int rows_per_slice, int images_per_slice,
-                                                            float* __restrict__ slab) {
+                                                            float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
+  __shared__ float4 s_part[16][17];
   constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
   constexpr int SX = 64 * 2 + 64;                 // bytes per pixel row of a 64-channel tile, padded
   constexpr int XROW = (WP + 2) * SX, DYROW = WP * SX;
   constexpr int CH = W * 8;                       // 16-byte chunks per image row of a 64-channel tile
   constexpr int IT = (CH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 X rows | dY row]
+  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
+    if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
+    return;
+  }
   unsigned char* xs = smem;
   unsigned char* ys = smem + 3 * XROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -778,13 +784,19 @@ template <int W>
 __global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
                                                               const unsigned short* __restrict__ X, long long ld_x, int B, int H,
                                                               int N, int K, int rows_per_slice, int images_per_slice,
-                                                              float* __restrict__ slab) {
+                                                              float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
+  __shared__ float4 s_part[16][17];
   constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
   constexpr int SX = 64 * 2 + 64;
   constexpr int PLANE = (WP + 2) * SX, XROW = 2 * PLANE, DYROW = WP * SX;
   constexpr int CHX = 2 * W * 8, CHY = W * 8;  // 16-byte chunks per input row / per dY row of a 64-channel tile
   constexpr int ITX = (CHX + 255) / 256, ITY = (CHY + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 input rows (E | O planes) | dY row]
+  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
+    if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
+    return;
+  }
   unsigned char* xs = smem;
   unsigned char* ys = smem + 3 * XROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1378,10 +1390,11 @@ extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin,
   return (size_t)wgrad3_plan(B, H, Cin, Cout).slices * Cout * 9 * Cin * sizeof(float);
 }
 
-extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
-                                      int W, int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes,
-                                      hd_stream stream) {
-  if (!dy || !x || !dw || !workspace) return HD_ERR_NULL;
+extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B,
+                                              int H, int W, int Cin, int Cout, int stride, void* dw, void* workspace,
+                                              size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
+                                              hd_stream stream) {
+  if (!dy || !x || !dw || !workspace || !job_out) return HD_ERR_NULL;
   if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return HD_ERR_SHAPE;
   if (dy_row_stride == 0) dy_row_stride = Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
@@ -1389,21 +1402,24 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
   const Wgrad3Plan p = wgrad3_plan(B, H, Cin, Cout);
   if (workspace_bytes < (size_t)p.slices * Cout * 9 * Cin * sizeof(float)) return HD_ERR_WORKSPACE;
+  hdfuse::ReduceJob jv;
+  const hd_status js = make_job_view(piggyback, &jv);
+  if (js != HD_OK) return js;
   hipStream_t s = (hipStream_t)stream;
   const auto* a = static_cast<const unsigned short*>(dy);
   const auto* b = static_cast<const unsigned short*>(x);
   float* slab = static_cast<float*>(workspace);
-  const dim3 grid((unsigned)p.tiles, (unsigned)p.slices);
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.slices + piggyback_rows(jv, (unsigned)p.tiles));
   const int WP = (W + 15) / 16 * 16;
   const size_t lds = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
 #define HD_WGRAD3_CASE(WW)                                                                                              \
   case WW:                                                                                                              \
     if (stride == 2)                                                                                                    \
       (void)hd_launch(conv3x3s2_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, \
-                      p.rows_per_slice, p.images_per_slice, slab);                                                      \
+                      p.rows_per_slice, p.images_per_slice, slab, p.slices, jv);                                       \
     else                                                                                                                \
       (void)hd_launch(conv3x3_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,   \
-                      p.rows_per_slice, p.images_per_slice, slab);                                                      \
+                      p.rows_per_slice, p.images_per_slice, slab, p.slices, jv);                                       \
     break;
   switch (W) {
     HD_WGRAD3_CASE(20)
@@ -1416,8 +1432,20 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   }
 #undef HD_WGRAD3_CASE
   HD_RETURN_IF_LAUNCH_FAILED();
-  hd_wgrad_job job = {slab, p.slices, (int64_t)Cout * 9 * Cin, dw};
-  return hd_wgrad_reduce(&job, stream);
+  job_out->slab = slab;
+  job_out->slices = p.slices;
+  job_out->count = (int64_t)Cout * 9 * Cin;
+  job_out->dw = dw;
+  return HD_OK;
+}
+
+extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
+                                      int W, int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes,
+                                      hd_stream stream) {
+  hd_wgrad_job job;
+  const hd_status st = hd_conv3x3_wgrad_partial(dy, dy_row_stride, x, x_row_stride, B, H, W, Cin, Cout, stride, dw, workspace,
+                                                workspace_bytes, nullptr, &job, stream);
+  return st != HD_OK ? st : hd_wgrad_reduce(&job, stream);
 }
 
 extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {

@@ -989,6 +989,14 @@ class _WgradChain:
             pair[t] = buf
         return buf
 
+    @staticmethod
+    def _reduce_now(job, device) -> None:
+        """The slice sum as a launch of its own (noted for bench.py's per-launch rooflines: slab in, bf16 gradient out)."""
+        _note_bytes("wgrad_reduce", int(job.slices) * int(job.count) * 4 + int(job.count) * 2, {"flops": int(job.slices) * int(job.count)})
+        with _ktimed("wgrad_reduce"):
+            check(_lib.load().hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                  "hd_wgrad_reduce")
+
     @classmethod
     def piggyback(cls, device):
         """The pending job of `device` (to ride in the launch being prepared), or None."""
@@ -997,29 +1005,29 @@ class _WgradChain:
 
     @classmethod
     def submit(cls, device, job, keep, leaf=None) -> None:
-        """`job` (a filled WgradJob) has been launched: chain it, or sum it right away outside a training step."""
-        if cls.enabled:
+        """`job` (a filled WgradJob) has been launched: chain it, or sum it right away.  Chained only inside a training step
+        AND when the gradient goes to an autograd LEAF (the bf16 weight shadow): AccumulateGrad takes a leaf's first gradient
+        as it is and nothing reads it before the bucket is packed; a non-leaf weight (autocast's cast of a float32 master)
+        has its gradient cast back by the very next autograd node, which must see the finished sum."""
+        if cls.enabled and leaf is not None and leaf.is_leaf:
             cls._pending[cls._key(device)] = (job, keep)
             if leaf is not None:
                 import weakref
                 cls._handed.append((weakref.ref(leaf), int(job.dw)))
         else:
-            check(_lib.load().hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "hd_wgrad_reduce")
+            cls._reduce_now(job, device)
 
     @classmethod
     def flush_device(cls, device) -> None:
         """Sum the pending job of one device now (a launch that cannot carry it is about to use the stream)."""
         pend = cls._pending.pop(cls._key(device), None)
         if pend is not None:
-            check(_lib.load().hd_wgrad_reduce(C.byref(pend[0]), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
-                  "hd_wgrad_reduce")
+            cls._reduce_now(pend[0], device)
 
     @classmethod
     def flush(cls) -> None:
-        lib = _lib.load()
         for key, (job, keep) in list(cls._pending.items()):
-            dev = torch.device(key[0], key[1])
-            check(lib.hd_wgrad_reduce(C.byref(job), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "hd_wgrad_reduce")
+            cls._reduce_now(job, torch.device(key[0], key[1]))
         cls._pending.clear()
         # a chained gradient is complete only after the launch that carried its sum: autograd must have taken the returned
         # tensor as it is (AccumulateGrad steals a fresh dense gradient); a copy taken earlier would hold unsummed bytes
@@ -1128,12 +1136,12 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
     job = _lib.WgradJob()
     # fused: d(out) and y are read where dy was
     _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K) + (2 * R * N if bn is not None else 0), {"flops": 2 * R * K * N})
-    with _timed("pointwise_wgrad"):
+    with _ktimed("pointwise_wgrad"):
         check(lib.hd_pointwise_wgrad_partial(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
                                              C.byref(bn) if bn is not None else None, _ptr(x), int(ld_x), R, K, N, _ptr(dw),
                                              _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
                                              _stream(dy)), "hd_pointwise_wgrad_partial")
-        _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
+    _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
     return dw
 
 
@@ -1146,7 +1154,8 @@ def conv3x3_wgrad_supported(x: torch.Tensor, cout: int, stride: int = 1) -> bool
     return bool(_lib.load().hd_conv3x3_wgrad_supported(B, H // stride, W // stride, K, int(cout), int(stride)))
 
 
-def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: Optional[torch.Tensor] = None,
+                       leaf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2: dy [B, Cout, H, W], x [B, Cin, stride H, stride W]
     bf16 channels-last rows -> dw [Cout, Cin, 3, 3] bf16 in channels-last memory ([Cout][ky][kx][Cin]); no autograd."""
     lib = _lib.load()
@@ -1163,10 +1172,14 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: 
     dw = out if out is not None else torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     if dw.dtype != torch.bfloat16 or tuple(dw.shape) != (N, K, 3, 3) or not dw.is_contiguous(memory_format=torch.channels_last):
         raise _lib.HdError("conv3x3_wgrad: `out` must be a channels-last bf16 [Cout, Cin, 3, 3] tensor")
+    pend = _WgradChain.piggyback(dy.device)
+    job = _lib.WgradJob()
     _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
-    with _timed("conv3x3_wgrad"):
-        check(lib.hd_conv3x3_wgrad(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
-                                   ws.numel(), _stream(dy)), "hd_conv3x3_wgrad")
+    with _ktimed("conv3x3_wgrad"):
+        check(lib.hd_conv3x3_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
+                                           ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job), _stream(dy)),
+              "hd_conv3x3_wgrad_partial")
+    _WgradChain.submit(dy.device, job, (ws,), leaf)
     return dw
 
 
@@ -1228,7 +1241,7 @@ class _Conv3x3Fn(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_wgrad_rows(g, x, st)
+            dw = conv3x3_wgrad_rows(g, x, st, leaf=weight)
         return dx, dw, None, None, None
 
 
@@ -1293,11 +1306,11 @@ def stem_conv_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, leaf: Optional[torch
     dw = torch.empty((N, 3, 6, 6), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     job = _lib.WgradJob()
     _note_bytes("stem_conv_wgrad", x.numel() * x.element_size() + dy.numel() * 2, {"flops": 2 * B * (H // 2) * (W // 2) * N * 108})
-    with _timed("stem_conv_wgrad"):
+    with _ktimed("stem_conv_wgrad"):
         check(lib.hd_stem_conv_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), 0 if x.dtype == torch.float32 else 1, B, H, W, N,
                                              _ptr(dw), _ptr(ws), ws.numel(), C.byref(job), _stream(dy)),
               "hd_stem_conv_wgrad_partial")
-        _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
+    _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
     return dw
 
 

@@ -527,6 +527,11 @@ int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int strid
 size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H, int W,
                            int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
+/* The same in its two halves (see hd_wgrad_job): partial products now, the slice sum by whoever runs *job_out; a pending
+ * job of an earlier call may ride along as `piggyback` (nullable). */
+hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
+                                   int W, int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes,
+                                   const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream);
 
 /* ---- nearest 2x upsampling + channel concatenation in one pass (csrc/upcat.hip) ----
  * The top-down junctions of the YOLOv5 PAFPN neck (README.md:9): out[b, y, x, :] = [small[b, y/2, x/2, :] | big[b, y, x, :]]

@@ -445,6 +445,8 @@ def test_bottleneck_shortcut_gradient_through_the_fork_matches_autograd_add(c, h
             res[on] = (y.detach().float(), x.grad.float(), m.cv1.conv.weight.grad.float().clone(), m.cv2.conv.weight.grad.float().clone())
         finally:
             layers.ConvBNAct.fork_shortcut = True
-    for a, b in zip(res[True], res[False]):   # two runs: the BatchNorm sums' float atomics differ in their last bits
-        tol = 2.0 ** -6 * b.abs() + 2.0 ** -8 * b.abs().mean() + 1e-7
+    # two runs: the BatchNorm sums' float atomics differ in their last bits, which moves single bf16 roundings of the
+    # operands; dx is a SUM of two gradients that partly cancel, so the floor is a rounding of a typical operand
+    for a, b in zip(res[True], res[False]):
+        tol = 2.0 ** -6 * b.abs() + 2.0 ** -6 * b.abs().mean() + 1e-7
         assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
