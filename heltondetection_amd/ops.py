@@ -1207,6 +1207,60 @@ def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Ten
     return y
 
 
+class FlippedWeights:
+    """The flipped, transposed copies hd_conv3x3_fwd needs as a data gradient (wt[c][ky][kx][n] = w[n][2-ky][2-kx][c]), rebuilt
+    for every registered weight by ONE launch at the head of a training step (hd_conv3x3_flip_weights) instead of a flip + a
+    permuting copy per layer in backward.  One instance per train.Trainer (it owns the buffers for as long as the trainer —
+    and any hipGraph captured from it — lives): built from the bf16 weight shadows of the model's 3x3 / stride 1 layers,
+    `refresh()` inside the step before forward (so a captured graph replays it), and `with flipped:` around forward +
+    backward makes it the one _Conv3x3Fn consults; outside that window the copy is built per call, so a stale one can never
+    be used."""
+
+    _current = None
+
+    def __init__(self, weights):
+        self.items = []
+        self.by_ptr = {}
+        for w in weights:
+            if not (w.is_cuda and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.bfloat16
+                    and w.is_contiguous(memory_format=torch.channels_last)):
+                continue
+            if len(self.items) >= 32:   # HD_MAX_FLIP
+                break
+            N, K = w.shape[0], w.shape[1]
+            wt = torch.empty((K, N, 3, 3), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
+            self.items.append((w, wt))
+            self.by_ptr[w.data_ptr()] = wt
+
+    def __len__(self):
+        return len(self.items)
+
+    def refresh(self) -> None:
+        if not self.items:
+            return
+        n = len(self.items)
+        src = (C.c_void_p * n)(*[w.data_ptr() for w, _ in self.items])
+        dst = (C.c_void_p * n)(*[t.data_ptr() for _, t in self.items])
+        cout = (C.c_int * n)(*[int(w.shape[0]) for w, _ in self.items])
+        cin = (C.c_int * n)(*[int(w.shape[1]) for w, _ in self.items])
+        dev = self.items[0][0].device
+        check(_lib.load().hd_conv3x3_flip_weights(n, src, dst, cout, cin, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+              "hd_conv3x3_flip_weights")
+
+    def __enter__(self):
+        self._prev, FlippedWeights._current = FlippedWeights._current, self
+        return self
+
+    def __exit__(self, *exc):
+        FlippedWeights._current = self._prev
+        return False
+
+    @classmethod
+    def get(cls, weight: torch.Tensor):
+        cur = cls._current
+        return cur.by_ptr.get(weight.data_ptr()) if cur is not None else None
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """3x3 / pad 1 convolution of stride 1 or 2.  Stride 1 with a supported shape: forward on hd_conv3x3_fwd (BatchNorm
     statistics into `slot` from its epilogue) and the data gradient on the same kernel with the flipped, transposed weights;
@@ -1235,7 +1289,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.ours and conv3x3_fwd_supported(g, x.shape[1]):
                 # dx = conv3x3(dy, wt) with wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]
-                wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+                wt = FlippedWeights.get(weight)   # rebuilt for all layers by one launch at the head of the step
+                if wt is None:
+                    wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
                 dx = conv3x3_fwd_rows(g, wt, None, name="conv3x3_dgrad")
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,

@@ -123,6 +123,16 @@ class Trainer:
         else:
             self.opt = torch.optim.AdamW(groups, lr=lr, betas=(0.937, 0.999), fused=self.device.type == "cuda")
         self._shadows_dirty = True  # the shadows start uninitialised; weights_changed() marks them stale again
+        # the 3x3 / stride 1 layers' data gradients run hd_conv3x3_fwd on flipped, transposed weights: one launch per step
+        # rebuilds them all from the bf16 shadows (ops.FlippedWeights)
+        self._flipped = None
+        if self.shadows is not None and self.device.type == "cuda":
+            from . import ops
+            ws = [m.weight_lp for m in model.modules() if isinstance(m, ShadowConv2d) and m.weight_lp is not None
+                  and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
+                  and m.in_channels % 64 == 0 and m.out_channels % 64 == 0]
+            fl = ops.FlippedWeights(ws)
+            self._flipped = fl if len(fl) else None
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: warmup_cosine(s, total_steps, warmup_steps))
         self._graph = None
         self._static = None
@@ -161,6 +171,9 @@ class Trainer:
             from . import ops
             chain = ops._WgradChain   # weight-gradient slice sums ride in the next weight-gradient launch (ops._WgradChain)
             chain.enabled = True
+            if self._flipped is not None:
+                self._flipped.refresh()
+                self._flipped.__enter__()
         try:
             with self.rand, torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=use_amp):
                 loss, parts = self.model.forward_train(images, gt_boxes, gt_cls, m_valid)
@@ -174,6 +187,8 @@ class Trainer:
             LowpWeights.on = False
             if chain is not None:
                 chain.enabled = False
+                if self._flipped is not None:
+                    self._flipped.__exit__()
         return loss.detach(), parts
 
     def _capture(self, batch):

@@ -523,6 +523,12 @@ hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int
  * H, W: the OUTPUT size; dy [B, H, W, Cout], x [B, stride H, stride W, Cin] bfloat16 rows (strides in elements, 0 = dense).
  * W in {20, 26, 40, 52, 80, 104}; Cin, Cout multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
  * workspace: hd_conv3x3_wgrad_workspace_bytes(...), 16-byte aligned, contents undefined on entry and exit. */
+/* The flipped, transposed weights hd_conv3x3_fwd takes as a data gradient, wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c], for up
+ * to HD_MAX_FLIP layers in ONE launch (w[l]: bfloat16 [Cout][3][3][Cin], wt[l]: bfloat16 [Cin][3][3][Cout]; the pointer and
+ * size arrays are host memory).  The weights change once per optimizer step: rebuild the copies at the head of the step. */
+#define HD_MAX_FLIP 32
+hd_status hd_conv3x3_flip_weights(int n_layers, const void* const* w, void* const* wt, const int* cout, const int* cin,
+                                  hd_stream stream);
 int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride);
 size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H, int W,

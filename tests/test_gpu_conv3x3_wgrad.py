@@ -107,3 +107,24 @@ def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
     dref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w.float(), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                (True, False, False))[0]
     assert torch.equal(dx.float(), dref.to(torch.bfloat16).float())
+
+
+def test_flipped_weights_of_all_layers_in_one_launch_equal_flip_permute():
+    """hd_conv3x3_flip_weights (ops.FlippedWeights): wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c] for a batch of layers with
+    different (ragged) channel counts, bit for bit what flip + permute + contiguous builds; consulted only inside `with`."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn((n, c, 3, 3), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+          for n, c in ((64, 64), (128, 64), (64, 256), (96, 40), (256, 256), (32, 33))]
+    fl = ops.FlippedWeights(ws)
+    assert len(fl) == len(ws)
+    fl.refresh()
+    assert ops.FlippedWeights.get(ws[0]) is None            # not active outside the window
+    with fl:
+        for w in ws:
+            got = ops.FlippedWeights.get(w)
+            want = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(got, want)
+    assert ops.FlippedWeights.get(ws[0]) is None
