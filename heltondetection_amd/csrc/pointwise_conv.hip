@@ -640,6 +640,85 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_kernel(const unsigned 
     }
 }
 
+// 32 x 32 tiles: channel counts that are multiples of 32 but not of 64 (the 32-channel layers of YOLOv5s at 160 x 160).  One
+// tile is one wave's MFMA, so the four waves split the 64-row stage along the REDUCTION instead (16 rows each) and fold their
+// partial tiles in LDS at the end; rows of 64 bytes need no padding for the transpose reads (four rows = four bank quarters).
+template <bool BNB>
+__global__ __launch_bounds__(256) void pointwise_wgrad32_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
+                                                                const unsigned short* __restrict__ X, long long ld_x, int M, int N,
+                                                                int K, int rows_per_split, float* __restrict__ slab, int n_splits,
+                                                                const hdfuse::BnBwd bn, const hdfuse::ReduceJob job) {
+  constexpr int ROWS = 64, SR = 64;  // bytes per LDS row of a 32-channel tile
+  __shared__ float4 s_part[16][17];
+  __shared__ float s_bn[BNB ? 4 * 32 : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char tY[ROWS * SR];
+  __shared__ __attribute__((aligned(16))) unsigned char tX[ROWS * SR];
+  __shared__ float s_red[4][32][33];
+  if ((int)blockIdx.y >= n_splits) {
+    const long long blk = (long long)(blockIdx.y - n_splits) * gridDim.x + blockIdx.x;
+    if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_k = K / 32;
+  const int n0 = (blockIdx.x / tiles_k) * 32, k0 = (blockIdx.x % tiles_k) * 32;
+  const int split = blockIdx.y;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int steps = m_end > m_begin ? (m_end - m_begin + ROWS - 1) / ROWS : 0;
+  const int row_t = tid >> 2, ch_t = tid & 3;  // one 16-byte chunk of each operand per thread per stage
+
+  hdfuse::Place pa;
+  pa.base = dY + n0 + ch_t * 8;
+  pa.ld = ld_dy;
+  hdfuse::Coef8 cf;
+  if (BNB) {
+    pa.set(dY, ld_dy, bn, n0 + ch_t * 8);
+    hdfuse::fill_coefs(bn, n0, 32, s_bn, split == 0 && blockIdx.x % tiles_k == 0);
+    __syncthreads();
+    cf.load(s_bn, 32, ch_t * 8);
+  }
+  u32x4 ry[2], rx[2], rz[2];
+  auto issue = [&](int t, int st) {
+    int m = m_begin + t * ROWS + row_t;
+    m = m < M ? m : M - 1;
+    ry[st] = *reinterpret_cast<const u32x4*>(pa.base + (long long)m * pa.ld);
+    rx[st] = *reinterpret_cast<const u32x4*>(X + (long long)m * ld_x + k0 + ch_t * 8);
+    if (BNB) rz[st] = *reinterpret_cast<const u32x4*>(bn.y + (long long)m * bn.ld_y + n0 + ch_t * 8);
+  };
+  auto stash = [&](int t, int st) {  // rows past the slice end count as zero
+    const bool in = m_begin + t * ROWS + row_t < m_end;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4 v = BNB ? hdfuse::chunk(ry[st], rz[st], cf, bn.act) : ry[st];
+    *reinterpret_cast<u32x4*>(tY + row_t * SR + ch_t * 16) = in ? v : zero;
+    *reinterpret_cast<u32x4*>(tX + row_t * SR + ch_t * 16) = in ? rx[st] : zero;
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  if (steps > 0) issue(0, 0);
+  if (steps > 1) issue(1, 1);
+  for (int t = 0; t < steps; ++t) {
+    const int st = t & 1;
+    if (st == 0) stash(t, 0); else stash(t, 1);
+    if (t + 2 < steps) { if (st == 0) issue(t + 2, 0); else issue(t + 2, 1); }
+    __syncthreads();
+    const bf16x8 a = tr_fragment(tY, SR, 0, 16 * wave, lane);
+    const bf16x8 b = tr_fragment(tX, SR, 0, 16 * wave, lane);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+  __syncthreads();
+  float* out = slab + (size_t)split * N * K;
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int n = i >> 5, k = i & 31;
+    out[(size_t)(n0 + n) * K + k0 + k] = (s_red[0][n][k] + s_red[1][n][k]) + (s_red[2][n][k] + s_red[3][n][k]);
+  }
+}
+
 // Sum over the row slices on its own launch (the last weight gradient of a backward pass, or a caller that does not chain).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hdfuse::ReduceJob job) {
   __shared__ float4 s_part[16][17];
@@ -1129,6 +1208,19 @@ struct WgradPlan {
 };
 inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
   WgradPlan p;
+  if (Cin % 64 || Cout % 64) {  // 32 x 32 tiles (pointwise_wgrad32_kernel): tm = tn = 0 marks them
+    p.tm = p.tn = 0;
+    p.tiles = (Cout / 32) * (Cin / 32);
+    int s32 = 512 / p.tiles;
+    const int64_t max_s32 = (R + 255) / 256;  // at least four 64-row steps per slice
+    if (s32 > max_s32) s32 = (int)max_s32;
+    if (s32 < 1) s32 = 1;
+    int64_t rps32 = (R + s32 - 1) / s32;
+    rps32 = (rps32 + 63) / 64 * 64;
+    p.rows_per_split = (int)rps32;
+    p.splits = (int)((R + rps32 - 1) / rps32);
+    return p;
+  }
   // 128-wide tiles read each operand once per tile row / column; for a 128 x 128 gradient that is ONE tile, whose
   // ~200 row slices would write (and the reduce kernel read) as many slab bytes as the operands themselves: four
   // 64 x 64 tiles with a quarter of the slices instead
@@ -1175,7 +1267,10 @@ extern "C" hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, cons
 }
 
 extern "C" int hd_pointwise_wgrad_supported(int64_t R, int Cin, int Cout) {
-  return R >= 1 && R <= 0x7fffffff && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && Cin <= 8192 && Cout <= 8192;
+  // multiples of 64 take the 64 / 128-wide tiles; multiples of 32 (up to 256 channels) the 32 x 32 tiles
+  if (!(R >= 1 && R <= 0x7fffffff && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0 && Cin <= 8192 && Cout <= 8192))
+    return 0;
+  return (Cin % 64 == 0 && Cout % 64 == 0) || (Cin <= 256 && Cout <= 256);
 }
 
 extern "C" size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout) {
@@ -1280,7 +1375,13 @@ extern "C" hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_s
     else (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, false>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride,  \
                          M, Cout, Cin, p.rows_per_split, slab, p.splits, bv, jv);                                          \
   } while (0)
-  if (p.tm == 2 && p.tn == 2) HD_WG_LAUNCH(2, 2);
+  if (p.tm == 0) {
+    const dim3 g32((unsigned)p.tiles, (unsigned)p.splits + piggyback_rows(jv, (unsigned)p.tiles));
+    if (bn) (void)hd_launch(pointwise_wgrad32_kernel<true>, g32, dim3(256), 0, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                            p.rows_per_split, slab, p.splits, bv, jv);
+    else (void)hd_launch(pointwise_wgrad32_kernel<false>, g32, dim3(256), 0, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                         p.rows_per_split, slab, p.splits, bv, jv);
+  } else if (p.tm == 2 && p.tn == 2) HD_WG_LAUNCH(2, 2);
   else if (p.tm == 2) HD_WG_LAUNCH(2, 1);
   else if (p.tn == 2) HD_WG_LAUNCH(1, 2);
   else HD_WG_LAUNCH(1, 1);

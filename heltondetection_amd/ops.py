@@ -1127,7 +1127,7 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
     R = B * H * W
     nbytes = lib.hd_pointwise_wgrad_workspace_bytes(R, K, N)
     if nbytes == 0:
-        raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64")
+        raise _lib.HdError("pointwise_wgrad: Cin and Cout must be multiples of 64, or multiples of 32 up to 256")
     ws = _wgrad_workspace(dy.device, nbytes)
     dw = out if out is not None else torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
     if dw.dtype != torch.bfloat16 or dw.numel() != N * K or not dw.is_contiguous():

@@ -498,8 +498,8 @@ hd_status hd_stem_conv_wgrad_partial(const void* dy, int64_t dy_row_stride, cons
 
 /* Weight gradient of the same convolution: dw[Cout, Cin] (bfloat16) = dy[R, Cout]^T . x[R, Cin], float32 accumulate.
  * Two launches (row-sliced partial products into a float32 slab in `workspace`, then the sum over slices), no zero-fill.
- * Cin, Cout multiples of 64.  workspace: hd_pointwise_wgrad_workspace_bytes(R, Cin, Cout), 16-byte aligned, contents
- * undefined on entry and exit. */
+ * Cin, Cout multiples of 64 (64- / 128-wide tiles), or multiples of 32 up to 256 (32 x 32 tiles: hd_pointwise_wgrad_supported
+ * says).  workspace: hd_pointwise_wgrad_workspace_bytes(R, Cin, Cout), 16-byte aligned, contents undefined on entry and exit. */
 int hd_pointwise_wgrad_supported(int64_t R, int Cin, int Cout);
 size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cout);
 hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R, int Cin,
