@@ -334,7 +334,9 @@ def test_fused_conv_bn_act_node_matches_the_unfused_chain(cin, cout, hw, act, re
         a, b = runs[True][k], runs[False][k]
         if a is None:
             continue
-        tol = 2.0 ** -7 * b.abs() + 2.0 ** -9 * b.abs().mean() + 1e-7
+        # two runs: the statistics / reduce kernels' float atomics differ in their last bits, which moves single bf16 roundings
+        # (dx and dw are sums over many such terms): a couple of bf16 roundings of the element or of a typical one
+        tol = 2.0 ** -6 * b.abs() + 2.0 ** -6 * b.abs().mean() + 1e-7
         assert bool(((a - b).abs() <= tol).all()), (k, float(((a - b).abs() / tol).max()))
 
 
