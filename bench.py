@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--graph-split", choices=("auto", "on", "off"), default="auto",
                     help="multi-rank hipGraph mode: cut the captured step at the gradient-bucket boundaries (on / auto) or replay "
                          "one graph and launch the collectives behind it (off)")
+    ap.add_argument("--layer-detail", default="", help="write the per-launch table of the hand-written convolution kernels "
+                                                       "(name, shape, us, GB/s, TFLOP/s) of the roofline passes to this file")
     ap.add_argument("--no-legs", action="store_true", help="skip the fp32 and 832x832 companion legs of the default run")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each companion leg (after 5 warm-up steps)")
     ap.add_argument("--no-miopen-find", action="store_true",
@@ -517,6 +519,13 @@ def bn_family_roofline(model, batch, args, device, trainer=None):
                                   "few slice sums launched on their own",
                          "per_kernel": {k: _conv_kernel_entry(k, pms[k], pby[k], pn[k], sum((t or {}).get("flops", 0) for t in tags[k]))
                                         for k in pw_names}})
+    if pw is not None and getattr(args, "layer_detail", ""):
+        with open(args.layer_detail, "w") as f:
+            for k in pw_names:
+                for t_ms, nb, tag in zip(mid.get(k, ()), notes.get(k, ()), tags.get(k, ())):
+                    t_ = tag or {}
+                    f.write(json.dumps({"kernel": k, "shape": t_.get("shape"), "us": round(t_ms * 1e3, 2), "MB": round(nb / 1e6, 2),
+                                        "GB/s": round(nb / t_ms / 1e6, 1), "TFLOP/s": round(t_.get("flops", 0) / t_ms / 1e9, 1)}) + "\n")
     if pw is not None and args.model == "yolov5" and args.size == 640 and args.batch == 16 and args.variant == "s" and not args.fp32:
         pw["traffic"] = pmc_traffic("hand-written convolutions")
     for f_ in (fam, pw):

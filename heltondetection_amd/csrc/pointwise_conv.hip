@@ -267,34 +267,59 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   const int my = gw < RT ? (RT - 1 - gw) / GW + 1 : 0;
 
   // coalesced: instruction p of a lane takes chunk (p * 64 + lane) of the row block, i.e. 64 / CPR whole rows at a time
-  u32x4 nxt[NLD], nyy[BNB ? NLD : 1];
+  // D row blocks travel in registers ahead of the one being multiplied.  D = 2 for the deep variants (K >= 128, one or two
+  // waves per SIMD) was measured in the YOLOv5s step and bought nothing (forward +-0, data gradient +1-2 us per launch:
+  // the waves are paced by their LDS traffic — 72 KB per 32-row block at K = 256 — not by the load round trip), so D = 1.
+  constexpr int D = 1;
+  u32x4 nxt[D][NLD], nyy[BNB ? NLD : 1];
   hdfuse::Place pa;
   pa.base = A + (lane % CPR) * 8;
   pa.ld = lda;
   if (BNB) pa.set(A, lda, bn, (lane % CPR) * 8);
-  auto load_rows = [&](int rt) {
+  auto load_rows = [&](int rt, u32x4 (&dst)[NLD]) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int id = p * 64 + lane;
       int m = rt * (32 * TM) + id / CPR;
       m = m < M ? m : M - 1;  // rows past the end re-read the last row; their results are never stored
-      nxt[p] = *reinterpret_cast<const u32x4*>(pa.base + (long long)m * pa.ld);
+      dst[p] = *reinterpret_cast<const u32x4*>(pa.base + (long long)m * pa.ld);
       if (BNB) nyy[p] = *reinterpret_cast<const u32x4*>(bn.y + (long long)m * bn.ld_y + (id % CPR) * 8);
     }
   };
-  if (my > 0) load_rows(gw);  // in flight while the weight slab is staged
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < my) load_rows(gw + d * GW, nxt[d]);  // in flight while the weight slab is staged
   if (BNB) hdfuse::fill_coefs(bn, 0, K, s_bn, false);
-  if (TRB) {
-    for (int id = tid; id < K * (BN / 8); id += 256) {
-      const int row = id / (BN / 8), c = id % (BN / 8);
-      *reinterpret_cast<uint4*>(smem + row * L::SLAB_ROW_T + c * 16) =
-          *reinterpret_cast<const uint4*>(Bw + (long long)row * N + n0 + c * 8);
+  {
+    // the slab's BN x K / 8 chunks: ALL of a thread's loads are issued before its first LDS store (a load -> store loop waits
+    // out one L2 round trip per chunk: 8 of them, ~5 us, for the 32 KB slabs — half the launch on the 20 x 20 / 40 x 40 levels)
+    constexpr int NCH = BN * CPR, WIT = (NCH + 255) / 256;
+    u32x4 wreg[WIT];
+#pragma unroll
+    for (int p = 0; p < WIT; ++p) {
+      const int id = p * 256 + tid;
+      if (NCH % 256 == 0 || id < NCH) {
+        if (TRB) {
+          const int row = id / (BN / 8), c = id % (BN / 8);
+          wreg[p] = *reinterpret_cast<const u32x4*>(Bw + (long long)row * N + n0 + c * 8);
+        } else {
+          const int row = id / CPR, c = id % CPR;
+          wreg[p] = *reinterpret_cast<const u32x4*>(Bw + (long long)(n0 + row) * K + c * 8);
+        }
+      }
     }
-  } else {
-    for (int id = tid; id < BN * CPR; id += 256) {
-      const int row = id / CPR, c = id % CPR;
-      *reinterpret_cast<uint4*>(smem + Slab<K>::off(row, c)) =
-          *reinterpret_cast<const uint4*>(Bw + (long long)(n0 + row) * K + c * 8);
+#pragma unroll
+    for (int p = 0; p < WIT; ++p) {
+      const int id = p * 256 + tid;
+      if (NCH % 256 == 0 || id < NCH) {
+        if (TRB) {
+          const int row = id / (BN / 8), c = id % (BN / 8);
+          *reinterpret_cast<u32x4*>(smem + row * L::SLAB_ROW_T + c * 16) = wreg[p];
+        } else {
+          const int row = id / CPR, c = id % CPR;
+          *reinterpret_cast<u32x4*>(smem + Slab<K>::off(row, c)) = wreg[p];
+        }
+      }
     }
   }
   __syncthreads();
@@ -306,14 +331,18 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   hdfuse::Coef8 cf;
   if (BNB) cf.load(s_bn, K, (lane % CPR) * 8);  // behind the barrier above
 
-  for (int it = 0; it < my; ++it) {
+  for (int it0 = 0; it0 < my; it0 += D)
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int it = it0 + d;
+    if (D > 1 && it >= my) break;
     const int rt = gw + it * GW;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int id = p * 64 + lane;
-      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = BNB ? hdfuse::chunk(nxt[p], nyy[p], cf, bn.act) : nxt[p];
+      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = BNB ? hdfuse::chunk(nxt[d][p], nyy[p], cf, bn.act) : nxt[d][p];
     }
-    if (it + 1 < my) load_rows(rt + GW);
+    if (it + D < my) load_rows(rt + D * GW, nxt[d]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before its lanes read each other's
     f32x16 acc[TM][TN];
 #pragma unroll

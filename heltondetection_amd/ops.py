@@ -935,7 +935,7 @@ def pointwise_conv_rows(x: torch.Tensor, w2: torch.Tensor, stats: Optional[torch
     ld_y = _cl_row_stride(out, 8)
     if ld_y is None or out.shape != (B, N, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_conv: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cout, H, W]")
-    _note_bytes(name, 2 * (B * H * W * (K + N) + N * K), {"flops": 2 * B * H * W * K * N})
+    _note_bytes(name, 2 * (B * H * W * (K + N) + N * K), {"flops": 2 * B * H * W * K * N, "shape": (B * H * W, K, N)})
     with _ktimed(name):
         check(lib.hd_pointwise_conv(_ptr(x), int(ld_x), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_y), _ptr(stats), _stream(x)),
               "hd_pointwise_conv")
@@ -1086,7 +1086,7 @@ def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch
     if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
     _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K) + (2 * B * H * W * N if bn is not None else 0),
-                {"flops": 2 * B * H * W * K * N})
+                {"flops": 2 * B * H * W * K * N, "shape": (B * H * W, N, K)})
     if add is not None:
         ld_add = _cl_row_stride(add, 8)
         if bn is not None or ld_add is None or add.dtype != torch.bfloat16 or tuple(add.shape) != (B, K, H, W):
@@ -1135,7 +1135,7 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
     pend = _WgradChain.piggyback(dy.device)
     job = _lib.WgradJob()
     # fused: d(out) and y are read where dy was
-    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K) + (2 * R * N if bn is not None else 0), {"flops": 2 * R * K * N})
+    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K) + (2 * R * N if bn is not None else 0), {"flops": 2 * R * K * N, "shape": (R, K, N)})
     with _ktimed("pointwise_wgrad"):
         check(lib.hd_pointwise_wgrad_partial(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
                                              C.byref(bn) if bn is not None else None, _ptr(x), int(ld_x), R, K, N, _ptr(dw),
@@ -1174,7 +1174,8 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: 
         raise _lib.HdError("conv3x3_wgrad: `out` must be a channels-last bf16 [Cout, Cin, 3, 3] tensor")
     pend = _WgradChain.piggyback(dy.device)
     job = _lib.WgradJob()
-    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
+    _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K),
+                {"flops": 18 * B * H * W * K * N, "shape": (B, H, W, K, N, stride)})
     with _ktimed("conv3x3_wgrad"):
         check(lib.hd_conv3x3_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
                                            ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job), _stream(dy)),
@@ -1201,7 +1202,7 @@ def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Ten
             or not w.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.HdError("conv3x3_fwd: needs bf16 channels-last rows and a channels-last bf16 [Cout, Cin, 3, 3] weight")
     y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    _note_bytes(name, 2 * (B * H * W * (K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N})
+    _note_bytes(name, 2 * (B * H * W * (K + N) + 9 * N * K), {"flops": 18 * B * H * W * K * N, "shape": (B, H, W, K, N, 1)})
     with _ktimed(name):
         check(lib.hd_conv3x3_fwd(_ptr(x), int(ld_x), _ptr(w), B, H, W, K, N, _ptr(y), N, _ptr(stats), _stream(x)), "hd_conv3x3_fwd")
     return y
