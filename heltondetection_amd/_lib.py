@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -149,6 +149,8 @@ SIGNATURES = {
     "hd_bn_act_stats": (_I, [_P, _I, _L, _I, _P, _P]),
     "hd_bn_act_apply": (_I, [_P, _I, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P, _P]),
     "hd_bn_act_infer": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _I, _P, _L, _P, _P]),
+    "hd_bias_act_fwd": (_I, [_P, _I, _L, _I, _P, _I, _P, _P]),
+    "hd_bias_act_bwd": (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P]),
     "hd_yolo_detect_workspace_bytes": (_Z, [_P, _I, _I, _I]),
     "hd_yolo_detect": (_I, [_P, _I, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "hd_mosaic4": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, C.c_float, _P, _L, _L, _L, _L, _P]),

@@ -453,6 +453,100 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
   }
 }
 
+// ---- bias + activation of a biased convolution (the RPN head's conv -> ReLU) ---------------------------------------
+// y = act(x + bias_c), in place or not: the convolution is called WITHOUT its bias, so the library's broadcast add, the
+// separate activation and — backward — the activation's mask pass and the strided bias-gradient reduction (four passes +
+// a slow reduce on a 354 MB level of config 3) become one pass each way.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ x, long long nvec, int C,
+                                                           const float* __restrict__ bias, T* __restrict__ y) {
+  constexpr int V = RowVec<T>::N;
+  const int cg = C / V;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = (int)(i0 % cg);
+  float b[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) b[k] = bias[g * V + k];
+  long long i = i0;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[V];
+      RowVec<T>::unpack(raw[u], v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(v[k] + b[k]);
+      RowVec<T>::store(y + (i + u * stride) * V, v);
+    }
+  }
+  for (; i < nvec; i += stride) {
+    float v[V];
+    RowVec<T>::load(x + i * V, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = act_fwd<ACT>(v[k] + b[k]);
+    RowVec<T>::store(y + i * V, v);
+  }
+}
+
+// dx = dy * act'(y) from the OUTPUT y (ReLU: y > 0; none: 1 and no dx is written), d(bias) = per-channel sum of dx into
+// the replicated accumulators [kRep, 2, C] (first half; the second half receives zeros) like the BatchNorm reductions.
+template <typename T, int ACT, bool WRITE>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, long long nvec,
+                                                           int C, T* __restrict__ dx, float* __restrict__ dsums) {
+  constexpr int V = RowVec<T>::N;
+  extern __shared__ float s_acc[];
+  const int cg = C / V;
+  const bool slots = fold_by_slots(cg);
+  if (!slots) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.0f;
+    __syncthreads();
+  }
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = (int)(i0 % cg);
+  float s1[V], s2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.0f;
+  long long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {
+    uint4 ry[2], rg[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (ACT != ACT_NONE) ry[u] = *reinterpret_cast<const uint4*>(y + (i + u * stride) * V);
+      rg[u] = *reinterpret_cast<const uint4*>(dy + (i + u * stride) * V);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float yv[V], gv[V];
+      if (ACT != ACT_NONE) RowVec<T>::unpack(ry[u], yv);
+      RowVec<T>::unpack(rg[u], gv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        if (ACT == ACT_RELU) gv[k] = yv[k] > 0.0f ? gv[k] : 0.0f;
+        s1[k] += gv[k];
+      }
+      if (WRITE) RowVec<T>::store(dx + (i + u * stride) * V, gv);
+    }
+  }
+  for (; i < nvec; i += stride) {
+    float yv[V], gv[V];
+    if (ACT != ACT_NONE) RowVec<T>::load(y + i * V, yv);
+    RowVec<T>::load(dy + i * V, gv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      if (ACT == ACT_RELU) gv[k] = yv[k] > 0.0f ? gv[k] : 0.0f;
+      s1[k] += gv[k];
+    }
+    if (WRITE) RowVec<T>::store(dx + i * V, gv);
+  }
+  float* dst = dsums + (size_t)(blockIdx.x % kRep) * 2 * C;
+  if (slots) fold_slots<V>(s_acc, s1, s2, g, cg, C, dst);
+  else fold_atomic<V>(s_acc, s1, s2, g, C, dst);
+}
+
 struct Launch {
   unsigned grid, block;
 };
@@ -691,6 +785,57 @@ extern "C" hd_status hd_bn_act_bwd_dx(const void* x, const void* dy, int64_t dy_
   else HD_ACT_DISPATCH(__hip_bfloat16, HD_DX, __hip_bfloat16);
 #undef HD_DX
 #undef HD_DX_R
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_bias_act_fwd(const void* x, int dtype, int64_t R, int C, const float* bias, int act, void* y,
+                                     hd_stream stream) {
+  hd_status st = common_checks(dtype, R, C);
+  if (st != HD_OK) return st;
+  if (!x || !bias || !y) return HD_ERR_NULL;
+  if (act != ACT_NONE && act != ACT_RELU && act != ACT_SILU) return HD_ERR_SHAPE;
+  if (!hd_aligned16(x) || !hd_aligned16(y)) return HD_ERR_ALIGN;
+  const int V = dtype == 0 ? 4 : 8;
+  const long long nvec = R * (long long)(C / V);
+  const Launch l = plan(nvec / 4 + 1, C / V, 2048);
+  hipStream_t s = (hipStream_t)stream;
+#define HD_BIAS_F(T, A, XT)                                                                                        \
+  (void)hd_launch(bias_act_fwd_kernel<XT, A>, dim3(l.grid), dim3(l.block), 0, s, reinterpret_cast<const XT*>(x), nvec, C, \
+                  bias, reinterpret_cast<XT*>(y))
+  if (dtype == 0) HD_ACT_DISPATCH(float, HD_BIAS_F, float);
+  else HD_ACT_DISPATCH(__hip_bfloat16, HD_BIAS_F, __hip_bfloat16);
+#undef HD_BIAS_F
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_bias_act_bwd(const void* y, const void* dy, int dtype, int64_t R, int C, int act, void* dx,
+                                     float* dsums, hd_stream stream) {
+  hd_status st = common_checks(dtype, R, C);
+  if (st != HD_OK) return st;
+  if (!dy || !dsums) return HD_ERR_NULL;
+  if (act != ACT_NONE && act != ACT_RELU) return HD_ERR_SHAPE;  // the output alone decides act' only for these two
+  if (act == ACT_RELU && (!y || !dx)) return HD_ERR_NULL;
+  if (!hd_aligned16(dy) || (y && !hd_aligned16(y)) || (dx && !hd_aligned16(dx))) return HD_ERR_ALIGN;
+  const int V = dtype == 0 ? 4 : 8;
+  const long long nvec = R * (long long)(C / V);
+  const Launch l = plan(nvec / 8 + 1, C / V, 512);
+  const size_t lds = reduce_lds_bytes(l, C / V, C);
+  hipStream_t s = (hipStream_t)stream;
+#define HD_BIAS_B(XT, A, W)                                                                                        \
+  (void)hd_launch(bias_act_bwd_kernel<XT, A, W>, dim3(l.grid), dim3(l.block), lds, s, reinterpret_cast<const XT*>(y), \
+                  reinterpret_cast<const XT*>(dy), nvec, C, reinterpret_cast<XT*>(dx), dsums)
+  if (dtype == 0) {
+    if (act == ACT_RELU) HD_BIAS_B(float, ACT_RELU, true);
+    else if (dx) HD_BIAS_B(float, ACT_NONE, true);
+    else HD_BIAS_B(float, ACT_NONE, false);
+  } else {
+    if (act == ACT_RELU) HD_BIAS_B(__hip_bfloat16, ACT_RELU, true);
+    else if (dx) HD_BIAS_B(__hip_bfloat16, ACT_NONE, true);
+    else HD_BIAS_B(__hip_bfloat16, ACT_NONE, false);
+  }
+#undef HD_BIAS_B
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

@@ -440,8 +440,10 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   // 512 workgroups then ran as two rounds, each paying its slab load and first-block latency)
   const long long cap = lds > 80 * 1024 ? 256 : 512;
   long long g = (RT + 3) / 4 * NT;  // one row block per wave, or the persistent cap
-  g = (g + 7) / 8 * 8;
-  if (g > cap) g = cap;
+  long long L = 8;                  // the grid is a multiple of 8 (XCD remap) and of NT (one column tile per workgroup)
+  while (L % NT) L += 8;
+  g = (g + L - 1) / L * L;
+  if (g > cap) g = cap / L * L;
   const auto* a = static_cast<const unsigned short*>(A);
   const auto* b = static_cast<const unsigned short*>(Bw);
   auto* c = static_cast<unsigned short*>(Cmat);
@@ -470,12 +472,16 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
 }
 
 // -> true when the streaming form took the call
+// Column tiles of one streaming launch: every row block is pulled through L2 once per column tile (the workgroups of one row
+// range sit on one XCD), so wide outputs cost L2 bandwidth, not HBM; 32 covers ResNet50's 256 -> 1024 / 1024 <- 256 layers.
+constexpr int kMaxColumnTiles = 32;
+
 template <int K, bool TRB = false>
 bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
                 hd_status* st, const hdfuse::BnBwd* bnb = nullptr, const void* radd = nullptr, int64_t ld_r = 0) {
   constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
   const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
-  if (N / bn > 8) return false;
+  if (N / bn > kMaxColumnTiles) return false;
   if (bn == 128) {
     if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r); return true; }
     return false;
@@ -1437,14 +1443,14 @@ extern "C" int hd_pointwise_conv_resident(int64_t R, int Cin, int Cout) {
   if (!(Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256) || !hd_pointwise_conv_supported(R, Cin, Cout)) return 0;
   const int max_bn = Cin <= 128 ? 128 : 64;
   const int bn = (Cout % 128 == 0 && max_bn >= 128) ? 128 : (Cout % 64 == 0 ? 64 : 32);
-  return Cout / bn <= 8;
+  return Cout / bn <= kMaxColumnTiles;
 }
 
 extern "C" int hd_pointwise_conv_dgrad_supported(int64_t R, int Cin, int Cout) {
   if (!(Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) || !hd_pointwise_conv_supported(R, Cout, Cin)) return 0;
   const int max_bn = Cout <= 128 ? 128 : 64;  // the column tile try_stream<Cout, true> picks over the Cin output channels
   const int bn = (Cin % 128 == 0 && max_bn >= 128) ? 128 : (Cin % 64 == 0 ? 64 : 32);
-  return Cin / bn <= 8;
+  return Cin / bn <= kMaxColumnTiles;
 }
 
 extern "C" hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout,

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import ConvBNAct, ShadowConv2d
+from .layers import ConvBNAct, ShadowConv2d, conv_bias_act
 from .registry import ASSIGNERS, HEADS
 
 YOLOV5_ANCHORS = (((10, 13), (16, 30), (33, 23)), ((30, 61), (62, 45), (59, 119)), ((116, 90), (156, 198), (373, 326)))
@@ -138,12 +138,18 @@ class RPNHead(nn.Module):
 
     def forward(self, feats: List[torch.Tensor]):
         logits, deltas = [], []
+        # objectness and box deltas come out of ONE 1x1 convolution with the two weights stacked (A + 4A outputs): the hidden
+        # map is read once forward, and backward it receives one data gradient instead of two 256-channel maps plus their sum
+        A = self.A
+        w = torch.cat([self.obj.lp_weight(), self.reg.lp_weight()], 0)
+        b = torch.cat([self.obj.bias, self.reg.bias], 0)
         for f in feats:
-            t = F.relu(self.conv(f))
+            t = conv_bias_act(self.conv, f, "relu")  # bias + ReLU in one in-place pass after the bias-free convolution
             B = t.shape[0]
+            o = F.conv2d(t, w, b).float()
             # channels-last conv outputs: permute(0,2,3,1) is a free view; order = (y, x, anchor)
-            logits.append(self.obj(t).float().permute(0, 2, 3, 1).reshape(B, -1))
-            deltas.append(self.reg(t).float().permute(0, 2, 3, 1).reshape(B, -1, 4))
+            logits.append(o[:, :A].permute(0, 2, 3, 1).reshape(B, -1))
+            deltas.append(o[:, A:].permute(0, 2, 3, 1).reshape(B, -1, 4))
         return torch.cat(logits, 1), torch.cat(deltas, 1)
 
     @torch.no_grad()

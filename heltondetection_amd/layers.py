@@ -157,6 +157,23 @@ def pointwise_mode(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> int:
     return 1 if ops.pointwise_backward_usable(x, w) else 0
 
 
+def conv_bias_act(conv: nn.Conv2d, x: torch.Tensor, act=None) -> torch.Tensor:
+    """act(conv(x)) for a BIASED convolution followed by ReLU or nothing (the RPN head's 3x3 -> ReLU): on HIP the library runs
+    the convolution without its bias and one pass of ours adds the bias and applies the activation in place
+    (ops.bias_act; backward: mask + bias-gradient sums in one pass instead of a mask pass and a strided reduction)."""
+    if (conv.bias is not None and FusedBNAct.enabled and x.is_cuda and act in (None, "relu")
+            and conv.out_channels % 8 == 0 and conv.out_channels // 4 <= 256):
+        from . import ops
+        w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+        y = conv._conv_forward(x, w, None)
+        if ops.bias_act_supported(y, act):
+            return ops.bias_act(y, conv.bias, act, inplace=True)
+        y = y + conv.bias.to(y.dtype)[None, :, None, None]
+        return torch.relu(y) if act == "relu" else y
+    y = conv(x)
+    return torch.relu(y) if act == "relu" else y
+
+
 def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, residual_after_act: bool = False, out=None,
                 fork: bool = False):
     """Conv2d(bias=False) -> BatchNorm2d -> activation [-> / <- residual] on the fused HIP kernels: the 1x1 convolutions on

@@ -1730,6 +1730,56 @@ def pointwise_conv_bn_act(x, weight, gamma, beta, running_mean, running_var, eps
                                 _OutSlot(out) if out is not None else None, bool(ours_forward), bool(fork))
 
 
+class _BiasActFn(torch.autograd.Function):
+    """y = act(x + bias[c]) for a biased convolution that was run without its bias (csrc/bn_act.hip: hd_bias_act_fwd / _bwd).
+    Backward works from the output: dx = dy * (y > 0) for ReLU (dy itself for no activation) and the bias gradient is the
+    per-channel sum of dx taken in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, bias, code: int, inplace: bool):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        y = x if inplace else torch.empty_like(x, memory_format=torch.channels_last)
+        b32 = bias if bias.dtype == torch.float32 else bias.float()
+        check(lib.hd_bias_act_fwd(_ptr(x), 0 if x.dtype == torch.float32 else 1, B * H * W, Cc, _ptr(b32), code, _ptr(y),
+                                  _stream(x)), "hd_bias_act_fwd")
+        if inplace:
+            ctx.mark_dirty(x)
+        ctx.code, ctx.bias_dtype = code, bias.dtype
+        ctx.save_for_backward(y if code != 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        B, Cc, H, W = dy.shape
+        rep = lib.hd_bn_act_replicas()
+        dsums = torch.zeros(rep * 2 * Cc, dtype=torch.float32, device=dy.device)
+        dx = torch.empty_like(dy, memory_format=torch.channels_last) if ctx.code != 0 else None
+        check(lib.hd_bias_act_bwd(_ptr(y), _ptr(dy), 0 if dy.dtype == torch.float32 else 1, B * H * W, Cc, ctx.code, _ptr(dx),
+                                  _ptr(dsums), _stream(dy)), "hd_bias_act_bwd")
+        db = dsums.view(rep, 2, Cc)[:, 0].sum(0)
+        return (dx if dx is not None else dy), (db if ctx.bias_dtype == torch.float32 else db.to(ctx.bias_dtype)), None, None
+
+
+def bias_act_supported(x: torch.Tensor, act) -> bool:
+    return act in (None, "none", "relu") and bn_act_supported(x)
+
+
+def bias_act(x: torch.Tensor, bias: torch.Tensor, act=None, inplace: bool = False) -> torch.Tensor:
+    """act(x + bias[None, :, None, None]) on a dense channels-last float32 / bfloat16 HIP tensor, act None or "relu"; bias float32
+    (or x's dtype).  inplace: write over x (x must not be needed by the backward of whatever produced it — a convolution's
+    output is not)."""
+    if not bias_act_supported(x, act):
+        raise _lib.HdError("bias_act: needs a dense channels-last float32/bfloat16 HIP tensor with C % vec == 0, act None or relu")
+    if bias.dim() != 1 or bias.shape[0] != x.shape[1] or not bias.is_cuda:
+        raise _lib.HdError("bias_act: bias must be a HIP vector of C elements")
+    return _BiasActFn.apply(x, bias, _ACT_CODE[act], bool(inplace))
+
+
 def bn_act_slot(device, channels: int) -> _StatSlot:
     # forward sums + backward sums, each [replicas, 2, C]
     return _arena(torch.device(device)).alloc(4 * channels * _lib.load().hd_bn_act_replicas())

@@ -393,6 +393,14 @@ hd_status hd_bn_act_apply(const void* x, int dtype, int64_t R, int64_t stat_rows
  * ResNet bottleneck tail; 2 = y = act(bn(x)) + res, the YOLOv5 bottleneck shortcut.  Backward: only mode 1 needs the
  * kernels' help — pass the same `res` to _bwd_reduce and _bwd_dx (act' is taken at bn(x) + res) and _bwd_dx also
  * writes d(res) = dz into dres; for mode 2 d(res) is dy itself and the backward entry points are called with NULL. */
+/* Bias + activation of a biased convolution that was run WITHOUT its bias (the RPN head's conv -> ReLU; the reference's
+ * FasterRCNN, README.md:8): y = act(x + bias[c]) on channels-last rows [R, C] (dtype 0 float32 / 1 bfloat16, C a multiple
+ * of the 16-byte vector, dense rows; y may alias x).  Backward from the OUTPUT: dx = dy * act'(y) (act 2 = ReLU: y > 0;
+ * act 0: dx = dy, pass dx NULL to skip the write) and d(bias)[c] = sum over rows of dx, added into the replicated
+ * accumulators dsums [hd_bn_act_replicas()][2][C] float32 (first half of every replica; zeroed by the caller). */
+hd_status hd_bias_act_fwd(const void* x, int dtype, int64_t R, int C, const float* bias, int act, void* y, hd_stream stream);
+hd_status hd_bias_act_bwd(const void* y, const void* dy, int dtype, int64_t R, int C, int act, void* dx, float* dsums,
+                          hd_stream stream);
 hd_status hd_bn_act_infer(const void* x, int dtype, int64_t R, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var,
                           float eps, int act, void* y, int64_t y_row_stride, const hd_rows2* y_tail,

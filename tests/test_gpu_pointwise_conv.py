@@ -22,7 +22,9 @@ def _ref(x, w):
 # (K 512, 96, 1024), ragged row counts (not a multiple of 32 / 64 / 128) and a single-row input
 SHAPES = [(2, 32, 20, 20, 32), (2, 64, 24, 20, 64), (1, 64, 17, 13, 128), (2, 128, 9, 11, 128), (1, 128, 16, 16, 64),
           (2, 256, 10, 10, 256), (1, 256, 7, 9, 128), (1, 256, 5, 5, 32), (2, 64, 16, 16, 256), (1, 32, 33, 7, 96),
-          (2, 512, 10, 10, 512), (1, 1024, 6, 6, 512), (1, 96, 7, 7, 160), (1, 64, 1, 1, 64), (16, 64, 80, 80, 64)]
+          (2, 512, 10, 10, 512), (1, 1024, 6, 6, 512), (1, 96, 7, 7, 160), (1, 64, 1, 1, 64), (16, 64, 80, 80, 64),
+          # more than 8 column tiles per launch (ResNet50's 256 -> 1024; 12 and 20 tiles: not powers of two)
+          (2, 256, 13, 13, 1024), (1, 256, 9, 9, 768), (1, 64, 31, 9, 640), (4, 256, 52, 52, 1024)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -196,8 +198,10 @@ def test_resnet_width_layers_train_through_conv_bn_act(cin, cout):
     from heltondetection_amd import _lib, layers, ops
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    assert lib.hd_pointwise_conv_dgrad_supported(1000, 1024, 256) == 0  # 16 column tiles of 64: not resident
-    assert lib.hd_pointwise_conv_resident(1000, 256, 1024) == 0
+    assert lib.hd_pointwise_conv_dgrad_supported(1000, 2048, 256) == 0  # wider than the kernels' 1024 columns
+    assert lib.hd_pointwise_conv_resident(1000, 256, 2048) == 0
+    assert lib.hd_pointwise_conv_dgrad_supported(1000, 1024, 256) == 1  # 16 column tiles of 64 (<= 32)
+    assert lib.hd_pointwise_conv_resident(1000, 256, 1024) == 1
     torch.manual_seed(2)
     m = layers.ConvBNAct(cin, cout, 1, 1, act="relu").to(dev).to(memory_format=torch.channels_last).train()
     x0 = torch.randn((2, cin, 13, 13), device=dev).contiguous(memory_format=torch.channels_last)
@@ -405,7 +409,8 @@ def test_chained_weight_gradient_sums_ride_in_the_next_launch():
     assert torch.equal(got3, ref3)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (3, 128, 13, 11, 128), (2, 256, 10, 10, 64), (1, 64, 40, 40, 256)])
+@pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (3, 128, 13, 11, 128), (2, 256, 10, 10, 64), (1, 64, 40, 40, 256),
+                                   (2, 1024, 13, 13, 256), (1, 768, 9, 7, 256)])
 def test_pointwise_dgrad_with_the_shortcut_gradient_added_in_the_epilogue(shape):
     """hd_pointwise_conv_dgrad_add == hd_pointwise_conv_dgrad followed by a bf16 add (float32 sum of the two bf16 values, one
     rounding), bit for bit; also with the result written over the addend."""
