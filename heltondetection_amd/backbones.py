@@ -80,8 +80,13 @@ class _ResBottleneck(nn.Module):
             else:
                 y, idt = conv_bn_act(self.conv1, self.bn1, "relu", x), x
         else:
-            idt = conv_bn_act(self.downsample[0], self.downsample[1], None, x)
-            y = conv_bn_act(self.conv1, self.bn1, "relu", x)
+            # the block input feeds conv1 and the projection shortcut: conv1 hands on an alias whose gradient (the projection's
+            # data gradient) is added inside conv1's own data-gradient kernel — no separate add of two 100+ MB maps
+            if ConvBNAct.fork_shortcut:
+                y, x1 = conv_bn_act(self.conv1, self.bn1, "relu", x, fork=True)
+            else:
+                y, x1 = conv_bn_act(self.conv1, self.bn1, "relu", x), x
+            idt = conv_bn_act(self.downsample[0], self.downsample[1], None, x1)
         y = conv_bn_act(self.conv2, self.bn2, "relu", y)
         # relu(bn3(conv3) + identity) in one fused kernel (residual added before the activation)
         return conv_bn_act(self.conv3, self.bn3, "relu", y, idt, False)
@@ -121,10 +126,15 @@ class ResNet50(nn.Module):
         layers += [_ResBottleneck(self._c, width) for _ in range(n - 1)]
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, tap=None):
+        """tap(i, feature) -> feature: called on every stage output BEFORE the next stage reads it; a neck uses it to run its
+        lateral 1x1 convolution as a `fork` (layers.conv_bn_act) and hand back the alias, so that the stage output's gradient is
+        accumulated inside the data-gradient kernels of its consumers instead of by add launches (detectors.FasterRCNN)."""
         x = self.maxpool(FusedBNAct.apply(self.bn1, self.conv1(x), "relu"))
-        c2 = self.layer1(x)
-        c3 = self.layer2(c2)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
-        return [c2, c3, c4, c5]
+        feats = []
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            x = layer(x)
+            if tap is not None:
+                x = tap(i, x)
+            feats.append(x)
+        return feats

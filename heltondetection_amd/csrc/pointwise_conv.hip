@@ -25,6 +25,9 @@
 #include <hip/hip_bf16.h>
 
 #include "hd_bn_fuse.h"
+#include <cstdlib>
+#include <type_traits>
+
 #include "hd_common.h"
 
 namespace {
@@ -245,7 +248,11 @@ struct StreamLds {
 // ACC: the result is added to the rows of `radd` (bf16, row stride ld_r) before it is stored — the data gradient of a layer
 // whose input also feeds a shortcut: dx = dy . w + d(shortcut) in one pass (float32 add of the two bf16 values, one rounding:
 // what the separate bf16 add kernel of the autograd engine computes), instead of a launch that reads both and writes the sum.
-template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false, bool ACC = false>
+// DEEP: the long-launch form (>= kDeepBlocks row blocks per wave: the 832^2 / 1280^2 levels): two row blocks of register
+// lookahead with the loads issued behind the previous block's stores, every memory instruction of the steady-state loop
+// unconditional, operand fragments requested two k-steps ahead.  The short form (DEEP = false) is the round-2 kernel: on the
+// 640^2 pyramid a wave owns 1-4 blocks, the steady-state loop never runs and the deeper prologue costs 1-8 us per launch.
+template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false, bool ACC = false, bool DEEP = false>
 __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
                                                                const unsigned short* __restrict__ Bw,
                                                                unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
@@ -267,10 +274,9 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   const int my = gw < RT ? (RT - 1 - gw) / GW + 1 : 0;
 
   // coalesced: instruction p of a lane takes chunk (p * 64 + lane) of the row block, i.e. 64 / CPR whole rows at a time
-  // D row blocks travel in registers ahead of the one being multiplied.  D = 2 for the deep variants (K >= 128, one or two
-  // waves per SIMD) was measured in the YOLOv5s step and bought nothing (forward +-0, data gradient +1-2 us per launch:
-  // the waves are paced by their LDS traffic — 72 KB per 32-row block at K = 256 — not by the load round trip), so D = 1.
-  constexpr int D = 1;
+  // D row blocks travel in registers ahead of the one being multiplied: 2 for the deep variants (K >= 128, one or two waves
+  // per SIMD), whose loads are issued behind the previous block's stores (see `block` below); 1 for K <= 64 (4 waves per SIMD).
+  constexpr int D = (DEEP && K >= 128 && !BNB) ? 2 : 1;
   u32x4 nxt[D][NLD], nyy[BNB ? NLD : 1];
   hdfuse::Place pa;
   pa.base = A + (lane % CPR) * 8;
@@ -331,18 +337,35 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   hdfuse::Coef8 cf;
   if (BNB) cf.load(s_bn, K, (lane % CPR) * 8);  // behind the barrier above
 
-  for (int it0 = 0; it0 < my; it0 += D)
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const int it = it0 + d;
-    if (D > 1 && it >= my) break;
+  // One row block.  GUARD: rows past M exist in this block (or it is one of the wave's last blocks): stores and the next
+  // loads are conditional.  Without it every memory instruction of the block is issued unconditionally, which is what lets the
+  // compiler count them: behind a conditional store or load it must assume the instruction was NOT issued, and its
+  // s_waitcnt vmcnt(n) for the oldest loads then also drains everything younger (measured: the wait at the head of a block
+  // included the acknowledgement of the previous block's stores, or — with two blocks of lookahead — the loads issued a moment
+  // before; 46 % of the wave cycles of the K = 256 variants were parked, PMC on 692 224 x 256 x 256).
+  auto block = [&](auto guard_tag, const int it, u32x4 (&buf)[NLD]) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
     const int rt = gw + it * GW;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int id = p * 64 + lane;
-      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = BNB ? hdfuse::chunk(nxt[d][p], nyy[p], cf, bn.act) : nxt[d][p];
+      *reinterpret_cast<u32x4*>(area + Slab<K>::off(id / CPR, id % CPR)) = BNB ? hdfuse::chunk(buf[p], nyy[p], cf, bn.act) : buf[p];
     }
-    if (it + D < my) load_rows(rt + D * GW, nxt[d]);
+    if (D == 1 && it + D < my) load_rows(rt + D * GW, buf);
+    // ACC: the addend's chunks of this row block are requested now and consumed after the MFMA phase (a load -> add -> store
+    // chain inside the store loop made the fused form slower than the data gradient plus a separate add launch)
+    u32x4 racc[ACC ? TM : 1][ACC ? BN / 16 : 1];
+    if (ACC) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < BN / 16; ++q) {
+          const int id = q * 64 + lane, row = id / (BN / 8), c = id % (BN / 8);
+          int m = (rt * TM + i) * 32 + row;
+          m = m < M ? m : M - 1;
+          racc[i][q] = *reinterpret_cast<const u32x4*>(radd + (long long)m * ld_r + n0 + c * 8);
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before its lanes read each other's
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -351,17 +374,46 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // The operand fragments of k-step s + PD are requested before the MFMAs of k-step s are issued.  With one or two waves
+    // per SIMD nobody else covers an LDS round trip: the compiler's own schedule (read, wait, multiply, per fragment) left the
+    // deep variants 46 % of their wave cycles parked in s_waitcnt and the matrix pipe 20 % busy (PMC, 692 224 x 256 x 256).
+    constexpr int PD = (DEEP && K >= 128) ? 2 : 0;
+    if constexpr (PD == 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8 a[TM];
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 a[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(area + Slab<K>::off(i * 32 + frow, 2 * s + fh));
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(area + Slab<K>::off(i * 32 + frow, 2 * s + fh));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const bf16x8 b = TRB ? tr_fragment(smem, L::SLAB_ROW_T, j * 32, s * 16, lane)
-                             : *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 b = TRB ? tr_fragment(smem, L::SLAB_ROW_T, j * 32, s * 16, lane)
+                               : *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
+      bf16x8 fa[PD + 1][TM], fb[PD + 1][TN];
+      auto fetch = [&](int s, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(area + Slab<K>::off(i * 32 + frow, 2 * s + fh));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = TRB ? tr_fragment(smem, L::SLAB_ROW_T, j * 32, s * 16, lane)
+                     : *reinterpret_cast<const bf16x8*>(smem + Slab<K>::off(j * 32 + frow, 2 * s + fh));
+      };
+#pragma unroll
+      for (int s = 0; s < PD; ++s) fetch(s, fa[s], fb[s]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + PD < KS) fetch(s + PD, fa[(s + PD) % (PD + 1)], fb[(s + PD) % (PD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests above the multiplies they are meant to overlap
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % (PD + 1)][i], fb[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage reads done before the patch overwrites the area
@@ -387,10 +439,10 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
       for (int q = 0; q < BN / 16; ++q) {  // 32 rows x BN/8 chunks of 16 bytes over 64 lanes
         const int id = q * 64 + lane, row = id / (BN / 8), c = id % (BN / 8);
         uint4 v = *reinterpret_cast<const uint4*>(area + row * L::PATCH_ROW + c * 16);
-        if (m0 + row < M) {
+        if (!GUARD || m0 + row < M) {
           if (ACC) {
-            const uint4 r = *reinterpret_cast<const uint4*>(radd + (long long)(m0 + row) * ld_r + n0 + c * 8);
-            const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
+            const u32x4 r = racc[i][q];
+            const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r[0], r[1], r[2], r[3]};
             unsigned oo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -406,6 +458,26 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before it is overwritten
+    }
+    // D == 2: the loads of row block it + 2 are issued BEHIND this block's stores, so that everything older than the loads a
+    // block waits for is a full block old (vmcnt retires in issue order); rows past M are clamped inside load_rows
+    if (D > 1 && (!GUARD || it + D < my)) load_rows(rt + D * GW, buf);
+  };
+  {
+    const std::integral_constant<bool, true> guarded;
+    const std::integral_constant<bool, false> plain;
+    int it = 0;
+    if (D > 1) {
+      const int full_rt = M / (32 * TM);                                   // row blocks without rows past M
+      const int my_full = gw < full_rt ? (full_rt - 1 - gw) / GW + 1 : 0;  // this wave's share of them (<= my)
+      for (; it + 2 <= my_full; it += 2) {
+        block(plain, it, nxt[0]);
+        block(plain, it + 1, nxt[D - 1]);
+      }
+    }
+    for (; it < my; ++it) {  // D == 1: every block; D == 2: the last one or two, and the ragged one
+      if (D == 1 || (it & 1) == 0) block(guarded, it, nxt[0]);
+      else block(guarded, it, nxt[D - 1]);
     }
   }
 
@@ -429,6 +501,8 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   }
 }
 
+constexpr long long kDeepBlocks = 6;  // row blocks per wave from which the DEEP form of the streaming kernel is launched
+
 template <int K, int TN, int TM, bool TRB>
 hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats,
                         hipStream_t s, const hdfuse::BnBwd* bn = nullptr, const void* radd = nullptr, int64_t ld_r = 0) {
@@ -449,6 +523,8 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   auto* c = static_cast<unsigned short*>(Cmat);
   const hdfuse::BnBwd none = {};
   const unsigned short* no_add = nullptr;
+  // row blocks per wave of this launch: the deep form pays off from kDeepBlocks on (measured on the 640^2 and 832^2 pyramids)
+  const bool deep = K >= 128 && !bn && RT * NT >= kDeepBlocks * g * 4;
   if (bn) {
     if constexpr (TRB)
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c,
@@ -456,17 +532,32 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
     else
       return HD_ERR_SHAPE;
   } else if (radd) {
-    if constexpr (TRB)
-      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda,
-                      b, c, ldc, M, N, (float*)nullptr, none, static_cast<const unsigned short*>(radd), (long long)ld_r);
-    else
+    if constexpr (TRB) {
+      const auto* r = static_cast<const unsigned short*>(radd);
+      if (deep)
+        (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
+                        a, lda, b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r);
+      else
+        (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda,
+                        b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r);
+    } else {
       return HD_ERR_SHAPE;
-  } else if (stats && !TRB)
-    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, stats, none, no_add, 0ll);
-  else
-    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                    N, (float*)nullptr, none, no_add, 0ll);
+    }
+  } else if (stats && !TRB) {
+    if (deep)
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false, false, false, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
+                      a, lda, b, c, ldc, M, N, stats, none, no_add, 0ll);
+    else
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                      N, stats, none, no_add, 0ll);
+  } else {
+    if (deep)
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB, false, false, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
+                      a, lda, b, c, ldc, M, N, (float*)nullptr, none, no_add, 0ll);
+    else
+      (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
+                      N, (float*)nullptr, none, no_add, 0ll);
+  }
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -475,16 +566,22 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
 // Column tiles of one streaming launch: every row block is pulled through L2 once per column tile (the workgroups of one row
 // range sit on one XCD), so wide outputs cost L2 bandwidth, not HBM; 32 covers ResNet50's 256 -> 1024 / 1024 <- 256 layers.
 constexpr int kMaxColumnTiles = 32;
+constexpr long long kWideRows = 40000;    // rows from which the K = 256 kernels take 128-wide column tiles (see try_stream)
 
 template <int K, bool TRB = false>
 bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t ldc, int M, int N, float* stats, hipStream_t s,
                 hd_status* st, const hdfuse::BnBwd* bnb = nullptr, const void* radd = nullptr, int64_t ld_r = 0) {
-  constexpr int kMaxBN = K <= 128 ? 128 : 64;  // slab <= 32 KB
-  const int bn = N % 128 == 0 && kMaxBN >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
+  // K = 256: a 128-wide column tile needs a 64 KB slab (one workgroup per CU either way): its load is the start-up cost of the
+  // launch, which loses on the 40 x 40 / 20 x 20 levels (+3-5 us) and wins once there are enough row blocks per workgroup to
+  // amortise it — every row block is then pulled through L2 by N / 128 instead of N / 64 workgroups
+  static const char* wide_env = getenv("HD_STREAM_WIDE_ROWS");
+  const long long wide_rows = wide_env ? atoll(wide_env) : kWideRows;
+  const int max_bn = (K <= 128 || (M >= wide_rows && !bnb)) ? 128 : 64;
+  const int bn = N % 128 == 0 && max_bn >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > kMaxColumnTiles) return false;
   if (bn == 128) {
-    if constexpr (K <= 128) { *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r); return true; }
-    return false;
+    *st = launch_stream<K, 4, 1, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
+    return true;
   }
   if (bn == 64) {
     if constexpr (K <= 64) *st = launch_stream<K, 2, 2, TRB>(A, lda, Bw, Cmat, ldc, M, N, stats, s, bnb, radd, ld_r);
@@ -1262,6 +1359,12 @@ inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
   const bool big = (int64_t)Cin * Cout > 128 * 128;
   p.tm = Cout % 128 == 0 && big ? 2 : 1;
   p.tn = Cin % 128 == 0 && big ? 2 : 1;
+  static const char* force = getenv("HD_WGRAD_TILE");  // experiments only: "tm,tn"
+  if (force && force[0] && force[1] == ',' && force[2]) {
+    const int ftm = force[0] - '0', ftn = force[2] - '0';
+    if ((ftm == 1 || ftm == 2) && Cout % (64 * ftm) == 0) p.tm = ftm;
+    if ((ftn == 1 || ftn == 2) && Cin % (64 * ftn) == 0) p.tn = ftn;
+  }
   p.tiles = (Cout / (64 * p.tm)) * (Cin / (64 * p.tn));
   int s = 512 / p.tiles;  // ~2 workgroups per CU (256 measured equal within noise)
   const int64_t max_s = (R + 127) / 128;  // at least two 64-row steps per slice

@@ -7,7 +7,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import backbones, heads, necks, assigners  # noqa: F401  (registers the classes)
+from . import backbones, heads, layers, necks, assigners  # noqa: F401  (registers the classes)
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS
 
 
@@ -78,6 +78,19 @@ class FasterRCNN(nn.Module):
         self.roi_head = HEADS.build(roi_head)
 
     def extract(self, images):
+        if (self.training and layers.ConvBNAct.fork_shortcut and hasattr(self.neck, "lateral_fork")
+                and isinstance(self.backbone, backbones.ResNet50)):
+            # the neck's laterals run as taps on the stage outputs: each output's gradient then flows through one chain
+            # (lateral -> next stage's conv1 -> projection shortcut), every link adding the next one's gradient in its
+            # data-gradient epilogue
+            lats = [None] * len(self.backbone.out_channels)
+
+            def tap(i, f):
+                lats[i], alias = self.neck.lateral_fork(i, f)
+                return alias
+
+            feats = self.backbone(images, tap)
+            return self.neck(feats, lats)
         return self.neck(self.backbone(images))
 
     def forward_train(self, images, gt_boxes, gt_cls, m_valid):

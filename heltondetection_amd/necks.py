@@ -107,8 +107,13 @@ class PAFPN(nn.Module):
         self.p2_only = p2_only
         self.out_channels = out_channels
 
-    def forward(self, feats):
-        lat = [l(f) for l, f in zip(self.lateral, feats)]
+    def lateral_fork(self, i: int, feat):
+        """Lateral i on a backbone stage output, as a fork: -> (lateral, alias of feat for the backbone's next stage)."""
+        return self.lateral[i](feat, fork=True)
+
+    def forward(self, feats, laterals=None):
+        """laterals: the lateral maps when they were already taken through lateral_fork (backbone taps)."""
+        lat = list(laterals) if laterals is not None else [l(f) for l, f in zip(self.lateral, feats)]
         L = len(lat)
         td = [None] * L
         td[L - 1] = lat[L - 1]

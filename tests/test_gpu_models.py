@@ -432,3 +432,44 @@ def test_one_graph_replayed_optimizer_step_tracks_the_eager_step_fp32(gpu):
     pn = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(pg, pe))
     pd = sum(float((b.double() ** 2).sum()) for b in pe)
     assert (pn / pd) ** 0.5 < 2e-3   # parameters: the update difference above, relative to the weights' own size
+
+
+def test_stage_output_tap_chain_gives_the_gradients_of_the_plain_graph():
+    """A ResNet stage output feeding the neck's lateral (tap, fork), the next block's conv1 (fork) and its projection shortcut:
+    with the forks the stage output's gradient is accumulated inside the data-gradient kernels, without them by autograd's
+    adds — same values up to the BatchNorm sums' float atomics.  (Whole-model comparisons are meaningless here: two identical
+    bf16 runs of the random-init ResNet50 + PAFPN differ by 0.6 rel. L2 in their features, tools/tap_noise_probe.py.)"""
+    from heltondetection_amd import layers, ops
+    from heltondetection_amd.backbones import _ResBottleneck
+    from heltondetection_amd.layers import ConvBNAct, ShadowConv2d
+    gpu = torch.device("cuda:0")
+    torch.manual_seed(11)
+    ds = torch.nn.Sequential(ShadowConv2d(256, 512, 1, 2, bias=False), torch.nn.BatchNorm2d(512))
+    block = _ResBottleneck(256, 128, 2, ds).to(gpu).to(memory_format=torch.channels_last).train()
+    lateral = ConvBNAct(256, 256, 1, 1, act="silu").to(gpu).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((2, 256, 20, 24), device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g_lat = torch.randn((2, 256, 20, 24), device=gpu).contiguous(memory_format=torch.channels_last)
+    g_out = torch.randn((2, 512, 10, 12), device=gpu).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.fork_shortcut = on
+        try:
+            block.zero_grad(set_to_none=True); lateral.zero_grad(set_to_none=True)
+            ops.bn_arena_reset(gpu)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if on:
+                    lat, alias = lateral(x, fork=True)
+                    assert alias is not x and alias.data_ptr() == x.data_ptr()
+                else:
+                    lat, alias = lateral(x), x
+                out = block(alias)
+            ((lat.float() * g_lat).sum() + (out.float() * g_out).sum()).backward()
+            ops.flush_wgrad()
+            res[on] = [lat.detach().float(), out.detach().float(), x.grad.float().clone()] + \
+                      [p.grad.float().clone() for p in list(block.parameters()) + list(lateral.parameters())]
+        finally:
+            layers.ConvBNAct.fork_shortcut = True
+    for a, b in zip(res[True], res[False]):
+        tol = 2.0 ** -5 * b.abs() + 2.0 ** -5 * b.abs().mean() + 1e-7
+        assert bool(((a - b).abs() <= tol).all()), (tuple(a.shape), float(((a - b).abs() / tol).max()))

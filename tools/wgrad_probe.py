@@ -10,7 +10,10 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr())
 shapes = [(6400, 256, 256), (6400, 512, 512), (6400, 512, 256), (6400, 1024, 512), (25600, 128, 128), (25600, 256, 256),
           (25600, 512, 256), (102400, 64, 64), (102400, 128, 128), (102400, 256, 128), (409600, 64, 64), (409600, 32, 32)]
-NB, IT = 6, 30
+if "--frcnn" in sys.argv:  # ResNet50 + PAFPN at 832^2 bs16
+    shapes = [(692224, 64, 64), (692224, 64, 256), (692224, 256, 64), (173056, 256, 128), (173056, 128, 512), (173056, 512, 128),
+              (43264, 512, 256), (43264, 256, 1024), (43264, 1024, 256), (10816, 1024, 512), (173056, 512, 256), (692224, 256, 256)]
+NB, IT = (3, 10) if "--frcnn" in sys.argv else (6, 30)
 def timed(fn):
     for i in range(3): fn(i)
     torch.cuda.synchronize()
