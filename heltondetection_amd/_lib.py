@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -145,6 +145,8 @@ SIGNATURES = {
     "hd_adamw_multi": (_I, [_P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "hd_maxpool5_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_maxpool5_bwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "hd_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "hd_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_bn_act_replicas": (C.c_int, []),
     "hd_bn_act_stats": (_I, [_P, _I, _L, _I, _P, _P]),
     "hd_bn_act_apply": (_I, [_P, _I, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P, _P]),

@@ -8,6 +8,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from . import ops
 from .layers import C3, SPPF, ConvBNAct, FusedBNAct, ShadowConv2d, conv_bn_act
 from .registry import BACKBONES
 
@@ -130,7 +131,11 @@ class ResNet50(nn.Module):
         """tap(i, feature) -> feature: called on every stage output BEFORE the next stage reads it; a neck uses it to run its
         lateral 1x1 convolution as a `fork` (layers.conv_bn_act) and hand back the alias, so that the stage output's gradient is
         accumulated inside the data-gradient kernels of its consumers instead of by add launches (detectors.FasterRCNN)."""
-        x = self.maxpool(FusedBNAct.apply(self.bn1, self.conv1(x), "relu"))
+        x = FusedBNAct.apply(self.bn1, self.conv1(x), "relu")
+        if FusedBNAct.enabled and ops.maxpool3s2_supported(x):
+            x = ops.maxpool3s2(x)  # one byte of tap index per output, gather backward (csrc/pool.hip)
+        else:
+            x = self.maxpool(x)
         feats = []
         for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             x = layer(x)

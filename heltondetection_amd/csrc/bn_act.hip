@@ -127,10 +127,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   float s[V], ss[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) s[k] = ss[k] = 0.0f;
-  // Software-pipelined: the next four vectors are requested (unconditionally, so the compiler can count them) before the
-  // current four are consumed.  A load -> wait -> use loop keeps 4 x 16 bytes per lane in flight and then drains; with two
-  // workgroups per CU that is ~8 MB on the whole chip, i.e. ~4 TB/s at a 2 us loaded round trip (what these kernels reached).
-  auto fold4 = [&](const uint4* raw) {
+  long long i = i0;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float v[V];
@@ -140,34 +141,6 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         s[k] += v[k];
         ss[k] = fmaf(v[k], v[k], ss[k]);
       }
-    }
-  };
-  auto get4 = [&](long long at, uint4* raw) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (at + u * stride) * V);
-  };
-  // two named buffers, two batches per trip: with one buffer and a copy the compiler coalesces the copy away and sinks the
-  // loads below the uses again
-  long long i = i0;
-  const long long step = 4 * stride;
-  if (i + 3 * stride < nvec) {
-    uint4 qa[4], qb[4];
-    get4(i, qa);
-    i += step;
-    while (i + step + 3 * stride < nvec) {
-      get4(i, qb);
-      fold4(qa);
-      get4(i + step, qa);
-      fold4(qb);
-      i += 2 * step;
-    }
-    if (i + 3 * stride < nvec) {
-      get4(i, qb);
-      fold4(qa);
-      fold4(qb);
-      i += step;
-    } else {
-      fold4(qa);
     }
   }
   for (; i < nvec; i += stride) {
@@ -252,50 +225,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     a[k] = s_coef[g * V + k];
     b[k] = s_coef[C + g * V + k];
   }
-  // software-pipelined like bn_stats_kernel: the next four vectors are in flight while the current four are transformed and
-  // stored, and a wait on them does not include the stores issued after them (vmcnt retires in issue order)
-  auto get4 = [&](long long at, uint4* rx, uint4* rr) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) rx[u] = *reinterpret_cast<const uint4*>(x + (at + u * stride) * V);
-    if (RES != 0) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) rr[u] = *reinterpret_cast<const uint4*>(res + (at + u * stride) * V);
-    }
-  };
-  auto put4 = [&](long long at, const uint4* rx, const uint4* rr) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float v[V], rv[V];
-      RowVec<T>::unpack(rx[u], v);
-      if (RES != 0) RowVec<T>::unpack(rr[u], rv);
-#pragma unroll
-      for (int k = 0; k < V; ++k) {
-        const float z = fmaf(a[k], v[k], b[k]);
-        v[k] = RES == 0 ? act_fwd<ACT>(z) : (RES == 1 ? act_fwd<ACT>(z + rv[k]) : act_fwd<ACT>(z) + rv[k]);
-      }
-      RowVec<T>::store(y.at(at + u * stride, cg, C), v);
-    }
-  };
   long long i = i0;
-  const long long step = 4 * stride;
-  if (i + 3 * stride < nvec) {  // two named buffers, two batches per trip (see bn_stats_kernel)
-    uint4 xa[4], ra[RES != 0 ? 4 : 1], xb[4], rb[RES != 0 ? 4 : 1];
-    get4(i, xa, ra);
-    i += step;
-    while (i + step + 3 * stride < nvec) {
-      get4(i, xb, rb);
-      put4(i - step, xa, ra);
-      get4(i + step, xa, ra);
-      put4(i, xb, rb);
-      i += 2 * step;
-    }
-    if (i + 3 * stride < nvec) {
-      get4(i, xb, rb);
-      put4(i - step, xa, ra);
-      put4(i, xb, rb);
-      i += step;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
+    float v[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) RowVec<T>::load(x + (i + u * stride) * V, v[u]);
+    if (RES == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[u][k] = act_fwd<ACT>(fmaf(a[k], v[u][k], b[k]));
+        RowVec<T>::store(y.at(i + u * stride, cg, C), v[u]);
+      }
     } else {
-      put4(i - step, xa, ra);
+      float rv[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) RowVec<T>::load(res + (i + u * stride) * V, rv[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float z = fmaf(a[k], v[u][k], b[k]);
+          v[u][k] = RES == 1 ? act_fwd<ACT>(z + rv[u][k]) : act_fwd<ACT>(z) + rv[u][k];
+        }
+        RowVec<T>::store(y.at(i + u * stride, cg, C), v[u]);
+      }
     }
   }
   for (; i < nvec; i += stride) {
@@ -373,16 +327,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     be[k] = beta[c];
     s1[k] = s2[k] = 0.0f;
   }
-  // software-pipelined like bn_stats_kernel: the next two rows (x, dy [, res]) are in flight while the current two are folded
-  auto get2 = [&](long long at, uint4* rx, uint4* rg, uint4* rr) {
+  long long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
+    uint4 rx[2], rg[2], rr[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      rx[u] = *reinterpret_cast<const uint4*>(x + (at + u * stride) * V);
-      rg[u] = *reinterpret_cast<const uint4*>(dy.at(at + u * stride, cg, C));
-      if (RES) rr[u] = *reinterpret_cast<const uint4*>(res + (at + u * stride) * V);
+      rx[u] = *reinterpret_cast<const uint4*>(x + (i + u * stride) * V);
+      rg[u] = *reinterpret_cast<const uint4*>(dy.at(i + u * stride, cg, C));
+      if (RES) rr[u] = *reinterpret_cast<const uint4*>(res + (i + u * stride) * V);
     }
-  };
-  auto fold2 = [&](const uint4* rx, const uint4* rg, const uint4* rr) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       float xv[V], gv[V], rv[V];
@@ -398,28 +351,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         s1[k] += dz;
         s2[k] = fmaf(dz, xh, s2[k]);
       }
-    }
-  };
-  long long i = i0;
-  const long long step = 2 * stride;
-  if (i + stride < nvec) {  // two named buffers, two batches per trip (see bn_stats_kernel)
-    uint4 xa[2], ga2[2], ra[RES ? 2 : 1], xb[2], gb2[2], rb[RES ? 2 : 1];
-    get2(i, xa, ga2, ra);
-    i += step;
-    while (i + step + stride < nvec) {
-      get2(i, xb, gb2, rb);
-      fold2(xa, ga2, ra);
-      get2(i + step, xa, ga2, ra);
-      fold2(xb, gb2, rb);
-      i += 2 * step;
-    }
-    if (i + stride < nvec) {
-      get2(i, xb, gb2, rb);
-      fold2(xa, ga2, ra);
-      fold2(xb, gb2, rb);
-      i += step;
-    } else {
-      fold2(xa, ga2, ra);
     }
   }
   for (; i < nvec; i += stride) {
@@ -481,54 +412,27 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
     P[k] = -A[k] * s_coef[C + c] * is;
     Q[k] = -A[k] * (s_coef[c] + s_coef[C + c] * c0);
   }
-  // software-pipelined like bn_apply_kernel: the next two rows are in flight while the current two are transformed and stored
-  auto get2 = [&](long long at, uint4* rx, uint4* rg, uint4* rr) {
+  long long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {  // 4 independent 16-byte loads in flight per lane
+    float xv[2][V], gv[2][V], rv[2][V];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      rx[u] = *reinterpret_cast<const uint4*>(x + (at + u * stride) * V);
-      rg[u] = *reinterpret_cast<const uint4*>(dy.at(at + u * stride, cg, C));
-      if (RES) rr[u] = *reinterpret_cast<const uint4*>(res + (at + u * stride) * V);
+      RowVec<T>::load(x + (i + u * stride) * V, xv[u]);
+      RowVec<T>::load(dy.at(i + u * stride, cg, C), gv[u]);
+      if (RES) RowVec<T>::load(res + (i + u * stride) * V, rv[u]);
     }
-  };
-  auto put2 = [&](long long at, const uint4* rx, const uint4* rg, const uint4* rr) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      float xv[V], gv[V], rv[V];
-      RowVec<T>::unpack(rx[u], xv);
-      RowVec<T>::unpack(rg[u], gv);
-      if (RES) RowVec<T>::unpack(rr[u], rv);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        float z = fmaf(az[k], xv[k], bz[k]);
-        if (RES) z += rv[k];
-        const float dz = gv[k] * act_grad<ACT>(z);
-        xv[k] = fmaf(A[k], dz, fmaf(P[k], xv[k], Q[k]));
-        if (RES) rv[k] = dz;  // d(res) = dz
+        float z = fmaf(az[k], xv[u][k], bz[k]);
+        if (RES) z += rv[u][k];
+        const float dz = gv[u][k] * act_grad<ACT>(z);
+        xv[u][k] = fmaf(A[k], dz, fmaf(P[k], xv[u][k], Q[k]));
+        if (RES) rv[u][k] = dz;  // d(res) = dz
       }
-      RowVec<T>::store(dx + (at + u * stride) * V, xv);
-      if (RES) RowVec<T>::store(dres + (at + u * stride) * V, rv);
-    }
-  };
-  long long i = i0;
-  const long long step = 2 * stride;
-  if (i + stride < nvec) {  // two named buffers, two batches per trip (see bn_stats_kernel)
-    uint4 xa[2], ga2[2], ra[RES ? 2 : 1], xb[2], gb2[2], rb[RES ? 2 : 1];
-    get2(i, xa, ga2, ra);
-    i += step;
-    while (i + step + stride < nvec) {
-      get2(i, xb, gb2, rb);
-      put2(i - step, xa, ga2, ra);
-      get2(i + step, xa, ga2, ra);
-      put2(i, xb, gb2, rb);
-      i += 2 * step;
-    }
-    if (i + stride < nvec) {
-      get2(i, xb, gb2, rb);
-      put2(i - step, xa, ga2, ra);
-      put2(i, xb, gb2, rb);
-      i += step;
-    } else {
-      put2(i - step, xa, ga2, ra);
+      RowVec<T>::store(dx + (i + u * stride) * V, xv[u]);
+      if (RES) RowVec<T>::store(dres + (i + u * stride) * V, rv[u]);
     }
   }
   for (; i < nvec; i += stride) {

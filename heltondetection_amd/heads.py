@@ -140,16 +140,27 @@ class RPNHead(nn.Module):
         logits, deltas = [], []
         # objectness and box deltas come out of ONE 1x1 convolution with the two weights stacked (A + 4A outputs): the hidden
         # map is read once forward, and backward it receives one data gradient instead of two 256-channel maps plus their sum
+        # The stack is padded to a multiple of 8 channels and run WITHOUT bias; ops.bias_act adds it in place and takes its
+        # gradient in one pass: the library's bias gradient of a 15-channel channels-last map is a strided reduction that
+        # took 1.1 ms at the 208 x 208 level of config 3 (profiles/r03_frcnn_step_order.txt history in DESIGN.md section 8).
         A = self.A
-        w = torch.cat([self.obj.lp_weight(), self.reg.lp_weight()], 0)
-        b = torch.cat([self.obj.bias, self.reg.bias], 0)
+        wo, wr = self.obj.lp_weight(), self.reg.lp_weight()
+        pad = (-5 * A) % 8
+        ws = [wo, wr] + ([wo.new_zeros((pad,) + tuple(wo.shape[1:]))] if pad else [])
+        bs = [self.obj.bias, self.reg.bias] + ([self.obj.bias.new_zeros(pad)] if pad else [])
+        w, b = torch.cat(ws, 0), torch.cat(bs, 0)
         for f in feats:
             t = conv_bias_act(self.conv, f, "relu")  # bias + ReLU in one in-place pass after the bias-free convolution
             B = t.shape[0]
-            o = F.conv2d(t, w, b).float()
+            o = F.conv2d(t, w.to(t.dtype) if w.dtype != t.dtype and not torch.is_autocast_enabled() else w)
+            if ops.bias_act_supported(o, None):
+                o = ops.bias_act(o, b, None, inplace=True)
+            else:
+                o = o + b.to(o.dtype)[None, :, None, None]
+            o = o.float()
             # channels-last conv outputs: permute(0,2,3,1) is a free view; order = (y, x, anchor)
             logits.append(o[:, :A].permute(0, 2, 3, 1).reshape(B, -1))
-            deltas.append(o[:, A:].permute(0, 2, 3, 1).reshape(B, -1, 4))
+            deltas.append(o[:, A:5 * A].permute(0, 2, 3, 1).reshape(B, -1, 4))
         return torch.cat(logits, 1), torch.cat(deltas, 1)
 
     @torch.no_grad()

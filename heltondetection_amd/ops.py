@@ -781,6 +781,49 @@ def maxpool5(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return _MaxPool5Fn.apply(x, _OutSlot(out) if out is not None else None)
 
 
+class _MaxPool3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        dt = {torch.float32: 0, torch.bfloat16: 1}[x.dtype]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((B, Cc, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        check(lib.hd_maxpool3s2_fwd(_ptr(x), dt, B, H, W, Cc, _ptr(out), _ptr(idx), _stream(x)), "hd_maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.meta = (dt, B, H, W, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        dt, B, H, W, Cc = ctx.meta
+        want = torch.float32 if dt == 0 else torch.bfloat16
+        if g.dtype != want or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.to(want).contiguous(memory_format=torch.channels_last)
+        gin = torch.empty((B, Cc, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        check(lib.hd_maxpool3s2_bwd(_ptr(g), _ptr(idx), dt, B, H, W, Cc, _ptr(gin), _stream(g)), "hd_maxpool3s2_bwd")
+        return gin
+
+
+def maxpool3s2_supported(x: torch.Tensor) -> bool:
+    """HIP path of the 3x3 / stride 2 / pad 1 max-pool: a dense channels-last float32 (C % 4 == 0) / bfloat16 (C % 8 == 0) tensor."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    vec = 4 if x.dtype == torch.float32 else 8
+    return x.shape[1] % vec == 0 and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
+
+
+def maxpool3s2(x: torch.Tensor) -> torch.Tensor:
+    """3x3 / stride 2 / pad 1 max-pool (the ResNet stem) on a dense channels-last HIP tensor (csrc/pool.hip): one byte of tap
+    index per output element, gather backward without atomics; values and gradients equal F.max_pool2d(x, 3, 2, 1)."""
+    if not maxpool3s2_supported(x):
+        raise _lib.HdError("maxpool3s2: needs a dense channels-last float32/bfloat16 HIP tensor")
+    return _MaxPool3s2Fn.apply(x)
+
+
 # ------------------------------------------------------------------------------- fused BN + act
 _ACT_CODE = {None: 0, "none": 0, "silu": 1, "relu": 2}
 

@@ -354,6 +354,12 @@ hd_status hd_maxpool5_fwd(const void* in, int64_t in_row_stride, int dtype, int 
                           void* out, int64_t out_row_stride, uint8_t* idx, hd_stream stream);
 hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, const uint8_t* idx, int dtype,
                           int B, int H, int W, int C, void* grad_in, hd_stream stream);
+/* 3x3 / stride 2 / pad 1 max-pool (the ResNet50 stem, reference README.md:8) on DENSE channels-last tensors: in [B, H, W, C]
+ * -> out [B, Ho, Wo, C] with Ho = (H - 1) / 2 + 1; idx: one byte per OUTPUT element (winning tap 0..8), dense.  Backward is
+ * the gather form (an input pixel sits under at most 2 x 2 windows): grad_in [B, H, W, C] from grad_out / idx, no atomics. */
+hd_status hd_maxpool3s2_fwd(const void* in, int dtype, int B, int H, int W, int C, void* out, uint8_t* idx, hd_stream stream);
+hd_status hd_maxpool3s2_bwd(const void* grad_out, const uint8_t* idx, int dtype, int B, int H, int W, int C, void* grad_in,
+                            hd_stream stream);
 
 /* Fused BatchNorm2d (batch statistics) + activation on a dense channels-last tensor seen as rows
  * [R = B*H*W, C]; dtype 0 = float32 (C % 4 == 0), 1 = bfloat16 (C % 8 == 0); C/vec <= 256.

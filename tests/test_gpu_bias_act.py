@@ -98,3 +98,28 @@ def test_rpn_head_matches_the_three_separate_biased_convolutions():
         l2 = float((a - b).norm() / (b.norm() + 1e-12))
         mx = float((a - b).abs().max() / (b.abs().max() + 1e-12))
         assert l2 < 1e-2 and mx < 2.0 ** -4, (tuple(a.shape), l2, mx)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 24), (1, 8, 7, 9), (3, 24, 13, 1), (1, 16, 1, 5), (2, 64, 52, 52), (1, 8, 2, 2)])
+def test_maxpool3s2_equals_the_library_pool_forward_and_backward(shape, dtype):
+    """hd_maxpool3s2_fwd / _bwd (the ResNet stem's pooling): values and gradients equal F.max_pool2d(x, 3, 2, 1) exactly, odd
+    and even sizes.  The input takes nine distinct small integers arranged so that every 3x3 window sees each at most once
+    (value = perm[b, c][(h % 3) * 3 + w % 3]): the argmax is unique, so the two implementations must agree bit for bit."""
+    import torch.nn.functional as F
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    perm = torch.stack([torch.randperm(9, generator=g) for _ in range(B * C)]).view(B, C, 9).float()
+    cell = (torch.arange(H).view(H, 1) % 3) * 3 + (torch.arange(W).view(1, W) % 3)
+    x0 = perm[:, :, cell.reshape(-1)].view(B, C, H, W) - 4.0
+    x = _cl(x0.to(dev).to(dtype)).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = ops.maxpool3s2(x)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, ref)
+    gy = _cl(torch.randint(-3, 4, ref.shape, generator=g).float().to(dev).to(dtype))
+    y.backward(gy)
+    ref.backward(gy)
+    assert torch.equal(x.grad, xr.grad)
