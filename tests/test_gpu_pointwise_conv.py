@@ -460,3 +460,48 @@ def test_bottleneck_shortcut_gradient_through_the_fork_matches_autograd_add(c, h
     for a, b in zip(res[True], res[False]):
         tol = 2.0 ** -6 * b.abs() + 2.0 ** -6 * b.abs().mean() + 1e-7
         assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+
+
+# ---- the DEEP (long-launch) form of the streaming kernels: >= 6 row blocks per wave, K >= 128 ------------------------------
+# (B, Cin, H, W, Cout): 128-wide column tiles for K = 256 (rows >= 40 000), the 64-wide ones below that, K = 128 at 208 x 208,
+# ragged row counts (the peeled last blocks), many column tiles
+DEEP_SHAPES = [(16, 256, 104, 104, 256), (1, 256, 419, 413, 256), (3, 256, 113, 117, 512), (16, 128, 208, 208, 128),
+               (1, 128, 833, 829, 128), (2, 256, 157, 127, 64)]
+
+
+@pytest.mark.parametrize("shape", DEEP_SHAPES)
+def test_deep_streaming_form_is_exact_on_integer_data_forward_gradient_and_fused_add(shape):
+    """Small integers (exact sums in float32, results exactly representable in bf16): the long-launch form of
+    hd_pointwise_conv / _dgrad / _dgrad_add — two row blocks of lookahead, peeled guarded blocks, fragments two k-steps ahead —
+    must reproduce the float32 matmul exactly, statistics included, on full and ragged row counts."""
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H)
+    x = torch.randint(-2, 3, (B, K, H, W), generator=g, dtype=torch.int8).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randint(-1, 2, (N, K), generator=g, dtype=torch.int8).to(dev).to(torch.bfloat16)
+    # sparse weights keep most results below 256, where every integer is a bf16 value (larger ones round once, as the reference)
+    keep = (torch.rand((N, K), generator=g) < 64.0 / K).to(dev)
+    w = torch.where(keep, w, torch.zeros_like(w))
+    lib = _lib.load()
+    rep = lib.hd_bn_act_replicas()
+    stats = torch.zeros(rep * 2 * N, dtype=torch.float32, device=dev)
+    y = ops.pointwise_conv_rows(x, w, stats)
+    R = B * H * W
+    xr = x.permute(0, 2, 3, 1).reshape(R, K).float()
+    ref = (xr @ w.float().t()).to(torch.bfloat16).float()  # exact integer sums, one rounding to bf16 (exact up to 256)
+    got = y.permute(0, 2, 3, 1).reshape(R, N).float()
+    assert torch.equal(got, ref)
+    want = torch.stack([ref.double().sum(0), (ref.double() ** 2).sum(0)])
+    have = stats.view(rep, 2, N).double().sum(0)
+    assert float(((have - want).abs() / (want.abs() + 1.0)).max()) < 1e-6
+    # data gradient of the same layer (dy has N channels, the result K) and its fused-add form
+    if lib.hd_pointwise_conv_dgrad_supported(R, K, N):
+        dy = torch.randint(-2, 3, (B, N, H, W), generator=g, dtype=torch.int8).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dref = (dy.permute(0, 2, 3, 1).reshape(R, N).float() @ w.float()).to(torch.bfloat16).float()
+        dx = ops.pointwise_dgrad_rows(dy, w)
+        assert torch.equal(dx.permute(0, 2, 3, 1).reshape(R, K).float(), dref)
+        r = torch.randint(-3, 4, (B, K, H, W), generator=g, dtype=torch.int8).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dxa = ops.pointwise_dgrad_rows(dy, w, add=r)
+        want_a = (dref + r.permute(0, 2, 3, 1).reshape(R, K).float()).to(torch.bfloat16).float()
+        assert torch.equal(dxa.permute(0, 2, 3, 1).reshape(R, K).float(), want_a)
