@@ -576,7 +576,11 @@ bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t 
   // amortise it — every row block is then pulled through L2 by N / 128 instead of N / 64 workgroups
   static const char* wide_env = getenv("HD_STREAM_WIDE_ROWS");
   const long long wide_rows = wide_env ? atoll(wide_env) : kWideRows;
-  const int max_bn = (K <= 128 || (M >= wide_rows && !bnb)) ? 128 : 64;
+  // ... and only for launches that take the deep form: a 128-wide tile in the short form was measured slower wherever it ran
+  // (the 80 x 80 level of YOLOv5l: +0.4 ms per step): the wide launch has N / 128 column tiles on <= 256 workgroups
+  const long long wide_blocks = ((long long)M + 31) / 32 * (N / 128);
+  const bool wide = K > 128 && !bnb && M >= wide_rows && N % 128 == 0 && wide_blocks >= kDeepBlocks * 256 * 4;
+  const int max_bn = (K <= 128 || wide) ? 128 : 64;
   const int bn = N % 128 == 0 && max_bn >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > kMaxColumnTiles) return false;
   if (bn == 128) {
