@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 

@@ -5,7 +5,8 @@
 // float32 masters by another two 26 us multi-tensor launches at the head of every step.  Here a descriptor table
 // (device-resident, built once) lists every tensor's parameter / gradient / moment pointers, and a chunk list maps
 // workgroups to (tensor, offset) ranges of 16 K elements, so one launch streams p, g, m, v once and writes p, m, v and the
-// bf16 shadow: 30 bytes per parameter, HBM-bound.
+// bf16 shadow: 30 bytes per parameter, HBM-bound.  Gradients are float32 or (g_dtype 1) bfloat16 — the weight shadows'
+// own gradients, read where autograd left them when no exchange has to pack them first (one rank).
 // Arithmetic follows torch.optim.AdamW (decoupled weight decay, bias corrections folded on the host):
 //   p *= 1 - lr wd;  m += (1 - b1)(g - m);  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps).
 #include <hip/hip_bf16.h>
@@ -35,17 +36,26 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const hd_adamw_tensor*
   const long long end = start + chunk_elems < d.n ? start + chunk_elems : d.n;
   float* __restrict__ p = static_cast<float*>(d.p);
   const float* __restrict__ g = static_cast<const float*>(d.g);
+  const unsigned short* __restrict__ gh = static_cast<const unsigned short*>(d.g);  // g_dtype 1: bfloat16 gradients
+  const bool g16 = d.g_dtype == 1;
   float* __restrict__ m = static_cast<float*>(d.m);
   float* __restrict__ v = static_cast<float*>(d.v);
   unsigned short* __restrict__ sh = static_cast<unsigned short*>(d.shadow);
   const float decay = 1.0f - lr * d.weight_decay;
-  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                     reinterpret_cast<uintptr_t>(v)) & 15u) == 0 && (!sh || (reinterpret_cast<uintptr_t>(sh) & 7u) == 0);
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 &&
+                   (reinterpret_cast<uintptr_t>(g) & (g16 ? 7u : 15u)) == 0 && (!sh || (reinterpret_cast<uintptr_t>(sh) & 7u) == 0);
   long long i = start + (long long)threadIdx.x * 4;
   if (vec) {
     for (; i + 3 < end; i += 1024) {
       float4 pv = *reinterpret_cast<const float4*>(p + i);
-      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 gv;
+      if (g16) {
+        const uint2 r = *reinterpret_cast<const uint2*>(gh + i);
+        gv = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                         __uint_as_float(r.y & 0xffff0000u));
+      } else {
+        gv = *reinterpret_cast<const float4*>(g + i);
+      }
       float4 mv = *reinterpret_cast<const float4*>(m + i);
       float4 vv = *reinterpret_cast<const float4*>(v + i);
       pv.x = adamw_one(pv.x, gv.x, mv.x, vv.x, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
@@ -70,7 +80,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const hd_adamw_tensor*
   }
   for (; i < end; i += vec ? end : 256) {
     float mv = m[i], vv = v[i];
-    const float pn = adamw_one(p[i], g[i], mv, vv, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
+    const float gi = g16 ? __uint_as_float((unsigned)gh[i] << 16) : g[i];
+    const float pn = adamw_one(p[i], gi, mv, vv, decay, b1c, b2, b2c, step_size, inv_sqrt_bc2, eps);
     p[i] = pn;
     m[i] = mv;
     v[i] = vv;

@@ -62,7 +62,7 @@ class _Bucket:
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, first_bucket_bytes: int = 4 << 20,
                  process_group=None, broadcast_params: bool = True, defer_collectives: bool = False,
-                 grad_sources: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None):
+                 grad_sources: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None, direct: bool = False):
         self.module = module
         # grad_sources: parameter -> the leaf tensor that receives its gradient instead of the parameter
         # (a bf16 weight shadow, train.LowpShadows); the bucket copy converts to fp32 while packing
@@ -72,6 +72,11 @@ class GradReducer:
         self.defer = defer_collectives
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # direct (one rank only): nothing is exchanged, so nothing is packed either — gradients stay where autograd left them
+        # (float32 on the parameters, bfloat16 on the weight shadows) and the optimizer reads them there (optim.HdAdamW with
+        # grad_from_shadows): two multi-tensor copies of all gradients per step less.  Parameters without a gradient are then
+        # SKIPPED by the optimizer (torch.optim semantics) instead of receiving zeros.
+        self.direct = bool(direct) and self.world == 1
         params = [p for p in module.parameters() if p.requires_grad]
         if self.world > 1 and broadcast_params:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -123,6 +128,10 @@ class GradReducer:
         parameters, bf16 from weight shadows — _foreach_copy_ keeps its single-launch path only for
         dtype-homogeneous lists), zero-fills the slots of parameters that received no gradient this step, and
         re-points .grad at the views.  Never launches a collective: that is _flush()'s job, in bucket order."""
+        if self.direct:
+            b.pending = 0
+            b.packed = True
+            return
         if b.flat.is_cuda:
             from . import ops
             ops.flush_wgrad()   # a chained weight gradient is complete only once its slice sum has been launched

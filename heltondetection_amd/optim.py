@@ -20,7 +20,7 @@ _CHUNK = 16384
 
 class _Desc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
-                ("n", C.c_int64), ("weight_decay", C.c_float), ("reserved", C.c_int32)]
+                ("n", C.c_int64), ("weight_decay", C.c_float), ("g_dtype", C.c_int32)]
 
 
 class HdAdamW(torch.optim.AdamW):
@@ -29,6 +29,15 @@ class HdAdamW(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self.shadows = dict(shadows or {})   # float32 master parameter -> its bf16 shadow (same memory order)
         self._tables = None                  # per group: (descriptor tensor, chunk_tensor, chunk_start, n_chunks, key)
+        # True: a parameter whose own .grad is None takes the gradient of its shadow (bfloat16) where autograd left it — the
+        # one-rank form of train.Trainer, where no exchange packs the gradients into float32 buckets first
+        self.grad_from_shadows = False
+
+    def _grad(self, p):
+        if p.grad is not None or not self.grad_from_shadows:
+            return p.grad
+        sh = self.shadows.get(p)
+        return sh.grad if sh is not None else None
 
     @property
     def writes_shadows(self) -> bool:
@@ -39,7 +48,7 @@ class HdAdamW(torch.optim.AdamW):
         self._tables = None
 
     def _key(self, group):
-        return tuple((p.data_ptr(), p.grad.data_ptr()) for p in group["params"] if p.grad is not None)
+        return tuple((p.data_ptr(), g.data_ptr()) for p, g in ((p, self._grad(p)) for p in group["params"]) if g is not None)
 
     def _step_of(self, p) -> float:
         st = self.state.get(p)
@@ -50,7 +59,7 @@ class HdAdamW(torch.optim.AdamW):
         step per parameter; they differ when a parameter started receiving gradients later or after a loaded state_dict with
         mixed counts, and the bias corrections are per step count).  Parameters advance together afterwards, so the
         partition stays valid until the gradient set changes (the key)."""
-        ps_all = [p for p in group["params"] if p.grad is not None]
+        ps_all = [p for p in group["params"] if self._grad(p) is not None]
         if not ps_all:
             return None
         by_step = {}
@@ -67,14 +76,16 @@ class HdAdamW(torch.optim.AdamW):
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            g, m, v, sh = p.grad, st["exp_avg"], st["exp_avg_sq"], self.shadows.get(p)
+            g, m, v, sh = self._grad(p), st["exp_avg"], st["exp_avg_sq"], self.shadows.get(p)
             for t, what in ((p, "parameter"), (g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")):
-                if t.dtype != torch.float32 or t.device != dev or t.stride() != p.stride() or not _dense(t):
-                    raise _lib.HdError(f"HdAdamW: {what} must be a dense float32 tensor in the parameter's memory order")
-            if sh is not None and (sh.dtype != torch.bfloat16 or sh.stride() != p.stride() or sh.shape != p.shape):
+                ok_dtype = t.dtype == torch.float32 or (what == "gradient" and t.dtype == torch.bfloat16)
+                if not ok_dtype or t.device != dev or not _same_order(t, p) or not _dense(t):
+                    raise _lib.HdError(f"HdAdamW: {what} must be a dense float32 tensor (gradients: or bfloat16) in the "
+                                       f"parameter's memory order")
+            if sh is not None and (sh.dtype != torch.bfloat16 or not _same_order(sh, p)):
                 raise _lib.HdError("HdAdamW: a shadow must be a bfloat16 tensor of the parameter's shape and memory order")
             descs[i] = _Desc(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else None,
-                             p.numel(), float(group["weight_decay"]), 0)
+                             p.numel(), float(group["weight_decay"]), 1 if g.dtype == torch.bfloat16 else 0)
             for start in range(0, p.numel(), _CHUNK):
                 ct.append(i)
                 cs.append(start)
@@ -108,6 +119,12 @@ class HdAdamW(torch.optim.AdamW):
                 if rc != 0:
                     raise _lib.HdError(f"hd_adamw_multi failed ({rc})")
         return loss
+
+
+def _same_order(t: torch.Tensor, p: torch.Tensor) -> bool:
+    """Same shape and the same strides on every dimension that has more than one element (the stride of a size-1 dimension is
+    arbitrary: a [N, K, 1, 1] gradient viewed from a [N, K] matrix and its channels-last parameter share one memory order)."""
+    return t.shape == p.shape and all(a == b for a, b, n in zip(t.stride(), p.stride(), t.shape) if n > 1)
 
 
 def _dense(t: torch.Tensor) -> bool:

@@ -91,9 +91,12 @@ class Trainer:
         if os.environ.get("HD_GRAPH_SPLIT") == "0" and graph_split != "force":
             graph_split = False
         self.graph_split = bool(graph_split) and self.use_graph and (world > 1 or graph_split == "force")
+        # one rank + the HIP optimizer: no packing at all, HdAdamW reads the gradients where autograd left them
+        direct = (world == 1 and self.device.type == "cuda" and hd_optimizer and not self.graph_split
+                  and os.environ.get("HD_DIRECT_GRADS", "1") != "0")
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes,
                                    defer_collectives=self.use_graph and not self.graph_split,
-                                   grad_sources=self.shadows.grad_sources() if self.shadows else None)
+                                   grad_sources=self.shadows.grad_sources() if self.shadows else None, direct=direct)
         # graph_sync: drain the stream after every replayed graph / segment before the collectives are launched.
         # Needed only for the gloo REHEARSAL backend (several ranks time-slicing one GPU): gloo's worker thread
         # blocks on a host-side stream synchronise for its D2H staging copy, and with two processes sharing the
@@ -120,6 +123,7 @@ class Trainer:
             from .optim import HdAdamW
             self.opt = HdAdamW(groups, lr=lr, betas=(0.937, 0.999),
                                shadows=self.shadows.grad_sources() if self.shadows else None)
+            self.opt.grad_from_shadows = self.reducer.direct
         else:
             self.opt = torch.optim.AdamW(groups, lr=lr, betas=(0.937, 0.999), fused=self.device.type == "cuda")
         self._shadows_dirty = True  # the shadows start uninitialised; weights_changed() marks them stale again
@@ -145,6 +149,15 @@ class Trainer:
         self.verify_overlap = os.environ.get("HD_GRAPH_VERIFY_OVERLAP", "1") != "0"
         self.graph_overlap_check = None
         self.graph_overlap_error = None
+
+    def grad_of(self, p: torch.nn.Parameter):
+        """The gradient the last step left for parameter `p` (float32 copy / tensor), or None.  With several ranks every
+        parameter's .grad is a float32 view of its (averaged) bucket; with ONE rank and the HIP optimizer nothing is packed:
+        a convolution weight's gradient then lives on its bfloat16 shadow and `p.grad` is None (GradReducer `direct`)."""
+        if p.grad is not None:
+            return p.grad
+        src = self.shadows.grad_sources().get(p) if self.shadows is not None else None
+        return src.grad.float() if src is not None and src.grad is not None else None
 
     def _fwd_bwd(self, images, gt_boxes, gt_cls, m_valid):
         self.reducer.prepare()

@@ -578,7 +578,7 @@ typedef struct hd_adamw_tensor {
   void* shadow;
   int64_t n;
   float weight_decay;
-  int32_t reserved;
+  int32_t g_dtype; /* dtype of g: 0 = float32, 1 = bfloat16 */
 } hd_adamw_tensor;
 hd_status hd_adamw_multi(const hd_adamw_tensor* tensors, const int32_t* chunk_tensor, const int64_t* chunk_start, int n_chunks,
                          int chunk_elems, double lr, double beta1, double beta2, double eps, double bc1, double bc2,

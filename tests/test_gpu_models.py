@@ -36,7 +36,8 @@ def test_yolov5s_overfits_one_batch_and_detects(gpu, focal):
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     for p in model.parameters():
-        assert p.grad is not None and torch.isfinite(p.grad).all()
+        g = tr.grad_of(p)  # one rank: a weight's gradient stays on its bf16 shadow (Trainer.grad_of)
+        assert g is not None and torch.isfinite(g).all()
     model.eval()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         det, cnt = model.forward_test(batch[0], conf_thr=0.001, iou_thr=0.45, max_nms=2000, max_det=50)
@@ -90,8 +91,12 @@ def test_faster_rcnn_trains_and_detects(gpu, cfg):
         assert torch.isfinite(parts).all()
         first = float(loss) if first is None else first
     assert float(loss) < first * 1.5
-    n_with_grad = sum(1 for p in model.parameters() if p.grad is not None and torch.isfinite(p.grad).all())
-    assert n_with_grad == sum(1 for p in model.parameters() if p.requires_grad)
+    gs = [tr.grad_of(p) for p in model.parameters() if p.requires_grad]
+    assert all(torch.isfinite(g).all() for g in gs if g is not None)
+    # one rank: parameters the step does not reach (the bottom-up path of a P2-only neck) have NO gradient and are skipped by
+    # the optimizer, as in plain PyTorch; with several ranks their bucket slots carry zeros (dist.GradReducer)
+    unused_ok = bool(getattr(model.neck, "p2_only", False))
+    assert sum(g is not None for g in gs) == len(gs) or (unused_ok and sum(g is not None for g in gs) > 0.5 * len(gs))
     model.eval()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         det, cnt = model.forward_test(batch[0])
@@ -149,8 +154,9 @@ def test_lowp_weight_shadows_match_autocast_casts(gpu):
         assert all((m.weight_lp is not None) == lowp for m in convs)
         loss0, _ = tr._fwd_bwd(*batch)
         tr.reducer.finish()
-        assert all(m.weight.grad.dtype == torch.float32 and m.weight.grad.shape == m.weight.shape for m in convs)
-        out[lowp] = (float(loss0), [m.weight.grad.clone() for m in convs], model.c2.bias.grad.clone())
+        gs = [tr.grad_of(m.weight) for m in convs]
+        assert all(g.dtype == torch.float32 and g.shape == m.weight.shape for g, m in zip(gs, convs))
+        out[lowp] = (float(loss0), [g.clone() for g in gs], model.c2.bias.grad.clone())
         if lowp:
             before = model.c2.weight.detach().clone()
             losses = [float(tr.step(*batch)[0]) for _ in range(6)]
@@ -264,7 +270,7 @@ def test_other_yolov5_widths_train_and_detect(gpu, variant):
     losses = [float(tr.step(*batch)[0]) for _ in range(8)]
     assert tr._graph is not None, tr.graph_error
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
-    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert all(torch.isfinite(tr.grad_of(p)).all() for p in model.parameters() if tr.grad_of(p) is not None)
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         det, cnt = model.forward_test(batch[0], conf_thr=0.01)
@@ -294,7 +300,7 @@ def test_yolov5l_640_bs16_graph_replayed_steps(gpu):
         # the first dozen AdamW steps of a random-init `l` model at lr 1e-3 plateau (eager and replayed alike,
         # scratch/graph_probe3.py); "decreasing" is judged on window means over 21 replayed steps
         assert len(replayed) >= 8 and np.mean(replayed[-4:]) < np.mean(replayed[:4]) and losses[-1] < losses[0], losses
-        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        assert all(torch.isfinite(tr.grad_of(p)).all() for p in model.parameters() if tr.grad_of(p) is not None)
     finally:
         torch.backends.cudnn.benchmark = was
 
@@ -355,7 +361,7 @@ def test_config5_faster_rcnn_pafpn_1280_visdrone_graph_steps(gpu):
         assert tr._graph is not None, tr.graph_error
         assert np.isfinite(losses).all() and torch.isfinite(parts).all(), losses
         assert losses[-1] < 1.5 * losses[0]
-        n_with_grad = sum(1 for p in model.parameters() if p.grad is not None and torch.isfinite(p.grad).all())
+        n_with_grad = sum(1 for p in model.parameters() if tr.grad_of(p) is not None and torch.isfinite(tr.grad_of(p)).all())
         assert n_with_grad == sum(1 for p in model.parameters() if p.requires_grad)
         # the detector's own anchor set at this resolution is config 5's: 5 levels x 3 anchors over 1280^2
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):

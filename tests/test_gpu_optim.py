@@ -81,3 +81,41 @@ def test_trainer_with_hd_adamw_tracks_torch_adamw():
             for master, shadow in tr.shadows.grad_sources().items():
                 assert torch.equal(shadow.detach(), master.detach().to(torch.bfloat16))
     assert abs(losses[True][0] - losses[False][0]) < 1e-3 * abs(losses[False][0]) + 1e-4  # same first step
+
+
+def test_hd_adamw_reads_bfloat16_gradients_from_the_shadows():
+    """grad_from_shadows (the one-rank form of train.Trainer): a shadowed parameter whose own .grad is None takes its shadow's
+    bfloat16 gradient where autograd left it; the update equals torch.optim.AdamW fed the same values as float32."""
+    from heltondetection_amd.optim import HdAdamW
+    dev = torch.device("cuda:0")
+    a, b = _params(dev, 3), [p.detach().clone().requires_grad_(True) for p in _params(dev, 3)]
+    shadows = {a[0]: torch.empty_like(a[0], dtype=torch.bfloat16).requires_grad_(True),
+               a[4]: torch.empty_like(a[4], dtype=torch.bfloat16).requires_grad_(True),
+               a[5]: torch.empty_like(a[5], dtype=torch.bfloat16).requires_grad_(True)}
+    groups = lambda ps: [{"params": [p for p in ps if p.ndim > 1], "weight_decay": 0.05},
+                         {"params": [p for p in ps if p.ndim <= 1], "weight_decay": 0.0}]
+    oa = HdAdamW(groups(a), lr=3e-3, betas=(0.937, 0.999), shadows=shadows)
+    oa.grad_from_shadows = True
+    ob = torch.optim.AdamW(groups(b), lr=3e-3, betas=(0.937, 0.999), foreach=False, fused=False)
+    g = torch.Generator().manual_seed(5)
+    for step in range(5):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).to(dev)
+            if pa in shadows:
+                pa.grad = None
+                shadows[pa].grad = torch.empty_like(shadows[pa]).copy_(gr)        # bf16, the parameter's memory order
+                pb.grad = torch.empty_like(pb).copy_(shadows[pa].grad.float())    # the same values, float32
+            else:
+                pa.grad = torch.empty_like(pa).copy_(gr)
+                pb.grad = torch.empty_like(pb).copy_(gr)
+        oa.step(); ob.step()
+        for pa, pb in zip(a, b):
+            assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7), (step, pa.shape, float((pa - pb).abs().max()))
+    for p, sh in shadows.items():
+        assert torch.equal(sh.detach(), p.detach().to(torch.bfloat16))
+    # without the switch a parameter without its own gradient is skipped, as in torch.optim
+    oa.grad_from_shadows = False
+    before = a[0].detach().clone()
+    a[0].grad = None
+    oa.step()
+    assert torch.equal(a[0].detach(), before)
