@@ -79,15 +79,22 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__
     for (int ty = 0; ty < 5; ++ty) {
       const int yy = y + ty - 2;
       if (yy < 0 || yy >= H) continue;
+      // the five taps of a row are requested together (clamped columns; out-of-range ones are skipped below): a
+      // load -> compare chain per tap made the kernel 25 dependent L2 round trips long
+      float v[5][V];
+#pragma unroll
+      for (int tx = 0; tx < 5; ++tx) {
+        const int xx = min(max(x + tx - 2, 0), W - 1);
+        Vec<T>::load(in + (((size_t)b * H + yy) * W + xx) * ld_in + c0, v[tx]);
+      }
+#pragma unroll
       for (int tx = 0; tx < 5; ++tx) {
         const int xx = x + tx - 2;
         if (xx < 0 || xx >= W) continue;
-        float v[V];
-        Vec<T>::load(in + (((size_t)b * H + yy) * W + xx) * ld_in + c0, v);
 #pragma unroll
         for (int k = 0; k < V; ++k)
-          if (v[k] > best[k] || v[k] != v[k]) {
-            best[k] = v[k];
+          if (v[tx][k] > best[k] || v[tx][k] != v[tx][k]) {
+            best[k] = v[tx][k];
             bi[k] = ty * 5 + tx;
           }
       }
@@ -124,23 +131,23 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__
     for (int ty = 0; ty < 5; ++ty) {
       const int qy = y - ty + 2;
       if (qy < 0 || qy >= H) continue;
+      // the tap bytes of the five windows of this row are requested together (clamped columns); the gradient of a window is
+      // loaded only when one of its taps points here
+      uint2 tb[5];
+#pragma unroll
+      for (int tx = 0; tx < 5; ++tx) {
+        const int qx = min(max(x - tx + 2, 0), W - 1);
+        const size_t q = (((size_t)b * H + qy) * W + qx) * C + c0;
+        if (V == 8) tb[tx] = *reinterpret_cast<const uint2*>(idx + q);
+        else tb[tx] = make_uint2(*reinterpret_cast<const uint32_t*>(idx + q), 0u);
+      }
+#pragma unroll
       for (int tx = 0; tx < 5; ++tx) {
         const int qx = x - tx + 2;
         if (qx < 0 || qx >= W) continue;
-        const size_t q = (((size_t)b * H + qy) * W + qx) * C + c0;
         uint32_t taps[V];
-        if (V == 8) {
-          const uint2 t = *reinterpret_cast<const uint2*>(idx + q);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            taps[k] = (t.x >> (8 * k)) & 255u;
-            taps[(4 + k) % V] = (t.y >> (8 * k)) & 255u;
-          }
-        } else {
-          const uint32_t t = *reinterpret_cast<const uint32_t*>(idx + q);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) taps[k] = (t >> (8 * k)) & 255u;
-        }
+        for (int k = 0; k < V; ++k) taps[k] = ((k < 4 ? tb[tx].x : tb[tx].y) >> (8 * (k & 3))) & 255u;
         const uint32_t want = ty * 5 + tx;
         bool any = false;
 #pragma unroll
