@@ -25,7 +25,6 @@
 #include <hip/hip_bf16.h>
 
 #include "hd_bn_fuse.h"
-#include <cstdlib>
 #include <type_traits>
 
 #include "hd_common.h"
@@ -574,12 +573,10 @@ bool try_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, int64_t 
   // K = 256: a 128-wide column tile needs a 64 KB slab (one workgroup per CU either way): its load is the start-up cost of the
   // launch, which loses on the 40 x 40 / 20 x 20 levels (+3-5 us) and wins once there are enough row blocks per workgroup to
   // amortise it — every row block is then pulled through L2 by N / 128 instead of N / 64 workgroups
-  static const char* wide_env = getenv("HD_STREAM_WIDE_ROWS");
-  const long long wide_rows = wide_env ? atoll(wide_env) : kWideRows;
   // ... and only for launches that take the deep form: a 128-wide tile in the short form was measured slower wherever it ran
   // (the 80 x 80 level of YOLOv5l: +0.4 ms per step): the wide launch has N / 128 column tiles on <= 256 workgroups
   const long long wide_blocks = ((long long)M + 31) / 32 * (N / 128);
-  const bool wide = K > 128 && !bnb && M >= wide_rows && N % 128 == 0 && wide_blocks >= kDeepBlocks * 256 * 4;
+  const bool wide = K > 128 && !bnb && M >= kWideRows && N % 128 == 0 && wide_blocks >= kDeepBlocks * 256 * 4;
   const int max_bn = (K <= 128 || wide) ? 128 : 64;
   const int bn = N % 128 == 0 && max_bn >= 128 ? 128 : (N % 64 == 0 ? 64 : 32);
   if (N / bn > kMaxColumnTiles) return false;
@@ -1363,12 +1360,6 @@ inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
   const bool big = (int64_t)Cin * Cout > 128 * 128;
   p.tm = Cout % 128 == 0 && big ? 2 : 1;
   p.tn = Cin % 128 == 0 && big ? 2 : 1;
-  static const char* force = getenv("HD_WGRAD_TILE");  // experiments only: "tm,tn"
-  if (force && force[0] && force[1] == ',' && force[2]) {
-    const int ftm = force[0] - '0', ftn = force[2] - '0';
-    if ((ftm == 1 || ftm == 2) && Cout % (64 * ftm) == 0) p.tm = ftm;
-    if ((ftn == 1 || ftn == 2) && Cin % (64 * ftn) == 0) p.tn = ftn;
-  }
   p.tiles = (Cout / (64 * p.tm)) * (Cin / (64 * p.tn));
   int s = 512 / p.tiles;  // ~2 workgroups per CU (256 measured equal within noise)
   const int64_t max_s = (R + 127) / 128;  // at least two 64-row steps per slice
