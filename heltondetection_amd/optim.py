@@ -89,9 +89,38 @@ class HdAdamW(torch.optim.AdamW):
             for start in range(0, p.numel(), _CHUNK):
                 ct.append(i)
                 cs.append(start)
-        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
-        return (raw, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev), len(ct),
-                self._key(group), ps)
+        # the descriptors live in a PINNED host buffer owned by this table and travel with a non-blocking copy: when gradient
+        # addresses change (one-rank direct mode: autograd allocates the gradients anew, and inside a hipGraph capture they
+        # come from the graph's pool) only the pointers are patched and re-sent (`_repoint`) — cheap in eager mode, and legal
+        # inside a capture, where the copy becomes a graph node whose source stays alive as long as the optimizer
+        host = torch.empty(C.sizeof(descs), dtype=torch.uint8).pin_memory() if dev.type == "cuda" else \
+            torch.empty(C.sizeof(descs), dtype=torch.uint8)
+        C.memmove(host.data_ptr(), C.addressof(descs), C.sizeof(descs))
+        raw = torch.empty(C.sizeof(descs), dtype=torch.uint8, device=dev)
+        raw.copy_(host, non_blocking=True)
+        return [raw, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev), len(ct),
+                self._key(group), ps, host]
+
+    def _repoint(self, group, tabs) -> bool:
+        """Same parameters, new gradient tensors: patch the descriptors' gradient pointers in place.  -> False when the set of
+        parameters with a gradient (or a gradient's dtype / layout) changed and the tables have to be rebuilt."""
+        have = [p for p in group["params"] if self._grad(p) is not None]
+        if sum(len(t[5]) for t in tabs) != len(have) or {id(p) for t in tabs for p in t[5]} != {id(p) for p in have}:
+            return False
+        key = self._key(group)
+        for t in tabs:
+            raw, ps, host = t[0], t[5], t[6]
+            descs = (_Desc * len(ps)).from_address(host.data_ptr())
+            for i, p in enumerate(ps):
+                g = self._grad(p)
+                # dtype and element count are re-checked; the memory order of a gradient is a property of the op that
+                # produced it and was validated when the table was built
+                if (1 if g.dtype == torch.bfloat16 else 0) != descs[i].g_dtype or g.numel() != descs[i].n:
+                    return False
+                descs[i].g = g.data_ptr()
+            raw.copy_(host, non_blocking=True)
+            t[4] = key
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -103,12 +132,14 @@ class HdAdamW(torch.optim.AdamW):
             if group.get("amsgrad") or group.get("maximize"):
                 raise _lib.HdError("HdAdamW: amsgrad / maximize are not implemented")
             tabs = self._tables[gi]
-            if tabs is None or tabs[0][4] != self._key(group):   # first step, re-pointed gradients, loaded state
+            if tabs is None:                                     # first step, loaded state
+                tabs = self._tables[gi] = self._build(group)
+            elif tabs[0][4] != self._key(group) and not self._repoint(group, tabs):   # new gradient tensors / a new set
                 tabs = self._tables[gi] = self._build(group)
             if tabs is None:
                 continue
             b1, b2 = group["betas"]
-            for raw, ct, cs, n_chunks, _, ps in tabs:   # one launch per distinct step count (normally one)
+            for raw, ct, cs, n_chunks, _, ps, _host in tabs:   # one launch per distinct step count (normally one)
                 t = float(self.state[ps[0]]["step"]) + 1.0
                 for p in ps:
                     self.state[p]["step"] += 1

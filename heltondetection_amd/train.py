@@ -92,7 +92,9 @@ class Trainer:
             graph_split = False
         self.graph_split = bool(graph_split) and self.use_graph and (world > 1 or graph_split == "force")
         # one rank + the HIP optimizer: no packing at all, HdAdamW reads the gradients where autograd left them
-        direct = (world == 1 and self.device.type == "cuda" and hd_optimizer and not self.graph_split
+        # (hipGraph mode only: an eager step is launch-bound on the host, where re-pointing the optimizer's descriptor
+        # table at each step's fresh gradient tensors costs more than the two packing launches it saves)
+        direct = (world == 1 and self.device.type == "cuda" and hd_optimizer and self.use_graph and not self.graph_split
                   and os.environ.get("HD_DIRECT_GRADS", "1") != "0")
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes,
                                    defer_collectives=self.use_graph and not self.graph_split,
