@@ -779,6 +779,14 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
+    shipped_find_db = False
+    if not args.no_miopen_find:
+        # the library convolutions' solver search of one MI355X run is shipped (heltondetection_amd/miopen_db, tuning.py): the
+        # same library kernels every time instead of whatever a fresh search's first-call timings favour, and no search
+        from heltondetection_amd import tuning
+        shipped_find_db = tuning.use_shipped_find_db()
+        log(f"MIOpen user find-db: {'shipped (heltondetection_amd/miopen_db)' if shipped_find_db else os.environ.get('MIOPEN_USER_DB_PATH', 'default')}")
+
     if args.model == "frcnn" and not args.no_miopen_find and rank == 0:
         # MIOpen's solver search for ResNet50 at 832^2 is one long call inside the first step (minutes on a fresh
         # box): a heartbeat keeps the run visibly alive
@@ -813,7 +821,9 @@ def main():
             "config": {"workload": f"{model_name(args)} {args.size}x{args.size} bs={args.batch}/GPU train step "
                                    f"(fwd + HIP assign/loss/RoI ops + bwd + {exchange} + AdamW), random-init weights",
                        "global_batch": world * args.batch, "img_size": args.size, "num_classes": args.classes,
-                       "parallelism": f"dp{world}", "ranks": world, "backend": backend},
+                       "parallelism": f"dp{world}", "ranks": world, "backend": backend,
+                       "miopen_find_db": ("off" if args.no_miopen_find else
+                                          ("shipped" if shipped_find_db else os.environ.get("MIOPEN_USER_DB_PATH", "default")))},
             "final_loss": round(leg["loss"], 4),
         }
         if rehearsal and world > 1:

@@ -123,6 +123,9 @@ def train(cfg: Dict[str, Any], work_dir: str, device: Optional[str] = None, resu
     t = cfg["train"]
     torch.manual_seed(int(t["seed"]))  # identical init on every rank (GradReducer also broadcasts rank 0's parameters)
     torch.backends.cudnn.benchmark = bool(t["miopen_find"])
+    if t["miopen_find"]:
+        from . import tuning
+        tuning.use_shipped_find_db()  # the library convolutions' solver search of one MI355X run (tuning.py)
     log = RunLogger(work_dir, rank, **cfg["log"])
     if rank == 0:
         os.makedirs(work_dir, exist_ok=True)

@@ -136,3 +136,19 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 8" in r.stderr
+
+
+def test_shipped_find_db_is_selected_only_when_the_caller_chose_nothing(monkeypatch):
+    """tuning.use_shipped_find_db points MIOpen at heltondetection_amd/miopen_db unless MIOPEN_USER_DB_PATH is already set or
+    the switch HD_NO_SHIPPED_FIND_DB=1 is; the shipped directory holds text find-db / perf-db files for gfx950."""
+    import os
+    from heltondetection_amd import tuning
+    assert os.path.isdir(tuning._DB) and any(f.endswith(".ufdb.txt") and f.startswith("gfx950") for f in os.listdir(tuning._DB))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("HD_NO_SHIPPED_FIND_DB", raising=False)
+    assert tuning.use_shipped_find_db() is True and os.environ["MIOPEN_USER_DB_PATH"] == tuning._DB
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert tuning.use_shipped_find_db() is False and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setenv("HD_NO_SHIPPED_FIND_DB", "1")
+    assert tuning.use_shipped_find_db() is False and "MIOPEN_USER_DB_PATH" not in os.environ
