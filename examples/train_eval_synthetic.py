@@ -34,8 +34,16 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=30)
     ap.add_argument("--mosaic", type=float, default=0.5)
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--amp", choices=("bf16", "fp32", "torch_amp"), default="bf16",
+                    help="bf16: the product step (bf16 autocast, weight shadows, hand-written kernels); fp32: the same step without "
+                         "autocast; torch_amp: plain torch modules under bf16 autocast (tools/convergence_ab.py compares them)")
+    ap.add_argument("--seed", type=int, default=0, help="weight initialisation + the step's random draws (Mosaic)")
     args = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)
+    if args.amp == "torch_amp":
+        from heltondetection_amd.layers import ConvBNAct
+        ConvBNAct.fused = False
 
     # paint=True: boxes are drawn as class-coloured rectangles, so there is something to learn
     ann = coco_io.write_synthetic_coco(args.workdir, args.images, args.size, args.classes, seed=0, max_boxes=6, paint=True)
@@ -46,6 +54,7 @@ def main(argv=None):
     batches = [(b[0].contiguous(memory_format=torch.channels_last),) + b[1:] for b in batches]
     steps = args.epochs * len(batches)
     trainer = Trainer(model, lr=args.lr, total_steps=steps, warmup_steps=max(steps // 20, 1), device=dev, use_graph=True,
+                      amp_dtype=None if args.amp == "fp32" else torch.bfloat16, seed=args.seed,
                       augment=Mosaic(p=args.mosaic, max_boxes=2 * ds.max_boxes) if args.mosaic > 0 else None)
     first = last = None
     for ep in range(args.epochs):
@@ -63,7 +72,7 @@ def main(argv=None):
     with open(res_path, "w") as f:
         json.dump(results, f)
     metrics = coco_io.evaluate_coco_json(ann, res_path)
-    out = {"first_loss": first, "last_loss": last, "steps": steps, "hip_graph": trainer._graph is not None,
+    out = {"amp": args.amp, "seed": args.seed, "first_loss": first, "last_loss": last, "steps": steps, "hip_graph": trainer._graph is not None,
            "mAP50": metrics["mAP50"], "mAP50_95": metrics["mAP50_95"], "detections": len(results), **summary}
     print(json.dumps(out))
     return out

@@ -25,7 +25,7 @@ DEFAULTS: Dict[str, Dict[str, Any]] = {
     "data": {"type": "synthetic_coco", "root": None, "n_images": 64, "val_images": 16, "size": 640, "num_classes": 80,
              "style": "coco", "max_boxes": 40, "paint": False, "seed": 0, "batch": 16},
     "train": {"epochs": 1, "max_steps": None, "lr": 1e-3, "weight_decay": 5e-4, "warmup_steps": 10, "amp": "bf16",
-              "hip_graph": True, "mosaic": 0.0, "bucket_mb": 32, "log_every": 10, "eval_every": 0, "save_every": 1,
+              "hip_graph": True, "mosaic": 0.0, "bucket_mb": 0, "log_every": 10, "eval_every": 0, "save_every": 1,
               "seed": 0, "miopen_find": False},
     "eval": {"conf_thr": 0.001, "iou_thr": 0.6, "max_det": 300, "max_nms": 30000, "batch": None, "amp": "bf16"},
     "test": {"conf_thr": 0.25, "iou_thr": 0.45, "max_det": 300, "max_nms": 30000, "batch": None, "amp": "bf16"},

@@ -3,9 +3,10 @@
 The hot path shards by image: every detection op is per-image, so the only
 exchange is the gradient all-reduce.  GradReducer does that exchange MI355X-first rather than
 by wrapping torch's DDP:
-  * gradients are packed into a few large flat fp32 buckets (xGMI is 7 point-to-point links per
-    GPU and a ring all-reduce is bound by one link, so few large collectives beat many small
-    ones; the first bucket is smaller so communication starts early in backward);
+  * gradients are packed into flat fp32 buckets sized from the model (plan_buckets: ~8-20 per step — xGMI is 7
+    point-to-point links per GPU and a ring all-reduce is bound by one link, so a handful of large collectives beat
+    many small ones; the first bucket is smaller so communication starts early in backward, and the LAST one, whose
+    all-reduce nothing can hide, is at most 2 MB);
   * a bucket's all-reduce is launched (async, RCCL's own stream) the moment its last gradient
     has been produced by autograd, so it overlaps the rest of backward;
   * one multi-tensor copy per bucket packs the gradients, and parameters' .grad are re-pointed
@@ -59,10 +60,55 @@ class _Bucket:
         self.packed = False
 
 
+def plan_buckets(sizes: List[int], bucket_bytes: Optional[int] = None, first_bucket_bytes: Optional[int] = None,
+                 tail_bytes: Optional[int] = None) -> List[List[int]]:
+    """Partition of the gradients, given as byte sizes IN ARRIVAL ORDER (reverse registration order: the head's gradients
+    first, the stem's last), into consecutive buckets.  -> list of index lists.
+
+    Sized by time to completion, not by a byte constant (32 MB buckets put 84 % of YOLOv5s's 29 MB into one
+    bucket that is complete only when backward ends — nothing left to overlap it with):
+      * `bucket_bytes` (default: total / 16, at least 4 MB): YOLOv5s 29 MB -> 8 buckets, YOLOv5l 186 MB -> 12 MB buckets,
+        ResNet50-PAFPN 164 MB -> 10 MB.  A bucket's all-reduce overlaps the backward segments behind it; 8-20 collectives
+        per step keep the per-collective latency (tens of microseconds on 8 ranks) small against the step.
+      * `first_bucket_bytes` (default: a quarter of that): communication starts early.
+      * `tail_bytes` (default 2 MB, at most half a bucket): the LAST bucket — the gradients that arrive last (stem, first
+        stage) and whose all-reduce nothing can hide — is kept this small by closing the previous bucket early."""
+    total = sum(sizes)
+    if bucket_bytes is None:
+        bucket_bytes = max(4 << 20, total // 16)
+    bucket_bytes = max(int(bucket_bytes), 1)
+    first = int(first_bucket_bytes) if first_bucket_bytes is not None else max(bucket_bytes // 4, 1)
+    first = min(first, bucket_bytes)
+    tail = int(tail_bytes) if tail_bytes is not None else min(2 << 20, max(bucket_bytes // 2, 1))
+    # the tail: the longest suffix of at most `tail` bytes (at least the last gradient, at most all but one)
+    n = len(sizes)
+    cut, acc = n, 0
+    while cut > 1 and acc + sizes[cut - 1] <= tail:
+        cut -= 1
+        acc += sizes[cut]
+    if cut == n and n > 1:
+        cut = n - 1          # the last gradient alone exceeds the tail budget: it is the tail
+    if n <= 1 or total <= tail:
+        cut = 0 if total <= tail else cut
+    out, cur, cur_bytes, cap = [], [], 0, first
+    for i in range(cut):
+        cur.append(i)
+        cur_bytes += sizes[i]
+        if cur_bytes >= cap:
+            out.append(cur)
+            cur, cur_bytes, cap = [], 0, bucket_bytes
+    if cur:
+        out.append(cur)
+    if cut < n:
+        out.append(list(range(cut, n)))
+    return out
+
+
 class GradReducer:
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, first_bucket_bytes: int = 4 << 20,
+    def __init__(self, module: torch.nn.Module, bucket_bytes: Optional[int] = None, first_bucket_bytes: Optional[int] = None,
                  process_group=None, broadcast_params: bool = True, defer_collectives: bool = False,
-                 grad_sources: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None, direct: bool = False):
+                 grad_sources: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None, direct: bool = False,
+                 tail_bytes: Optional[int] = None):
         self.module = module
         # grad_sources: parameter -> the leaf tensor that receives its gradient instead of the parameter
         # (a bf16 weight shadow, train.LowpShadows); the bucket copy converts to fp32 while packing
@@ -82,16 +128,9 @@ class GradReducer:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=process_group)
         # gradients become ready roughly in reverse registration order
-        self.buckets: List[_Bucket] = []
-        cur, cur_bytes, cap = [], 0, first_bucket_bytes
-        for p in reversed(params):
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-            if cur_bytes >= cap:
-                self.buckets.append(_Bucket(cur))
-                cur, cur_bytes, cap = [], 0, bucket_bytes
-        if cur:
-            self.buckets.append(_Bucket(cur))
+        order = list(reversed(params))
+        plan = plan_buckets([p.numel() * 4 for p in order], bucket_bytes, first_bucket_bytes, tail_bytes)
+        self.buckets: List[_Bucket] = [_Bucket([order[i] for i in idx]) for idx in plan]
         self._bucket_of = {}
         for b in self.buckets:
             for p in b.params:

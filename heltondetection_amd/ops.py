@@ -1068,6 +1068,15 @@ class _WgradChain:
             cls._reduce_now(pend[0], device)
 
     @classmethod
+    def reset(cls) -> None:
+        """Forget the pending slice sum and the hand-over records WITHOUT launching anything: for a step that ended in an
+        exception (a failed hipGraph capture above all — the pending job's gradient pointer then lies in the destroyed capture's
+        private pool, and a later launch that carried it would write through freed memory).  The gradients of the
+        aborted step are lost, which is what an aborted step means."""
+        cls._pending.clear()
+        cls._handed.clear()
+
+    @classmethod
     def flush(cls) -> None:
         for key, (job, keep) in list(cls._pending.items()):
             cls._reduce_now(job, torch.device(key[0], key[1]))

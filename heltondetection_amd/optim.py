@@ -93,11 +93,16 @@ class HdAdamW(torch.optim.AdamW):
         # addresses change (one-rank direct mode: autograd allocates the gradients anew, and inside a hipGraph capture they
         # come from the graph's pool) only the pointers are patched and re-sent (`_repoint`) — cheap in eager mode, and legal
         # inside a capture, where the copy becomes a graph node whose source stays alive as long as the optimizer
-        host = torch.empty(C.sizeof(descs), dtype=torch.uint8).pin_memory() if dev.type == "cuda" else \
-            torch.empty(C.sizeof(descs), dtype=torch.uint8)
-        C.memmove(host.data_ptr(), C.addressof(descs), C.sizeof(descs))
+        # TWO host buffers, used alternately, each with the event of its last copy: a non-blocking copy reads its pinned source
+        # when the stream gets there, so a buffer may be patched again only after that event (the host can run
+        # more than a step ahead of the device in eager steps, and step N's kernel would read step N + 1's gradient addresses)
+        hosts = [torch.empty(C.sizeof(descs), dtype=torch.uint8).pin_memory() if dev.type == "cuda" else
+                 torch.empty(C.sizeof(descs), dtype=torch.uint8) for _ in range(2)]
+        for h in hosts:
+            C.memmove(h.data_ptr(), C.addressof(descs), C.sizeof(descs))
         raw = torch.empty(C.sizeof(descs), dtype=torch.uint8, device=dev)
-        raw.copy_(host, non_blocking=True)
+        host = _HostPair(hosts)
+        host.send(raw)
         return [raw, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev), len(ct),
                 self._key(group), ps, host]
 
@@ -110,7 +115,7 @@ class HdAdamW(torch.optim.AdamW):
         key = self._key(group)
         for t in tabs:
             raw, ps, host = t[0], t[5], t[6]
-            descs = (_Desc * len(ps)).from_address(host.data_ptr())
+            descs = (_Desc * len(ps)).from_address(host.next_buffer().data_ptr())
             for i, p in enumerate(ps):
                 g = self._grad(p)
                 # dtype and element count are re-checked; the memory order of a gradient is a property of the op that
@@ -118,7 +123,7 @@ class HdAdamW(torch.optim.AdamW):
                 if (1 if g.dtype == torch.bfloat16 else 0) != descs[i].g_dtype or g.numel() != descs[i].n:
                     return False
                 descs[i].g = g.data_ptr()
-            raw.copy_(host, non_blocking=True)
+            host.send(raw)
             t[4] = key
         return True
 
@@ -150,6 +155,36 @@ class HdAdamW(torch.optim.AdamW):
                 if rc != 0:
                     raise _lib.HdError(f"hd_adamw_multi failed ({rc})")
         return loss
+
+
+class _HostPair:
+    """The descriptor table's two pinned host copies.  `next_buffer()` returns the one that is NOT the source of the latest
+    copy, after waiting for its own last copy to have executed; `send()` copies it to the device table and records the event.
+    Inside a hipGraph capture nothing is waited for or recorded (an event recorded there belongs to the graph; the copy node
+    reads its source at replay time, and that source is left alone from then on because the capture's gradient addresses
+    never change again)."""
+
+    def __init__(self, hosts):
+        self.hosts, self.events, self.cur = hosts, [None, None], 0
+
+    def next_buffer(self) -> torch.Tensor:
+        nxt = 1 - self.cur
+        ev = self.events[nxt]
+        if ev is not None:
+            ev.synchronize()
+            self.events[nxt] = None
+        src, dst = self.hosts[self.cur], self.hosts[nxt]
+        if src.data_ptr() != dst.data_ptr():
+            dst.copy_(src)      # start from the latest table: only the gradient pointers are patched
+        self.cur = nxt
+        return dst
+
+    def send(self, raw: torch.Tensor) -> None:
+        raw.copy_(self.hosts[self.cur], non_blocking=True)
+        if raw.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(raw.device))
+            self.events[self.cur] = ev
 
 
 def _same_order(t: torch.Tensor, p: torch.Tensor) -> bool:

@@ -146,8 +146,8 @@ def train(cfg: Dict[str, Any], work_dir: str, device: Optional[str] = None, resu
         from .augment import Mosaic
         augment = Mosaic(p=float(t["mosaic"]), max_boxes=2 * ds.max_boxes)
     trainer = Trainer(model, lr=float(t["lr"]), weight_decay=float(t["weight_decay"]), amp_dtype=_AMP[t["amp"]],
-                      total_steps=total, warmup_steps=int(t["warmup_steps"]), bucket_bytes=int(t["bucket_mb"]) << 20,
-                      device=dev, use_graph=bool(t["hip_graph"]), augment=augment)
+                      total_steps=total, warmup_steps=int(t["warmup_steps"]), bucket_bytes=(int(t["bucket_mb"]) << 20) if t["bucket_mb"] else None,
+                      device=dev, use_graph=bool(t["hip_graph"]), augment=augment, seed=int(t["seed"]))
     step0 = 0
     if resume:
         meta = load_checkpoint(resume, model, trainer)

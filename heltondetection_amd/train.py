@@ -55,9 +55,15 @@ class Trainer:
     graph, launched right after the replay, so 1-GPU and N-GPU runs execute the same structure."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, amp_dtype=torch.bfloat16,
-                 total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: int = 32 << 20, device=None,
+                 total_steps: int = 1000, warmup_steps: int = 10, bucket_bytes: Optional[int] = None, device=None,
                  use_graph: bool = False, graph_warmup: int = 3, graph_sync: Optional[bool] = None,
-                 lowp_weights: bool = True, augment=None, graph_split: bool = True, hd_optimizer: bool = True):
+                 lowp_weights: bool = True, augment=None, graph_split: bool = True, hd_optimizer: bool = True,
+                 seed: Optional[int] = None):
+        """bucket_bytes: None = dist.GradReducer's policy (buckets sized from the model's gradient bytes, small final bucket).
+        seed: the step's random draws (Mosaic, DropBlock: rng.py) come from a per-RANK device generator seeded with
+        `seed * 1000003 + rank`, so the ranks of a data-parallel run augment differently while each stays reproducible
+        (with the default generator seeded identically on every rank, all ranks drew the same mosaics).  None:
+        the default device generator, as before (one rank / tests that seed it themselves)."""
         self.model = model
         # augment: callable (images, gt_boxes, gt_cls, m_valid) -> same 4-tuple, run on the device at the head of every step
         # (e.g. augment.Mosaic).  A TWO-PHASE augment (has `draw(B, S, device) -> tensors` and `apply(images, gt_boxes,
@@ -69,8 +75,15 @@ class Trainer:
         self._aug_two_phase = augment is not None and hasattr(augment, "draw") and hasattr(augment, "apply")
         self._aug_params = None
         from .rng import StepRandom
-        self.rand = StepRandom(device or next(model.parameters()).device)
-        self.device = device or next(model.parameters()).device
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        self.generator = None
+        if seed is not None and self.device.type == "cuda":
+            import torch.distributed as _td
+            rank = _td.get_rank() if _td.is_initialized() else 0
+            self.generator = torch.Generator(device=self.device).manual_seed(int(seed) * 1000003 + rank)
+            if self._aug_two_phase and getattr(augment, "generator", None) is None:
+                augment.generator = self.generator
+        self.rand = StepRandom(self.device, self.generator)
         self.amp_dtype = amp_dtype
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         from .layers import FusedBNAct
@@ -198,6 +211,10 @@ class Trainer:
             # buckets autograd left incomplete (parameters without a gradient this step) are packed here, inside
             # the captured region in hipGraph mode, so their packing copies replay with the graph
             self.reducer.pack_incomplete()
+        except BaseException:
+            if chain is not None:
+                chain.reset()   # nothing of an aborted step may ride in a later launch (see ops._WgradChain.reset)
+            raise
         finally:
             LowpWeights.on = False
             if chain is not None:
@@ -344,6 +361,14 @@ class Trainer:
                 self.use_graph = False
                 self.reducer.defer = False
                 self._graph = self._static = self._static_out = self._segments = None
+                from . import ops
+                ops._WgradChain.reset()   # a capture that failed on ANOTHER rank leaves this rank's chain state too
+                # eager steps allocate fresh gradient tensors every step: back to the packed buckets, whose addresses never
+                # change (the optimizer's descriptor table is then built once; see optim.HdAdamW._repoint)
+                if self.reducer.direct:
+                    self.reducer.direct = False
+                    if hasattr(self.opt, "grad_from_shadows"):
+                        self.opt.grad_from_shadows = False
                 torch.cuda.synchronize(self.device)
             elif self._segments is not None and self.reducer.world > 1 and not self.graph_sync and self.verify_overlap:
                 self._verify_overlap()

@@ -134,10 +134,12 @@ def _worker_overlap(rank, world, port, tmp, use_graph):
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = False
     model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=128)).to(dev)
+    model.load_state_dict(torch.load(os.path.join(tmp, "pretrained.pt")))   # off the chaotic random-init point (see the test)
     model = model.to(memory_format=torch.channels_last).train()
-    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=40, warmup_steps=0, bucket_bytes=2 << 20, device=dev,
+    # the SHIPPED bucket policy (dist.plan_buckets: VERDICT r03 #7 — the tests used to run with their own small buckets)
+    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=40, warmup_steps=0, device=dev,
                  use_graph=use_graph, graph_warmup=2, graph_sync=False)
-    assert isinstance(tr.opt, HdAdamW) and tr.shadows is not None and len(tr.reducer.buckets) >= 3
+    assert isinstance(tr.opt, HdAdamW) and tr.shadows is not None and len(tr.reducer.buckets) >= 6
 
     class _NoSched:   # the learning rate is set by hand below
         def step(self):
@@ -163,10 +165,38 @@ def _worker_overlap(rank, world, port, tmp, use_graph):
             "overlap_error": tr.graph_overlap_error, "loss": float(loss), "times": times, "before": before,
             "params": [p.detach().float().cpu() for p in model.parameters()],
             "shadows": [s_.detach().float().cpu() for s_ in tr.shadows.shadows],
-            "grads": [p.grad.detach().float().cpu().clone() for p in model.parameters()]}
+            "grads": [p.grad.detach().float().cpu().clone() for p in model.parameters()],
+            "buckets": [b.flat.detach().float().cpu().clone() for b in tr.reducer.buckets]}
     torch.save(info, os.path.join(tmp, f"o{'g' if use_graph else 'e'}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _pretrain(tmp_path, steps: int = 300):
+    """One rank, eager: YOLOv5s 128^2 trained for a few hundred product steps on four fixed batches; the state dict is what
+    both 2-rank runs below start from."""
+    from heltondetection_amd import synthetic as syn
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = False
+    model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=128)).to(dev)
+    model = model.to(memory_format=torch.channels_last).train()
+    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=steps + 10, warmup_steps=10, device=dev, use_graph=False)
+    g = syn.make_generator(77)
+    pool = []
+    for _ in range(4):
+        img = syn.make_images(4, 128, g).to(dev).contiguous(memory_format=torch.channels_last)
+        gtb, gtc, mv = syn.make_targets(4, 128, g, "coco", 8, 8)
+        pool.append((img, gtb.to(dev), gtc.to(dev), mv.to(dev)))
+    for i in range(steps):
+        loss, _ = tr.step(*pool[i % 4])
+    assert bool(torch.isfinite(loss))
+    torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(str(tmp_path), "pretrained.pt"))
+    del tr, model
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.timeout(900)
@@ -174,6 +204,7 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     """VERDICT r02 #2a: the overlapped (graph_sync = False) multi-rank branch executes with a collective, under bf16
     autocast + bf16 weight shadows + HdAdamW, with lr > 0 for exactly one graph-replayed optimizer step."""
     world = 2
+    _pretrain(tmp_path)
     for use_graph in (True, False):
         mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
     g0, g1 = torch.load(tmp_path / "og0.pt"), torch.load(tmp_path / "og1.pt")
@@ -197,13 +228,20 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     assert all(bool(torch.isfinite(a).all()) for a in g0["params"])
     moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["params"], g0["before"]))
     assert moved > 0                                                         # lr > 0: the replayed step moved the weights
-    # Against the eager 2-rank step only the forward is comparable sharply: at FIXED weights and data the bf16 step's
-    # gradients differ by 0.15-0.5 (relative L2) between two runs of the same program, eager or replayed, hand-written
-    # kernels on or off (tools/determinism_probe.py, profiles/r03_determinism.log, DESIGN.md section 9: bf16 storage of
-    # gradients with a large common-mode part that BatchNorm's backward cancels).  So: same loss to bf16 accuracy, and the
-    # averaged gradients no further from the eager run than two eager runs are from each other (a missing bucket is >= 1).
+    assert g0["segments"] >= 6                                               # the shipped bucket plan, not a test-sized one
+    # Against the eager 2-rank step, PER BUCKET.  Both runs start from the same pre-trained weights: at random init this
+    # network amplifies rounding differences so strongly that two FLOAT32 runs of one step differ by 0.27 in their gradients
+    # (profiles/r04_grad_fidelity.md: chaos of a random-init BatchNorm network, not bf16 storage of a common-mode part — that
+    # round-3 hypothesis is refuted there); after a few hundred steps two bf16 runs agree to ~0.14.  Bound stated before the
+    # first run of this form: every bucket's averaged gradient within 0.33 relative L2 (cosine >= 0.9) of the eager run's.  A
+    # bucket that missed its all-reduce, was reduced before its segment finished, or lost a tensor is off by >= 1.0: it
+    # cannot pass by a factor of three.
     assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"]), (g0["loss"], e0["loss"])
-    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["grads"], e0["grads"]))
-    den = sum(float((b ** 2).sum()) for b in e0["grads"])
-    assert den > 0 and (num / den) ** 0.5 < 0.75, (num / den) ** 0.5
+    assert len(g0["buckets"]) == len(e0["buckets"]) >= 6
+    worst = []
+    for k, (a, b) in enumerate(zip(g0["buckets"], e0["buckets"])):
+        rel = float((a.double() - b.double()).norm() / b.double().norm())
+        cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
+        worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
+    assert all(rel < 0.33 and cos >= 0.9 for rel, cos, _, _ in worst), worst
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing

@@ -138,17 +138,68 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 8" in r.stderr
 
 
-def test_shipped_find_db_is_selected_only_when_the_caller_chose_nothing(monkeypatch):
-    """tuning.use_shipped_find_db points MIOpen at heltondetection_amd/miopen_db unless MIOPEN_USER_DB_PATH is already set or
-    the switch HD_NO_SHIPPED_FIND_DB=1 is; the shipped directory holds text find-db / perf-db files for gfx950."""
+def test_shipped_find_db_is_selected_only_when_the_caller_chose_nothing(monkeypatch, tmp_path):
+    """tuning.use_shipped_find_db hands MIOpen a PRIVATE COPY of heltondetection_amd/miopen_db (MIOpen appends to its user
+    db: the tracked directory itself is never written, and two processes never share one copy) unless MIOPEN_USER_DB_PATH is
+    already set or the switch HD_NO_SHIPPED_FIND_DB=1 is; the shipped directory holds text find-db / perf-db files for gfx950."""
     import os
     from heltondetection_amd import tuning
-    assert os.path.isdir(tuning._DB) and any(f.endswith(".ufdb.txt") and f.startswith("gfx950") for f in os.listdir(tuning._DB))
+    shipped = sorted(f for f in os.listdir(tuning._DB) if f.endswith(".txt"))
+    assert os.path.isdir(tuning._DB) and any(f.endswith(".ufdb.txt") and f.startswith("gfx950") for f in shipped)
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.delenv("HD_NO_SHIPPED_FIND_DB", raising=False)
-    assert tuning.use_shipped_find_db() is True and os.environ["MIOPEN_USER_DB_PATH"] == tuning._DB
+    monkeypatch.delenv("HD_FIND_DB_DIR", raising=False)
+    monkeypatch.setattr(tuning, "_private", None)
+    assert tuning.use_shipped_find_db() is True
+    first = os.environ["MIOPEN_USER_DB_PATH"]
+    assert first != tuning._DB and first == tuning.find_db_dir() and sorted(os.listdir(first)) == shipped
+    assert tuning.use_shipped_find_db() is True and os.environ["MIOPEN_USER_DB_PATH"] == first   # idempotent in one process
+    # another process (simulated): its own directory
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setattr(tuning, "_private", None)
+    assert tuning.use_shipped_find_db() is True and os.environ["MIOPEN_USER_DB_PATH"] != first
+    # a persistent private directory, one per rank under a launcher
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setattr(tuning, "_private", None)
+    monkeypatch.setenv("HD_FIND_DB_DIR", str(tmp_path / "db"))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert tuning.use_shipped_find_db() is True and os.environ["MIOPEN_USER_DB_PATH"] == str(tmp_path / "db" / "rank1")
+    assert sorted(os.listdir(tmp_path / "db" / "rank1")) == shipped
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    monkeypatch.setattr(tuning, "_private", None)
     assert tuning.use_shipped_find_db() is False and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.setenv("HD_NO_SHIPPED_FIND_DB", "1")
     assert tuning.use_shipped_find_db() is False and "MIOPEN_USER_DB_PATH" not in os.environ
+
+
+def test_bucket_plan_overlaps_most_of_the_gradient_bytes_and_keeps_the_exposed_tail_small():
+    """with 32 MB buckets YOLOv5s (27.6 MB of float32 gradients) had two buckets, 4.4 and 23.2 MB, and the big
+    one held the stem, i.e. 84 % of the bytes were reduced with nothing left to overlap.  dist.plan_buckets sizes buckets from
+    the model: a partition in arrival order, >= 6 buckets for YOLOv5s, the LAST bucket (complete only when backward ends)
+    <= 2 MB, and no bucket but an oversized single parameter above twice the target."""
+    import torch
+    from heltondetection_amd.detectors import build_detector
+    from heltondetection_amd.dist import GradReducer, plan_buckets
+    for variant, min_buckets in (("s", 6), ("l", 8)):
+        model = build_detector(dict(type="YOLOv5", variant=variant, num_classes=80, img_size=640))
+        params = [p for p in model.parameters() if p.requires_grad]
+        sizes = [p.numel() * 4 for p in reversed(params)]
+        plan = plan_buckets(sizes)
+        assert [i for b in plan for i in b] == list(range(len(sizes)))           # a partition, in arrival order
+        nbytes = [sum(sizes[i] for i in b) for b in plan]
+        total, target = sum(sizes), max(4 << 20, sum(sizes) // 16)
+        assert len(plan) >= min_buckets, nbytes
+        assert nbytes[-1] <= 2 << 20 and nbytes[-1] <= 0.05 * total, nbytes       # the exposed tail
+        assert max(nbytes) < 2 * target + max(sizes), nbytes
+        red = GradReducer(model)                                                  # the shipped default takes this plan
+        assert [len(b.params) for b in red.buckets] == [len(b) for b in plan]
+        assert red.buckets[-1].params[-1] is params[0]                            # the stem's weight is in the last bucket
+    # degenerate inputs
+    assert plan_buckets([]) == [] and plan_buckets([10]) == [[0]]
+    assert plan_buckets([4 << 20, 4 << 20, 100]) == [[0], [1], [2]]
+    assert plan_buckets([1, 2, 3], 2, 2, 3) == [[0, 1], [2]]
+    # explicit sizes still work (tests, configs): 1 MB buckets over 10 x 0.5 MB
+    plan = plan_buckets([1 << 19] * 10, 1 << 20, 1 << 19, 1 << 19)
+    assert plan == [[0], [1, 2], [3, 4], [5, 6], [7, 8], [9]]
