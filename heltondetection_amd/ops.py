@@ -1197,6 +1197,61 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
     return dw
 
 
+class PwBwdSwitch:
+    """The one-launch backward of the 1x1 layers (csrc/pointwise_bwd.hip: data gradient + weight-gradient partials from one
+    staging of dy).  HD_FUSED_PW_BWD=0 goes back to the pair hd_pointwise_conv_dgrad + hd_pointwise_wgrad_partial."""
+    enabled = os.environ.get("HD_FUSED_PW_BWD", "1") != "0"
+
+
+def pointwise_bwd_supported(R: int, cin: int, cout: int) -> bool:
+    return PwBwdSwitch.enabled and bool(_lib.load().hd_pointwise_bwd_supported(int(R), int(cin), int(cout)))
+
+
+def pointwise_bwd_rows(dy: torch.Tensor, w2: torch.Tensor, x: torch.Tensor, add: Optional[torch.Tensor] = None,
+                       leaf: Optional[torch.Tensor] = None, out_dx: Optional[torch.Tensor] = None,
+                       out_dw: Optional[torch.Tensor] = None):
+    """(dx, dw) of a 1x1 convolution y = x . w2^T on channels-last rows, ONE launch, no autograd: dx[B, Cin, H, W] = dy . w2
+    (+ add), dw[Cout, Cin] = dy^T . x (bf16; complete after the next weight-gradient launch or flush_wgrad(), see
+    _WgradChain).  dy [B, Cout, H, W], x [B, Cin, H, W] bf16 channels-last rows; w2 the dense bf16 [Cout, Cin] forward weight."""
+    lib = _lib.load()
+    B, N, H, W = dy.shape
+    K = w2.shape[1]
+    R = B * H * W
+    ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
+    if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16
+            or not w2.is_contiguous() or tuple(w2.shape) != (N, K) or tuple(x.shape) != (B, K, H, W)):
+        raise _lib.HdError("pointwise_bwd: needs bf16 channels-last rows dy [B, Cout, H, W], x [B, Cin, H, W] and the dense bf16 "
+                           "[Cout, Cin] forward weight")
+    nbytes = lib.hd_pointwise_bwd_workspace_bytes(R, K, N)
+    if nbytes == 0:
+        raise _lib.HdError("pointwise_bwd: Cout must be 32 / 64 / 128 / 256 and Cin a multiple of 32")
+    dx = out_dx if out_dx is not None else torch.empty((B, K, H, W), dtype=torch.bfloat16, device=dy.device,
+                                                       memory_format=torch.channels_last)
+    ld_dx = _cl_row_stride(dx, 8)
+    if ld_dx is None or tuple(dx.shape) != (B, K, H, W) or dx.dtype != torch.bfloat16:
+        raise _lib.HdError("pointwise_bwd: `out_dx` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
+    ld_add = 0
+    if add is not None:
+        ld_add = _cl_row_stride(add, 8)
+        if ld_add is None or add.dtype != torch.bfloat16 or tuple(add.shape) != (B, K, H, W):
+            raise _lib.HdError("pointwise_bwd: `add` must be bf16 channels-last rows of dx's shape")
+    dw = out_dw if out_dw is not None else torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+    if dw.dtype != torch.bfloat16 or dw.numel() != N * K or not dw.is_contiguous():
+        raise _lib.HdError("pointwise_bwd: `out_dw` must be a dense bf16 tensor of Cout x Cin elements")
+    ws = _wgrad_workspace(dy.device, nbytes)
+    pend = _WgradChain.piggyback(dy.device)
+    job = _lib.WgradJob()
+    # each operand once: dy, x in; dx out (+ the addend in); w and the bf16 dw
+    _note_bytes("pointwise_bwd", 2 * (R * (N + 2 * K) + 2 * N * K) + (2 * R * K if add is not None else 0),
+                {"flops": 4 * R * K * N, "shape": (R, K, N)})
+    with _ktimed("pointwise_bwd"):
+        check(lib.hd_pointwise_bwd(_ptr(dy), int(ld_dy), _ptr(w2), _ptr(x), int(ld_x), R, K, N, _ptr(add), int(ld_add), _ptr(dx),
+                                   int(ld_dx), _ptr(dw), _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None,
+                                   C.byref(job), _stream(dy)), "hd_pointwise_bwd")
+    _WgradChain.submit(dy.device, job, (ws,), leaf)
+    return dx, dw
+
+
 def conv3x3_wgrad_supported(x: torch.Tensor, cout: int, stride: int = 1) -> bool:
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and _cl_row_stride(x, 8) is not None):
         return False
@@ -1478,11 +1533,14 @@ class _PointwiseConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16 or _cl_row_stride(dy, 8) is None:
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        ours = need_dx and bool(_lib.load().hd_pointwise_conv_dgrad_supported(x.shape[0] * x.shape[2] * x.shape[3], K, N))
+        R = x.shape[0] * x.shape[2] * x.shape[3]
+        ours = need_dx and bool(_lib.load().hd_pointwise_conv_dgrad_supported(R, K, N))
+        ours_w = need_dw and pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
+        if ours and ours_w and pointwise_bwd_supported(R, K, N):   # both gradients from one staging of dy
+            dx, dw = pointwise_bwd_rows(dy, weight.view(N, K), x, leaf=weight)
+            return dx, dw.view(N, K, 1, 1), None
         if ours:
             dx = pointwise_dgrad_rows(dy, weight.view(N, K))
-        R = x.shape[0] * x.shape[2] * x.shape[3]
-        ours_w = need_dw and pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
         if ours_w:
             dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
         lib_w, lib_x = need_dw and not ours_w, need_dx and not ours
@@ -1754,9 +1812,14 @@ class _PwConvBNActFn(torch.autograd.Function):
             return dx, dw, dg[1], dg[0], None, None, None, None, None, None, gres, None, None, None, None
         dy, dgamma, dbeta, gres = _bn_backward_dx(st, y_raw, g_)
         dx = dw = None
-        if need_dw and ours_dw:
+        if need_dw and ours_dw and need_dx and ours_dx and pointwise_bwd_supported(R, K, N):
+            # one launch: data gradient (+ the shortcut's gradient in its epilogue) and the weight-gradient partials
+            dx, dw = pointwise_bwd_rows(dy, weight.view(N, K), x, add=d_skip, leaf=weight)
+            dw = dw.view(N, K, 1, 1)
+            d_skip = None
+        if need_dw and ours_dw and dw is None:
             dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
-        if need_dx and ours_dx:
+        if need_dx and ours_dx and dx is None:
             dx = pointwise_dgrad_rows(dy, weight.view(N, K), add=d_skip)   # the shortcut's gradient rides in the epilogue
             d_skip = None
         lib_w, lib_x = need_dw and dw is None, need_dx and dx is None

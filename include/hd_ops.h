@@ -496,6 +496,22 @@ hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, cons
                                      void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback,
                                      hd_wgrad_job* job_out, hd_stream stream);
 
+/* The WHOLE backward of a 1x1 convolution in one launch (csrc/pointwise_bwd.hip; README.md:9 — every C3 / Bottleneck block
+ * of the reference's CSPDarknet / PAFPN is 1x1-heavy): dx[R, Cin] = dy[R, Cout] . w (+ add, as hd_pointwise_conv_dgrad_add;
+ * add nullable) AND the row-sliced float32 partial products of dw[Cout, Cin] = dy^T . x, from ONE staging of dy.  Replaces
+ * the pair hd_pointwise_conv_dgrad[_add] + hd_pointwise_wgrad_partial where Cout is 32 / 64 / 128 / 256 (the reduction of
+ * the data gradient) and Cin a multiple of 32 with at most 32 column tiles.  w: the forward weight [Cout][Cin] as it lies.
+ * The slab holds ONE partial per workgroup of a column tile (hd_pointwise_bwd_workspace_bytes: 4-8 MB whatever the layer);
+ * piggyback / job_out as for hd_pointwise_wgrad_partial.  dx may alias add.  hd_pointwise_bwd_tune(grid) overrides the
+ * planned main grid for experiments (0 = planned; call hd_pointwise_bwd_workspace_bytes again afterwards). */
+int hd_pointwise_bwd_supported(int64_t R, int Cin, int Cout);
+size_t hd_pointwise_bwd_workspace_bytes(int64_t R, int Cin, int Cout);
+void hd_pointwise_bwd_tune(int grid);
+hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride, int64_t R,
+                           int Cin, int Cout, const void* add, int64_t add_row_stride, void* dx, int64_t dx_row_stride, void* dw,
+                           void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
+                           hd_stream stream);
+
 /* The YOLOv5 v6.x stem, Conv2d(3, Cout, kernel 6, stride 2, padding 2, no bias), on channels-last images (csrc/stem_conv.hip;
  * the reference's backbone list, README.md:9).  x: [B, H, W, 3] float32 (x_dtype 0) or bfloat16 (1), dense, H even,
  * W % 4 == 0; w: bfloat16 [Cout][6][6][3] (the channels-last memory of a [Cout, 3, 6, 6] weight); Cout 32 or 64;
