@@ -174,8 +174,11 @@ def test_lowp_weight_shadows_match_autocast_casts(gpu):
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
                 assert model.c2.lp_weight() is model.c2.weight
     assert abs(out[True][0] - out[False][0]) <= 1e-4 * abs(out[False][0])
+    # Both sides are LIBRARY weight gradients rounded to bf16 (with shadows the gradient is born bf16, without them autocast's
+    # cast node produces it), possibly from different solvers: elements are equal or bf16 neighbours.  Bound: 3 bf16 ulps at the
+    # largest magnitude (3 * 2^-8).  Round 4 saw exactly 2 ulps (1.03e-2 of the maximum) on one fresh box, one above the old 1e-2.
     for a, b in zip(out[True][1] + [out[True][2]], out[False][1] + [out[False][2]]):
-        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-9
+        assert float((a - b).abs().max()) <= 3 * 2.0 ** -8 * float(b.abs().max()) + 1e-9
 
 
 def test_yolov5_frozen_backbone_dropblock_trains_under_graph(gpu):

@@ -23,7 +23,7 @@ PREDICTIONS, written before the first run (2026-10-04; the test bounds in tests/
     the product step no worse than torch-AMP by more than 0.05 in global cosine.
   * A after `--pretrain` steps (weights off the chaotic random-init point): single-run global cosine >= 0.9.
 
-    python tools/grad_fidelity.py [--size 640] [--batch 16] [--runs 8] [--pretrain 0] [--out profiles/r04_grad_fidelity.md]
+    python tools/grad_fidelity.py --miopen-find [--size 640] [--batch 16] [--runs 8] [--pretrain 0] [--out profiles/r04_grad_fidelity.md]
 """
 from __future__ import annotations
 
@@ -214,11 +214,15 @@ def main(argv=None):
     ap.add_argument("--out", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--skip-layers", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="MIOpen solver search + the shipped find-db, as bench.py runs")
     args = ap.parse_args(argv)
     from heltondetection_amd import synthetic as syn, tuning
     from heltondetection_amd.train import Trainer
-    tuning.use_shipped_find_db()
-    torch.backends.cudnn.benchmark = True
+    # process-wide settings are the CALLER's (the test suite runs this in-process: a solver search left switched on changed
+    # what every later test's library convolutions did); the command line below sets them
+    if args.miopen_find:
+        tuning.use_shipped_find_db()
+        torch.backends.cudnn.benchmark = True
     dev = torch.device("cuda", 0)
     g = syn.make_generator(1234)
 
