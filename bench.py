@@ -478,7 +478,7 @@ def _conv_kernel_entry(name, ms, nbytes, calls, flops):
 def bn_family_roofline(model, batch, args, device, trainer=None):
     """Step-weighted roofline of the fused BN+act kernels, measured IN the train step: three eager forward + loss +
     backward passes of this workload with every fused-BN launch stamping its own HIP event pair (kernel begin / end,
-    hd_debug_time_next_launch), so each kernel is timed on its real tensors in its real cache state (x fresh from the
+    hd_profile_time_next_launch), so each kernel is timed on its real tensors in its real cache state (x fresh from the
     convolution for stats / apply, x cold and dy fresh for the backward pair) — what a profiler reports for the same
     launches inside the replayed graph.  achieved = algorithmic bytes of all launches of a step / their summed time;
     the ops note each launch's algorithmic bytes and shape themselves (ops._note_bytes), in launch order."""
@@ -536,7 +536,7 @@ def bn_family_roofline(model, batch, args, device, trainer=None):
                       "layer_bytes_min_max": [sizes[0], sizes[-1]] if sizes else None,
                       "timed": "inside 3 eager forward+loss+backward passes of this workload right after the timed region: every "
                                "fused-BN launch stamps its own HIP event pair with the kernel's begin / end (hipExtLaunchKernel "
-                               "through hd_debug_time_next_launch) on the launch stream; per kernel the summed time of a pass, "
+                               "through hd_profile_time_next_launch) on the launch stream; per kernel the summed time of a pass, "
                                "median over the passes",
                       "per_kernel": {k: {"sum_ms": round(ms_k[k], 4), "GB/s": round(bytes_k[k] / ms_k[k] / 1e6, 1),
                                          "frac": round(bytes_k[k] / ms_k[k] / 1e6 / HBM_PEAK_GBS, 4), "launches": n_k[k]}

@@ -89,7 +89,7 @@ SIGNATURES = {
     "hd_abi_version": (C.c_int, []),
     "hd_status_str": (C.c_char_p, [_I]),
     "hd_device_count": (C.c_int, []),
-    "hd_debug_time_next_launch": (_I, [_P, _P]),
+    "hd_profile_time_next_launch": (_I, [_P, _P]),
     "hd_anchor_base": (_I, [_P, _I, _P, _I, _P]),
     "hd_anchor_grid": (_I, [_I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "hd_pairwise_iou": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P]),
@@ -104,6 +104,8 @@ SIGNATURES = {
     "hd_roi_level_map": (_I, [_P, _I, _I, _I, _F, _I, _P, _P]),
     "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
     "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
+    "hd_roi_align_bwd_gather_supported": (_I, [_P, _I, _I, _I, _I, _I, _L]),
+    "hd_roi_align_bwd_gather": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
     "hd_roi_pool_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_yolo_decode": (_I, [_P, _I, _P, _P]),

@@ -188,7 +188,7 @@ __device__ __forceinline__ int hd_lane() { return threadIdx.x & 63; }
 
 // ---- launches with optional kernel-only timing ----------------------------------------------------------
 // hd_launch() is hipLaunchKernel with the arguments converted to the kernel's exact parameter types.  When the
-// caller armed this thread with hd_debug_time_next_launch(start, stop) the launch goes through hipExtLaunchKernel
+// caller armed this thread with hd_profile_time_next_launch(start, stop) the launch goes through hipExtLaunchKernel
 // instead, which stamps the two events with the kernel's OWN begin / end (the dispatch packet's timestamps — the
 // interval rocprofv3 reports), so bench.py's rooflines are HIP-event measurements of the kernel alone, without
 // the host launch gap or the ~1.5 us boundary an event pair around the launch would include.

@@ -28,7 +28,7 @@ extern "C" int hd_device_count(void) {
 // Arms the calling thread: the next kernel launched through hd_launch() (the fused BN kernels, the dense loss
 // gradient, RoIAlign, pairwise IoU) stamps `start` / `stop` (hipEvent_t created with timing enabled) with that
 // kernel's own begin and end.  NULL, NULL disarms.  Measurement aid of bench.py; no effect on results.
-extern "C" hd_status hd_debug_time_next_launch(void* start_event, void* stop_event) {
+extern "C" hd_status hd_profile_time_next_launch(void* start_event, void* stop_event) {
   if ((start_event == nullptr) != (stop_event == nullptr)) return HD_ERR_NULL;
   HdLaunchTiming& t = hd_launch_timing();
   t.start = reinterpret_cast<hipEvent_t>(start_event);

@@ -451,6 +451,219 @@ __global__ __launch_bounds__(256) void roi_align_bwd_cl_kernel(const hd_roi_leve
   }
 }
 
+// ---- backward as a GATHER: no atomics, every cell written once, bit-reproducible ------------------------------
+// (the scatter above runs at the float-atomic rate, 0.60 ms at R = 2048, C = 256, behind a zero-fill of the
+// float32 maps and in front of their cast to bf16 — 0.9 + 0.9 + 1.4 GB of traffic for 25 MB of incoming gradient.)
+// A workgroup owns an 8 x 8 tile of cells of one (level, image) map and 256 channels (wave = 64 channels, lane = channel): it
+// scans the RoI list for the RoIs whose sampling window touches its tile (ballot-compacted in RoI order, so the summation
+// order is fixed), and for each of them forms, per axis, the dense little matrices
+//     Wy[cell row][ph] = sum over the SR samples of bin ph of the bilinear weight that sample gives this cell row (x 1/count)
+//     Wx[cell col][pw] = the same along x
+// (the forward is out[ph][pw] = sum_y sum_x Wy[y][ph] Wx[x][pw] f[y][x]; this is its transpose), stages the RoI's incoming
+// gradient block g[P][P][256 channels] in LDS with 16-byte loads (the next RoI's block travels in registers meanwhile), and
+// accumulates   acc[y][x] += sum_pw Wx[x][pw] (sum_ph Wy[y][ph] g[ph][pw])   in 64 registers per lane.  The finished tile goes
+// through LDS to 16-byte row stores in the MAP's dtype: the bf16 maps of a bf16 pyramid are written directly (no float32
+// accumulator maps, no zero-fill, no cast pass), tiles no RoI touches are written as zeros.
+constexpr int kGatherTile = 8;
+constexpr int kGatherMaxP = 8;
+constexpr int kGatherList = 1024;  // RoIs per scan chunk (LDS list)
+
+struct GatherPlan {
+  int tile_start[HD_MAX_LEVELS + 1];  // first workgroup of each level (x dimension of the grid)
+  int tiles_x[HD_MAX_LEVELS], tiles_y[HD_MAX_LEVELS];
+  int batch;
+};
+
+template <typename TG, typename TM, int SR>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const hd_roi_levels lv, const GatherPlan plan,
+                                                                   const float* __restrict__ rois, int R, int C, int P,
+                                                                   int aligned, const TG* __restrict__ grad_out,
+                                                                   long long out_sr, long long out_sh, long long out_sw) {
+  constexpr int T = kGatherTile;
+  constexpr int GV = 16 / (int)sizeof(TG);        // gradient elements per 16-byte chunk
+  constexpr int MV = 16 / (int)sizeof(TM);        // map elements per 16-byte chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][P*P*256] TG gradient blocks; later the output tile
+  __shared__ float s_wy[2][T][kGatherMaxP], s_wx[2][T][kGatherMaxP];
+  __shared__ unsigned s_rowmask[2], s_colmask[2];
+  __shared__ int s_list[kGatherList];
+  __shared__ int s_cnt, s_wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // which (level, image, tile)
+  int l = 0;
+  while (l + 1 < lv.n_levels && (int)blockIdx.x >= plan.tile_start[l + 1]) ++l;
+  const int local = (int)blockIdx.x - plan.tile_start[l];
+  const int per_img = plan.tiles_x[l] * plan.tiles_y[l];
+  const int bi = local / per_img, tq = local % per_img;
+  const int ty0 = (tq / plan.tiles_x[l]) * T, tx0 = (tq % plan.tiles_x[l]) * T;
+  const int H = lv.h[l], W = lv.w[l];
+  const int c0 = (int)blockIdx.y * 256;            // this workgroup's first channel
+  const int ch = c0 + wave * 64 + lane;            // this lane's channel
+  const bool ch_ok = ch < C;
+  const int nch = min(256, C - c0);                // channels of this workgroup (a multiple of 64)
+  const int blk_elems = P * P * 256;               // LDS gradient block (256-channel rows, nch of them used)
+
+  float acc[T][T];
+#pragma unroll
+  for (int y = 0; y < T; ++y)
+#pragma unroll
+    for (int x = 0; x < T; ++x) acc[y][x] = 0.0f;
+
+  const float scale = lv.spatial_scale[l];
+  // this thread's share of a RoI's gradient block: 16-byte chunks id = tid + 256 k of [P*P][nch]
+  const int cpr = nch / GV;                        // chunks per (ph, pw) row
+  const int nchunks = P * P * cpr;
+  constexpr int MAXL = (kGatherMaxP * kGatherMaxP * (256 / GV) + 255) / 256;
+  uint4 pre[MAXL];
+  auto load_block = [&](int r) {
+    const TG* gb = grad_out + (long long)r * out_sr + c0;
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) {
+      const int id = tid + 256 * k;
+      if (id < nchunks) {
+        const int p = id / cpr, q = id - p * cpr;
+        pre[k] = *reinterpret_cast<const uint4*>(gb + (long long)(p / P) * out_sh + (long long)(p % P) * out_sw + q * GV);
+      }
+    }
+  };
+  auto store_block = [&](int buf) {
+    TG* sb = reinterpret_cast<TG*>(smem) + (size_t)buf * blk_elems;
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) {
+      const int id = tid + 256 * k;
+      if (id < nchunks) {
+        const int p = id / cpr, q = id - p * cpr;
+        *reinterpret_cast<uint4*>(sb + p * 256 + q * GV) = pre[k];
+      }
+    }
+  };
+  // the per-axis weight matrices of RoI r against this tile (threads 0 .. 2 T P - 1), and which rows / columns are non-zero
+  auto weights = [&](int r, int buf) {
+    if (tid < 2) (tid == 0 ? s_rowmask : s_colmask)[buf] = 0u;
+    __syncthreads();
+    if (tid < 2 * T * P) {
+      const float* roi = rois + (size_t)r * 5;
+      const RoiGeom g = roi_geometry(roi, scale, P, SR, aligned);
+      const bool is_y = tid < T * P;
+      const int i = is_y ? tid : tid - T * P;
+      const int cell = i / P, p = i - cell * P;
+      const int size = is_y ? H : W;
+      const int cabs = (is_y ? ty0 : tx0) + cell;
+      const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
+      float w = 0.0f;
+#pragma unroll
+      for (int is = 0; is < SR; ++is) {
+        const float v = start + (float)p * bin + ((float)is + 0.5f) * bin / (float)SR;
+        const Tap1 t = tap1(size, v);
+        if (t.ok) {
+          if (t.lo == cabs) w += t.wlo;
+          if (t.hi == cabs && t.hi != t.lo) w += t.whi;
+        }
+      }
+      if (is_y) w *= 1.0f / g.count;   // count = SR * SR in {1, 4}: exact
+      (is_y ? s_wy : s_wx)[buf][cell][p] = w;
+      if (w != 0.0f) atomicOr(is_y ? &s_rowmask[buf] : &s_colmask[buf], 1u << cell);
+    }
+  };
+
+  for (int chunk = 0; chunk < R; chunk += kGatherList) {
+    // ---- scan: the RoIs of this chunk whose window touches the tile, in RoI order
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int chunk_n = min(kGatherList, R - chunk);
+    for (int base = 0; base < chunk_n; base += 256) {
+      const int r = chunk + base + tid;
+      bool hit = false;
+      if (base + tid < chunk_n) {
+        const float* roi = rois + (size_t)r * 5;
+        if ((int)roi[0] == bi && roi_level_of(roi, lv.k_min, lv.n_levels, lv.canonical_scale, lv.canonical_level) == l) {
+          const RoiGeom g = roi_geometry(roi, scale, P, SR, aligned);
+          // cells that can receive weight: floor(first sample) .. floor(last sample) + 1, conservatively widened by one
+          const float y_lo = g.start_h, y_hi = g.start_h + (float)P * g.bin_h;
+          const float x_lo = g.start_w, x_hi = g.start_w + (float)P * g.bin_w;
+          hit = y_hi + 2.0f >= (float)ty0 && y_lo - 2.0f <= (float)(ty0 + T - 1) && x_hi + 2.0f >= (float)tx0 &&
+                x_lo - 2.0f <= (float)(tx0 + T - 1);
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) s_wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = s_cnt;
+      for (int w2 = 0; w2 < wave; ++w2) off += s_wcnt[w2];
+      if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+      __syncthreads();
+      if (tid == 0) s_cnt += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      __syncthreads();
+    }
+    const int n = s_cnt;
+    if (n == 0) continue;
+    // ---- accumulate: block i in LDS buffer i & 1, block i + 1 in registers meanwhile
+    load_block(s_list[0]);
+    weights(s_list[0], 0);
+    store_block(0);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const int buf = i & 1;
+      if (i + 1 < n) load_block(s_list[i + 1]);
+      const TG* sb = reinterpret_cast<const TG*>(smem) + (size_t)buf * blk_elems + wave * 64 + lane;
+      const unsigned rowmask = s_rowmask[buf], colmask = s_colmask[buf];
+      if (rowmask != 0u && colmask != 0u && ch_ok) {
+        float gv[kGatherMaxP * kGatherMaxP];
+#pragma unroll
+        for (int p = 0; p < kGatherMaxP * kGatherMaxP; ++p)
+          if (p < P * P) gv[p] = ld_elem(sb + p * 256);
+#pragma unroll
+        for (int y = 0; y < T; ++y) {
+          if (!(rowmask & (1u << y))) continue;      // workgroup-uniform
+          float t[kGatherMaxP];
+#pragma unroll
+          for (int pw = 0; pw < kGatherMaxP; ++pw) {
+            t[pw] = 0.0f;
+            if (pw < P) {
+#pragma unroll
+              for (int ph = 0; ph < kGatherMaxP; ++ph)
+                if (ph < P) t[pw] = fmaf(s_wy[buf][y][ph], gv[ph * P + pw], t[pw]);
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < T; ++x) {
+            if (!(colmask & (1u << x))) continue;
+            float a = acc[y][x];
+#pragma unroll
+            for (int pw = 0; pw < kGatherMaxP; ++pw)
+              if (pw < P) a = fmaf(s_wx[buf][x][pw], t[pw], a);
+            acc[y][x] = a;
+          }
+        }
+      }
+      if (i + 1 < n) {
+        weights(s_list[i + 1], buf ^ 1);   // has a barrier inside: everybody is past its reads of buffer buf ^ 1 (block i - 1)
+        store_block(buf ^ 1);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- the tile, through LDS, as 16-byte row stores in the map's dtype: out[cell][nch]
+  __syncthreads();
+  TM* so = reinterpret_cast<TM*>(smem);
+  if (ch_ok) {
+#pragma unroll
+    for (int y = 0; y < T; ++y)
+#pragma unroll
+      for (int x = 0; x < T; ++x) st_elem(so + (y * T + x) * 256 + wave * 64 + lane, acc[y][x]);
+  }
+  __syncthreads();
+  TM* fimg = reinterpret_cast<TM*>(const_cast<void*>(lv.feat[l])) + (long long)bi * lv.sb[l] + c0;
+  const int ocpr = nch / MV;
+  for (int id = tid; id < T * T * ocpr; id += 256) {
+    const int cell = id / ocpr, q = id - cell * ocpr;
+    const int y = ty0 + cell / T, x = tx0 + cell % T;
+    if (y < H && x < W)
+      *reinterpret_cast<uint4*>(fimg + (long long)y * lv.sh[l] + (long long)x * lv.sw[l] + q * MV) =
+          *reinterpret_cast<const uint4*>(so + cell * 256 + q * MV);
+  }
+}
+
 // ---- quantised RoI max-pooling -------------------------------------------------------------------
 // Same mapping as RoIAlign: workgroup = (RoI, pooled row), lanes = channels, so the bin bounds are
 // wave-uniform scalars and a wave reads 64 consecutive channels of one cell per request.
@@ -659,6 +872,66 @@ extern "C" hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const fl
     hipLaunchKernelGGL((roi_align_bwd_kernel<float>), dim3(R, P), dim3(threads), 0, s, *grad_levels, rois, C, P,
                        sampling_ratio, aligned, reinterpret_cast<const float*>(grad_out), (long long)out_sr,
                        (long long)out_sc, (long long)out_sh, (long long)out_sw);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align_bwd_gather_supported(const hd_roi_levels* grad_levels, int R, int C, int P, int sampling_ratio,
+                                                 int grad_dtype, int64_t out_sc) {
+  if (!grad_levels || R < 0 || C < 64 || C % 64 || P < 1 || P > kGatherMaxP) return 0;
+  if (sampling_ratio != 1 && sampling_ratio != 2) return 0;
+  if (grad_dtype != 0 && grad_dtype != 1) return 0;
+  if (grad_levels->dtype != 0 && grad_levels->dtype != 1) return 0;
+  if (out_sc != 1) return 0;
+  const long long ma = grad_levels->dtype == 0 ? 4 : 8;  // map elements per 16 bytes
+  for (int l = 0; l < grad_levels->n_levels; ++l) {
+    if (grad_levels->sc[l] != 1 || !hd_aligned16(grad_levels->feat[l])) return 0;
+    if (grad_levels->sb[l] % ma || grad_levels->sh[l] % ma || grad_levels->sw[l] % ma) return 0;
+    if (grad_levels->h[l] < 1 || grad_levels->w[l] < 1) return 0;
+  }
+  return 1;
+}
+
+extern "C" hd_status hd_roi_align_bwd_gather(const hd_roi_levels* grad_levels, int batch, const float* rois, int R, int C, int P,
+                                             int sampling_ratio, int aligned, const void* grad_out, int grad_dtype,
+                                             int64_t out_sr, int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream) {
+  if (!grad_levels || (R > 0 && (!rois || !grad_out))) return HD_ERR_NULL;
+  if (batch < 1 || grad_levels->n_levels < 1 || grad_levels->n_levels > HD_MAX_LEVELS) return HD_ERR_SHAPE;
+  if (!hd_roi_align_bwd_gather_supported(grad_levels, R, C, P, sampling_ratio, grad_dtype, out_sc)) return HD_ERR_SHAPE;
+  const int gv = grad_dtype == 0 ? 4 : 8;
+  if (R > 0 && (!hd_aligned16(grad_out) || out_sr % gv || out_sh % gv || out_sw % gv)) return HD_ERR_ALIGN;
+  GatherPlan plan{};
+  int total = 0;
+  for (int l = 0; l < grad_levels->n_levels; ++l) {
+    plan.tile_start[l] = total;
+    plan.tiles_x[l] = (grad_levels->w[l] + kGatherTile - 1) / kGatherTile;
+    plan.tiles_y[l] = (grad_levels->h[l] + kGatherTile - 1) / kGatherTile;
+    total += plan.tiles_x[l] * plan.tiles_y[l] * batch;
+  }
+  for (int l = grad_levels->n_levels; l <= HD_MAX_LEVELS; ++l) plan.tile_start[l] = total;
+  plan.batch = batch;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)total, (unsigned)((C + 255) / 256));
+  const size_t gsz = grad_dtype == 0 ? 4 : 2, msz = grad_levels->dtype == 0 ? 4 : 2;
+  size_t lds = 2 * (size_t)P * P * 256 * gsz;
+  const size_t tile_bytes = (size_t)kGatherTile * kGatherTile * 256 * msz;
+  if (lds < tile_bytes) lds = tile_bytes;
+#define HD_ROI_GATHER(TG, TM, SR)                                                                                          \
+  (void)hd_launch(roi_align_bwd_gather_kernel<TG, TM, SR>, grid, dim3(256), lds, s, *grad_levels, plan, rois, R, C, P, aligned, \
+                  reinterpret_cast<const TG*>(grad_out), (long long)out_sr, (long long)out_sh, (long long)out_sw)
+  const bool gbf = grad_dtype == 1, mbf = grad_levels->dtype == 1;
+  if (sampling_ratio == 1) {
+    if (gbf && mbf) HD_ROI_GATHER(__hip_bfloat16, __hip_bfloat16, 1);
+    else if (gbf) HD_ROI_GATHER(__hip_bfloat16, float, 1);
+    else if (mbf) HD_ROI_GATHER(float, __hip_bfloat16, 1);
+    else HD_ROI_GATHER(float, float, 1);
+  } else {
+    if (gbf && mbf) HD_ROI_GATHER(__hip_bfloat16, __hip_bfloat16, 2);
+    else if (gbf) HD_ROI_GATHER(__hip_bfloat16, float, 2);
+    else if (mbf) HD_ROI_GATHER(float, __hip_bfloat16, 2);
+    else HD_ROI_GATHER(float, float, 2);
+  }
+#undef HD_ROI_GATHER
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

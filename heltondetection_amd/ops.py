@@ -109,11 +109,11 @@ class _timed:
 
 def _arm_kernel_timing():
     """Arms libhd_ops so that the NEXT launch of an hd_launch() kernel stamps a fresh event pair with the kernel's own
-    begin / end (hd_debug_time_next_launch: the dispatch's timestamps, what a profiler reports).  Returns the pair."""
+    begin / end (hd_profile_time_next_launch: the dispatch's timestamps, what a profiler reports).  Returns the pair."""
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()  # creates the hipEvent_t handles (torch creates them lazily at the first record)
     b.record()
-    check(_lib.load().hd_debug_time_next_launch(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)), "hd_debug_time_next_launch")
+    check(_lib.load().hd_profile_time_next_launch(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)), "hd_profile_time_next_launch")
     return a, b
 
 
@@ -131,7 +131,7 @@ class _ktimed:
 
     def __exit__(self, *exc):
         if self.name is not None:
-            _lib.load().hd_debug_time_next_launch(None, None)  # in case the call did not launch (empty input)
+            _lib.load().hd_profile_time_next_launch(None, None)  # in case the call did not launch (empty input)
             _TIMED[self.name].append(self.pair)
         return False
 
@@ -306,6 +306,12 @@ def roi_level_map(rois: torch.Tensor, k_min: int, n_levels: int, canonical_scale
     return out
 
 
+class RoiBwdSwitch:
+    """Which RoIAlign backward runs: the gather (csrc/roi_align.hip roi_align_bwd_gather_kernel: no atomics, every cell written
+    once in the maps' dtype, bit-reproducible) or the float-atomic scatter.  HD_ROI_BWD_GATHER=0 | 1 overrides the default."""
+    gather = os.environ.get("HD_ROI_BWD_GATHER", "1") != "0"
+
+
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, P, scales, sampling_ratio, aligned, k_min, canonical_scale, canonical_level,
@@ -333,13 +339,26 @@ class _RoIAlignFn(torch.autograd.Function):
         P, scales, sampling_ratio, aligned, k_min, cs, cl, shapes = ctx.meta
         if grad_out.dtype not in (_F32, torch.bfloat16):
             grad_out = grad_out.float()
+        R, Cc = rois.shape[0], shapes[0][0][1]
+        # gather form: every cell of the gradient maps written once in the features' own dtype, no atomics, no zero-fill, no
+        # cast pass, bit-reproducible (csrc/roi_align.hip: roi_align_bwd_gather_kernel)
+        if RoiBwdSwitch.gather and all(cl_fmt for _, cl_fmt, _ in shapes) and len({dt for _, _, dt in shapes}) == 1:
+            go = grad_out if grad_out.stride(1) == 1 else grad_out.contiguous(memory_format=torch.channels_last)
+            maps = [torch.empty(shape, dtype=dt, device=rois.device, memory_format=torch.channels_last) for shape, _, dt in shapes]
+            stg = _roi_levels(maps, scales, k_min, cs, cl, allow_bf16=True)
+            gdt = 0 if go.dtype == _F32 else 1
+            if lib.hd_roi_align_bwd_gather_supported(C.byref(stg), R, Cc, P, int(sampling_ratio), gdt, go.stride(1)):
+                with _ktimed("roi_align_bwd"):
+                    check(lib.hd_roi_align_bwd_gather(C.byref(stg), shapes[0][0][0], _ptr(rois), R, Cc, P, int(sampling_ratio),
+                                                      int(bool(aligned)), _ptr(go), gdt, go.stride(0), go.stride(1), go.stride(2),
+                                                      go.stride(3), _stream(rois)), "hd_roi_align_bwd_gather")
+                return (None,) * 10 + tuple(maps)
         # float32 accumulators for the atomics whatever the feature dtype (a bf16 running sum would round on
         # every add); cast once at the end for bf16 features
         grads = [torch.empty(shape, dtype=_F32, device=rois.device,
                              memory_format=torch.channels_last if cl_fmt else torch.contiguous_format).zero_()
                  for shape, cl_fmt, _ in shapes]
         st = _roi_levels(grads, scales, k_min, cs, cl)
-        R, Cc = rois.shape[0], shapes[0][0][1]
         with _ktimed("roi_align_bwd"):
             check(lib.hd_roi_align_bwd(C.byref(st), _ptr(rois), R, Cc, P, int(sampling_ratio), int(bool(aligned)),
                                        _ptr(grad_out), 0 if grad_out.dtype == _F32 else 1, grad_out.stride(0),
@@ -561,7 +580,7 @@ def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, sl
                              iters: int = 20) -> List[float]:
     """Measurement helper for bench.py: runs the loss forward once on `preds`, then launches
     hd_yolo_loss_bwd_dense `iters` times on the current stream, each launch stamping its own HIP event pair with
-    the kernel's begin / end (hd_debug_time_next_launch).  Returns the per-launch milliseconds."""
+    the kernel's begin / end (hd_profile_time_next_launch).  Returns the per-launch milliseconds."""
     lib = _lib.load()
     preds = [p.detach() for p in preds]
     st = _yolo_levels(preds, strides, anchors)
@@ -1985,7 +2004,7 @@ def time_bn_act_kernels(shape, dtype=torch.bfloat16, act: str = "silu", iters: i
                         residual_after_act: bool = False):
     """Measurement helper for bench.py: the four fused-BN kernels on one channels-last tensor of `shape`
     ([B,C,H,W]), each launched `iters` times on the current stream, every launch stamping its own HIP event pair
-    with the kernel's begin / end (hd_debug_time_next_launch), i.e. the kernel alone, without host launch gaps.
+    with the kernel's begin / end (hd_profile_time_next_launch), i.e. the kernel alone, without host launch gaps.
     Returns {kernel: (median ms, algorithmic bytes)}.
     residual_after_act: the apply kernel also reads a residual tensor (y = act(bn(x)) + r, the YOLOv5 shortcut;
     the backward kernels are the plain ones in that mode)."""

@@ -63,7 +63,7 @@ int hd_device_count(void);
  * BN+act, hd_yolo_loss_bwd_dense, hd_roi_align_fwd/_bwd fast paths, hd_pairwise_iou) records the kernel's own
  * begin / end into the two hipEvent_t (timing enabled) — the interval a profiler reports for the dispatch, free of
  * host launch gaps.  NULL, NULL disarms.  Results are unaffected. */
-hd_status hd_debug_time_next_launch(void* start_event, void* stop_event);
+hd_status hd_profile_time_next_launch(void* start_event, void* stop_event);
 
 /* ---- anchors (FasterRCNN RPN, README.md:8) --------------------------------- */
 
@@ -192,6 +192,17 @@ hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, 
                            int P, int sampling_ratio, int aligned, const void* grad_out,
                            int grad_dtype, int64_t out_sr, int64_t out_sc, int64_t out_sh,
                            int64_t out_sw, hd_stream stream);
+
+/* Backward as a gather (csrc/roi_align.hip, roi_align_bwd_gather_kernel): WRITES every cell of every level map of
+ * grad_levels (float32 or bfloat16 maps: grad_levels->dtype; nothing has to be zeroed) exactly once, without atomics, in a
+ * fixed summation order (RoI order): bit-reproducible.  `batch`: images per map (RoIs with other batch indices are ignored).
+ * Needs channels-last maps (sc == 1, 16-byte aligned rows) and gradient (out_sc == 1), C a multiple of 64, P <= 8,
+ * sampling_ratio 1 or 2: hd_roi_align_bwd_gather_supported() says whether a call qualifies (else: hd_roi_align_bwd). */
+int hd_roi_align_bwd_gather_supported(const hd_roi_levels* grad_levels, int R, int C, int P, int sampling_ratio,
+                                      int grad_dtype, int64_t out_sc);
+hd_status hd_roi_align_bwd_gather(const hd_roi_levels* grad_levels, int batch, const float* rois, int R, int C, int P,
+                                  int sampling_ratio, int aligned, const void* grad_out, int grad_dtype, int64_t out_sr,
+                                  int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream);
 
 /* ---- RoI max-pooling over pyramid levels (README.md:73 "FasterRCNN-FPNP2-RoIPooling") ---- */
 

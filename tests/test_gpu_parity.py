@@ -811,3 +811,41 @@ def test_iou_fast_quotient_paths_are_bit_exact(gpu, ops, M):
     got = ops.pairwise_iou(a[0].to(gpu), b.to(gpu)).cpu().numpy()
     ref = co.pairwise_iou(np.broadcast_to(a[0].numpy(), (B, N, 4)).copy(), b.numpy())
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("C,R,dtype", [(256, 2048, "bf16"), (64, 300, "f32"), (320, 1500, "bf16")])
+def test_roi_align_backward_gather_is_reproducible_and_equals_the_scatter(gpu, ops, C, R, dtype):
+    """the backward as a gather (one workgroup per 8 x 8 tile of cells, RoIs in list order, no atomics) writes
+    every cell of the gradient maps once in the maps' own dtype.  Checked: two runs are bit-identical (the scatter's float
+    atomics are not), the result equals the float-atomic scatter to float32 rounding (bf16 maps: one bf16 rounding), cells
+    under no RoI are exactly zero although the maps start uninitialised, R spans more than one scan chunk (1024), C is not a
+    multiple of 256 in one case."""
+    strides = [4, 8, 16, 32]
+    B, size = 3, 416
+    feats, rois = _roi_case(71 + C, B, C, size, R, strides)
+    # leave image 2 without RoIs on its upper half: whole tiles that nothing touches
+    rois[rois[:, 0] == 2, 2] = rois[rois[:, 0] == 2, 2].clamp(min=size * 0.6)
+    rois[rois[:, 0] == 2, 4] = torch.maximum(rois[rois[:, 0] == 2, 4], rois[rois[:, 0] == 2, 2] + 8.0)
+    scales = [1.0 / s for s in strides]
+    t = torch.bfloat16 if dtype == "bf16" else torch.float32
+    go = None
+    res = {}
+    for mode in ("gather", "gather2", "scatter"):
+        ops.RoiBwdSwitch.gather = mode != "scatter"
+        try:
+            fd = [dev(f, gpu).to(t).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+            out = ops.roi_align(fd, dev(rois, gpu), 7, scales, 2, True, 2, 224.0 / 4, 4, channels_last_out=True)
+            if go is None:
+                go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(gpu).to(t).contiguous(memory_format=torch.channels_last)
+            out.backward(go)
+            res[mode] = [f.grad.clone() for f in fd]
+        finally:
+            ops.RoiBwdSwitch.gather = True
+    for a, b, c in zip(res["gather"], res["gather2"], res["scatter"]):
+        assert a.dtype == t and torch.equal(a, b)                         # bit-reproducible
+        assert bool(torch.isfinite(a).all())
+        tol = 2e-5 if dtype == "f32" else 2.0 ** -7
+        err = (a.float() - c.float()).abs()
+        assert bool((err <= tol * c.float().abs() + tol * c.float().abs().mean()).all()), float(err.max())
+        assert bool((a[c == 0] == 0).all())                               # untouched cells are written as zeros
+    assert any(bool((g[2, :, : g.shape[2] // 4] == 0).all()) for g in res["gather"])   # the empty region exists
