@@ -105,7 +105,8 @@ SIGNATURES = {
     "hd_roi_align_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
     "hd_roi_align_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
     "hd_roi_align_bwd_gather_supported": (_I, [_P, _I, _I, _I, _I, _I, _L]),
-    "hd_roi_align_bwd_gather": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P]),
+    "hd_roi_align_bwd_gather_workspace_bytes": (_Z, [_I, _I]),
+    "hd_roi_align_bwd_gather": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P, _Z, _P]),
     "hd_roi_pool_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _L, _L, _L, _P]),
     "hd_yolo_decode": (_I, [_P, _I, _P, _P]),

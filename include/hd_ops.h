@@ -196,13 +196,16 @@ hd_status hd_roi_align_bwd(const hd_roi_levels* grad_levels, const float* rois, 
 /* Backward as a gather (csrc/roi_align.hip, roi_align_bwd_gather_kernel): WRITES every cell of every level map of
  * grad_levels (float32 or bfloat16 maps: grad_levels->dtype; nothing has to be zeroed) exactly once, without atomics, in a
  * fixed summation order (RoI order): bit-reproducible.  `batch`: images per map (RoIs with other batch indices are ignored).
- * Needs channels-last maps (sc == 1, 16-byte aligned rows) and gradient (out_sc == 1), C a multiple of 64, P <= 8,
- * sampling_ratio 1 or 2: hd_roi_align_bwd_gather_supported() says whether a call qualifies (else: hd_roi_align_bwd). */
+ * Needs channels-last maps (sc == 1, 16-byte aligned rows) and gradient (out_sc == 1), C a multiple of 64, P == 7,
+ * sampling_ratio 1 or 2; workspace: one 32-byte record per RoI + the per-image ranges of the list (hd_roi_align_bwd_gather_workspace_bytes; a
+ * list ordered by image lets every tile scan its own image's RoIs only; any order is accepted): hd_roi_align_bwd_gather_supported() says whether a call qualifies (else: hd_roi_align_bwd). */
 int hd_roi_align_bwd_gather_supported(const hd_roi_levels* grad_levels, int R, int C, int P, int sampling_ratio,
                                       int grad_dtype, int64_t out_sc);
+size_t hd_roi_align_bwd_gather_workspace_bytes(int R, int batch);
 hd_status hd_roi_align_bwd_gather(const hd_roi_levels* grad_levels, int batch, const float* rois, int R, int C, int P,
                                   int sampling_ratio, int aligned, const void* grad_out, int grad_dtype, int64_t out_sr,
-                                  int64_t out_sc, int64_t out_sh, int64_t out_sw, hd_stream stream);
+                                  int64_t out_sc, int64_t out_sh, int64_t out_sw, void* workspace, size_t workspace_bytes,
+                                  hd_stream stream);
 
 /* ---- RoI max-pooling over pyramid levels (README.md:73 "FasterRCNN-FPNP2-RoIPooling") ---- */
 

@@ -12,9 +12,10 @@ for R in (2048, 8192):
     go = torch.randn((R, 256, 7, 7), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     for name, img in (("real", torch.arange(16).repeat_interleave(R // 16)), ("no image matches", torch.full((R,), 99))):
         rois = torch.cat([img[:, None].float(), rb], 1).to(dev)
+        ws = torch.empty(lib.hd_roi_align_bwd_gather_workspace_bytes(R, 16), dtype=torch.uint8, device=dev)
         def run():
             ops.check(lib.hd_roi_align_bwd_gather(C.byref(st), 16, ops._ptr(rois), R, 256, 7, 2, 1, ops._ptr(go), 1, go.stride(0), go.stride(1),
-                                                  go.stride(2), go.stride(3), ops._stream(rois)), "gather")
+                                                  go.stride(2), go.stride(3), ops._ptr(ws), ws.numel(), ops._stream(rois)), "gather")
         for _ in range(2): run()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
