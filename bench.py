@@ -155,17 +155,20 @@ def loss_bwd_bytes(B, size, no, na=3, strides=(8, 16, 32)):
 
 
 def pmc_traffic(kernel, shape: str = ""):
-    """HBM bytes from the committed counter run of this round (profiles/r03_pmc_traffic.json, made by tools/prof_r03.sh:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager train steps of the final build, FETCH doubled for
-    16-byte streams as MI355X_MICROARCH.md prescribes).  `kernel`: a family name of that file ("hand-written convolutions",
-    "fused BN+act") -> bytes per train step; or a kernel-name fragment -> bytes per launch of the first kernel whose name
-    contains it.  None when the file has no such entry (other model / size: the counter run is YOLOv5s 640^2 bs16).  PMC
-    counters cannot be read from inside this process, so this is a look-up, and the JSON line says so (traffic_source)."""
+    """HBM bytes from the committed counter run of THIS round's build (profiles/r04_pmc_traffic.json, made by tools/prof_r04.sh +
+    tools/pmc_traffic_r04.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled for 16-byte streams as
+    MI355X_MICROARCH.md prescribes).  `kernel`: a family name of that file ("hand-written convolutions", "fused BN+act") -> bytes
+    per train step (YOLOv5s 640^2 bs16); a single-kernel key of its "single_kernels" table -> bytes per launch; or a kernel-name
+    fragment -> bytes per launch of the first step kernel whose name contains it.  None when the file has no such entry (other
+    model / size).  PMC counters cannot be read from inside this process, so this is a look-up, and the line says so."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         fam = rec.get("families_per_step", {}).get(kernel)
         if fam is not None:
             return int(fam["traffic_bytes_per_step"])
+        one = rec.get("single_kernels", {}).get(kernel)
+        if one is not None:
+            return int(one["traffic_bytes_per_launch"])
         for name, v in rec.get("kernels", {}).items():
             if kernel in name:
                 return int(v["traffic_bytes_per_launch"])
@@ -174,19 +177,9 @@ def pmc_traffic(kernel, shape: str = ""):
     return None
 
 
-TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager YOLOv5s 640x640 " \
-                 "bs16 train steps of this build, tools/prof_r03.sh; families: bytes per train step, single kernels: bytes per launch; " \
-                 "null = no entry for this workload)"
-
-
-def pmc_traffic_r02(kernel, shape: str):
-    """Round-2 counter run (profiles/r02_pmc_traffic.json), for the kernels that have not changed since: bytes per launch
-    when it was taken on exactly `shape`."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[kernel]
-        return rec["traffic_bytes"] if rec.get("shape") == shape else None
-    except Exception:
-        return None
+TRAFFIC_SOURCE = "profiles/r04_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build: eager " \
+                 "YOLOv5s 640x640 bs16 train steps (tools/prof_r04.sh: families = bytes per train step, step kernels = bytes per launch) " \
+                 "and the single-kernel probe at the micro leg's shapes (tools/pmc_traffic_r04.sh); null = no entry for this workload)"
 
 
 def usable_cores() -> int:
@@ -341,11 +334,13 @@ def micro_kernels(device):
         ops.disable_timing()
         return ts[len(ts) // 2]
 
-    def add(name, ms, nbytes, shape, bound="hbm"):
+    def add(name, ms, nbytes, shape, bound="hbm", tkey=None):
         print(f"[bench micro] {name} {shape}: {ms:.4f} ms", file=sys.stderr, flush=True)
         gbs = nbytes / ms / 1e6
         res.append({"kernel": name, "shape": shape, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 2),
                     "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / HBM_PEAK_GBS, 4), "bound": bound})
+        if tkey is not None:   # HBM bytes per launch from this round's counter run on exactly this shape (pmc_traffic)
+            res[-1]["traffic"] = pmc_traffic(tkey)
 
     g = syn.make_generator(7)
     # config 5: 1280^2 A=3 anchors x ~500 gt, materialised + fused (B=2 keeps the output at 1.6 GB)
@@ -354,7 +349,7 @@ def micro_kernels(device):
     b = torch.stack([syn.random_boxes(M, 1280.0, g, 4.0, 64.0) for _ in range(B)]).to(device)
     out_holder = {}
     ms = ktime("pairwise_iou", lambda: out_holder.__setitem__("o", ops.pairwise_iou(a, b)))
-    add("pairwise_iou_cols_kernel", ms, B * (16 * (N + M) + 4 * N * M), f"B={B} N={N} M={M}")
+    add("pairwise_iou_cols_kernel", ms, B * (16 * (N + M) + 4 * N * M), f"B={B} N={N} M={M}", tkey="pairwise_iou_cols_kernel")
     out_holder.clear()
     ms = timeit(lambda: ops.iou_assign(a, b))
     add("iou_assign_kernel(+finalize)", ms, B * (16 * (N + M) + 8 * N), f"B={B} N={N} M={M}", "valu")
@@ -421,7 +416,8 @@ def micro_kernels(device):
             touched = roi_touched_elements(rois, feats, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, 4)
             ms = ktime("roi_align_fwd", lambda: ops.roi_align(feats, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True))
             add(f"roi_align_fwd_cl_kernel<{dn}>", ms, R * 256 * 49 * esz + touched * esz,
-                f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the {touched * esz / 1e6:.0f} MB of feature bytes under the RoIs, once)")
+                f"R={R} C=256 P=7 s=2 {dn} maps -> {dn} out (out bytes + the {touched * esz / 1e6:.0f} MB of feature bytes under the RoIs, once)",
+                tkey=f"roi_align_fwd_cl_kernel<{dn}> R={R}")
             if per_img == 128:
                 fr = [f.detach().requires_grad_(True) for f in feats]
                 out = ops.roi_align(fr, rois, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, True, 2, 224.0, 4, True)
@@ -432,9 +428,9 @@ def micro_kernels(device):
                 torch.cuda.synchronize()
                 tb = sorted(ops.collect_timing()["roi_align_bwd"])
                 ops.disable_timing()
-                add("roi_align_bwd_cl_kernel", tb[len(tb) // 2], R * 256 * 49 * esz + 2 * touched * 4,
-                    f"R={R} C=256 P=7 s=2 grad {dn} -> f32 maps (kernel only; float atomics; bytes = grad in + touched f32 cells read-modify-write)",
-                    "atomic")
+                add("roi_align_bwd_gather_kernel", tb[len(tb) // 2], R * 256 * 49 * esz + map_bytes,
+                    f"R={R} C=256 P=7 s=2 grad {dn} -> {dn} maps (kernel only; no atomics: bytes = grad in + every map cell written once)",
+                    tkey=f"roi_align_bwd_gather_kernel<{dn}>")
                 del fr, out, go
         del feats
     # RPN proposals, config 3: 832^2, 5 levels x 3 anchors, pre 2000 / post 1000
@@ -677,18 +673,22 @@ def roi_align_roofline(model, batch, args, device):
     esz = fs[0].element_size()
     touched = roi_touched_elements(rois5, fs, rh.scales, rh.k_min, len(fs))
     f_bytes = R * Cc * rh.P * rh.P * esz + touched * esz
-    b_bytes = R * Cc * rh.P * rh.P * esz + 2 * touched * 4
+    # backward = the gather (csrc/roi_align.hip): the incoming gradient once + every cell of the gradient maps WRITTEN once in
+    # the features' dtype (no float32 accumulators, no zero-fill, no cast)
+    map_elems = int(sum(f.numel() for f in fs))
+    b_bytes = R * Cc * rh.P * rh.P * esz + map_elems * esz
     shape = f"R={R} C={Cc} P={rh.P} s={rh.sr} {args.size} bs{args.batch} {str(fs[0].dtype).replace('torch.', '')}"
-    main = _hbm_entry("roi_align_fwd_cl_kernel + roi_align_bwd_cl_kernel (hd_roi_align_fwd / _bwd), one launch each per step",
+    main = _hbm_entry("roi_align_fwd_cl_kernel + roi_align_bwd_gather_kernel (hd_roi_align_fwd / hd_roi_align_bwd_gather), one launch each per step",
                       f_ms + b_ms, f_bytes + b_bytes, 2,
                       {"shape": shape, "touched_feature_elements": int(touched), "pyramid_elements": int(sum(f.numel() for f in fs)),
                        "timed": "every launch stamps its own HIP event pair (kernel begin / end) on the step's own pyramid and sampled RoIs",
                        "per_kernel": {"roi_align_fwd_cl_kernel": {"ms": round(f_ms, 4), "GB/s": round(f_bytes / f_ms / 1e6, 1),
                                                                   "frac": round(f_bytes / f_ms / 1e6 / HBM_PEAK_GBS, 4)},
-                                      "roi_align_bwd_cl_kernel": {"ms": round(b_ms, 4), "GB/s": round(b_bytes / b_ms / 1e6, 1),
-                                                                  "frac": round(b_bytes / b_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                                                  "bound": "float-atomic rate (~1.3 TB/s of added bytes chip-wide)"}}},
-                      traffic=pmc_traffic_r02("roi_align_step", shape))
+                                      "roi_align_bwd_gather_kernel": {"ms": round(b_ms, 4), "GB/s": round(b_bytes / b_ms / 1e6, 1),
+                                                                      "frac": round(b_bytes / b_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                                      "bound": "hbm write (every map cell once) + per-RoI tile work",
+                                                                      "algorithmic_bytes": int(b_bytes)}}},
+                      traffic=None)   # the counter run prices the two kernels on the micro leg's random RoIs (`kernels`), not these
     return main
 
 
@@ -922,9 +922,8 @@ def main():
                         out.setdefault("roofline_secondary", []).append(
                             {"kernel": k["kernel"], "bound": "hbm", "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": k["frac_of_8TB/s"], "shape": k["shape"], "avg_launch_ms": k["ms"],
-                             "algorithmic_bytes_per_launch": int(k["algorithmic_MB"] * 1e6), "traffic":
-                                 pmc_traffic_r02("pairwise_iou_cols_kernel", k["shape"]),
-                             "traffic_source": "profiles/r02_pmc_traffic.json (the kernel is unchanged since that counter run)"})
+                             "algorithmic_bytes_per_launch": int(k["algorithmic_MB"] * 1e6),
+                             "traffic": pmc_traffic("pairwise_iou_cols_kernel"), "traffic_source": TRAFFIC_SOURCE})
             except Exception as e:  # the headline number must survive a micro-leg problem
                 out["kernels_error"] = repr(e)
         # Companion legs (N = 1, default workload only): short runs under the same timing contract, reported inside this line,
