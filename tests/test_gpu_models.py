@@ -436,7 +436,11 @@ def test_one_graph_replayed_optimizer_step_tracks_the_eager_step_fp32(gpu):
     num = sum(float((((a - ba) - (b - bb)).double() ** 2).sum()) for a, ba, b, bb in zip(pg, bg, pe, be))
     den = sum(float(((b - bb).double() ** 2).sum()) for b, bb in zip(pe, be))
     # the replayed UPDATE is the eager update: AdamW normalises every gradient to ~ +-lr, so the parameters whose gradient is
-    # at the float-atomic noise level (2e-5 of the norm) may flip — measured 0.034; a wrong or missing replay gives ~1.4
+    # at the float-atomic noise level may flip — measured 0.034 (round 3; the bound below was set after that run); a wrong or
+    # missing replay gives ~1.4.  Round 4 measured the cause: at random init this network amplifies summation-order differences
+    # so strongly that two FLOAT32 runs of one step differ by 0.27 in their gradients at 640^2 (profiles/r04_grad_fidelity.md),
+    # so an optimizer step from random init cannot be compared sharply; the sharp checks are tests/test_gpu_grad_fidelity.py
+    # (per layer, identical inputs) and the per-bucket check of tests/test_gpu_dist_graph.py (pre-trained weights).
     assert den > 0 and (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
     pn = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(pg, pe))
     pd = sum(float((b.double() ** 2).sum()) for b in pe)
