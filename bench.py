@@ -31,7 +31,8 @@ Extra objects in that line:
                 does (HD_DIRECT_GRADS=0): the per-rank program a scaling efficiency should be quoted against.
   fp32, size_832, frcnn_832, frcnn_1280_visdrone   companion legs under the same timing contract (north_star names 640^2 and
                 832^2; BASELINE.json configs 3 and 5), each with its own dominant-family roofline; skipped, and marked so, once
-                the run has used its wall-clock budget (--leg-budget seconds).
+                the run has used its wall-clock budget (--leg-budget seconds, default 240: the whole default run then ends within
+                about five minutes even on a box that has to search every library solver anew).
 """
 from __future__ import annotations
 
@@ -81,7 +82,7 @@ def parse():
                                                        "(name, shape, us, GB/s, TFLOP/s) of the roofline passes to this file")
     ap.add_argument("--no-legs", action="store_true", help="skip the fp32 and 832x832 companion legs of the default run")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each companion leg (after 5 warm-up steps)")
-    ap.add_argument("--leg-budget", type=float, default=420.0,
+    ap.add_argument("--leg-budget", type=float, default=240.0,
                     help="seconds since start after which no further companion leg is started (they are marked skipped)")
     ap.add_argument("--style", choices=("coco", "visdrone"), default="coco", help="synthetic ground truth (SURVEY.md section 8d)")
     ap.add_argument("--no-miopen-find", action="store_true",
@@ -841,7 +842,7 @@ def main():
         shipped_find_db = tuning.use_shipped_find_db()
         log(f"MIOpen user find-db: {'shipped (heltondetection_amd/miopen_db)' if shipped_find_db else os.environ.get('MIOPEN_USER_DB_PATH', 'default')}")
 
-    if args.model == "frcnn" and not args.no_miopen_find and rank == 0:
+    if (args.model == "frcnn" or not args.no_legs) and not args.no_miopen_find and rank == 0:
         # MIOpen's solver search for ResNet50 at 832^2 is one long call inside the first step (minutes on a fresh
         # box): a heartbeat keeps the run visibly alive
         import threading
