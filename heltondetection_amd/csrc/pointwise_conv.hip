@@ -25,6 +25,7 @@
 #include <hip/hip_bf16.h>
 
 #include "hd_bn_fuse.h"
+#include <cstdlib>
 #include <type_traits>
 
 #include "hd_common.h"
@@ -866,37 +867,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hdfuse::ReduceJ
 // the dY row; the nine taps are nine (row slot, pixel shift) views of that ring, so borders need no masks — out-of-image
 // rows are stored as zeros, out-of-image pixels are the halo.  Per 16 pixels a wave issues one dY fragment, nine X
 // fragments and nine MFMAs.  The next X row and dY row travel in registers while the current row is multiplied.
-template <int W>
-__global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
-                                                            const unsigned short* __restrict__ X, long long ld_x, int B, int H,
-                                                            int N, int K, int rows_per_slice, int images_per_slice,
-                                                            float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
+// PAIR: a 512-thread workgroup whose two halves (waves 0-3, 4-7) are two workgroups of the plain form on two CONSECUTIVE row
+// slices, each with its own LDS ring, sharing the barriers (so both run the same padded number of iterations); at the end the
+// upper half's 9 x 16 accumulators are added to the lower half's through LDS (three passes of three taps) and ONE partial is
+// written: the slab — 37.7 MB written and read back per layer at 256 slices x tiles, the largest weight-gradient slab of
+// the step (profiles/r04_pmc_traffic.json) — halves at unchanged parallelism (8 waves per CU either way).
+template <int W, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(
+    const unsigned short* __restrict__ dY, long long ld_dy, const unsigned short* __restrict__ X, long long ld_x, int B, int H,
+    int N, int K, int rows_per_slice, int images_per_slice, float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
   __shared__ float4 s_part[16][17];
   constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
   constexpr int SX = 64 * 2 + 64;                 // bytes per pixel row of a 64-channel tile, padded
   constexpr int XROW = (WP + 2) * SX, DYROW = WP * SX;
+  constexpr int RING = 3 * XROW + DYROW;
   constexpr int CH = W * 8;                       // 16-byte chunks per image row of a 64-channel tile
   constexpr int IT = (CH + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 X rows | dY row]
-  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
-    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per half: [3 X rows | dY row]; later the fold area
+  const int n_groups = PAIR ? (n_slices + 1) / 2 : n_slices;            // slab partials = grid rows that multiply
+  if ((int)blockIdx.y >= n_groups) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    if (PAIR && threadIdx.x >= 256) return;
+    const long long blk = (long long)(blockIdx.y - n_groups) * gridDim.x + blockIdx.x;
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  unsigned char* xs = smem;
-  unsigned char* ys = smem + 3 * XROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = PAIR ? (int)(threadIdx.x >> 8) : 0;
+  unsigned char* xs = smem + half * RING;
+  unsigned char* ys = xs + 3 * XROW;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = K / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   // a slice is a range of image rows of one image (rows_per_slice < H), or images_per_slice whole images
+  const int slice = PAIR ? (int)blockIdx.y * 2 + half : (int)blockIdx.y;
+  const bool live_slice = slice < n_slices;       // an odd slice count leaves the last upper half without work
   const int spi = (H + rows_per_slice - 1) / rows_per_slice;  // slices per image (1 when a slice holds whole images)
-  const int b_first = spi > 1 ? blockIdx.y / spi : blockIdx.y * images_per_slice;
-  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
-  const int h0 = spi > 1 ? (blockIdx.y % spi) * rows_per_slice : 0;
+  const int b_first = spi > 1 ? slice / spi : slice * images_per_slice;
+  const int b_last = !live_slice ? b_first : (spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice));
+  const int h0 = spi > 1 ? (slice % spi) * rows_per_slice : 0;
   const int h1 = min(H, h0 + rows_per_slice);
+  // both halves run the same number of (image, row) iterations: the barriers are the workgroup's
+  const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
-  for (int i = tid; i < (3 * XROW + DYROW) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -943,9 +956,11 @@ __global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(co
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   u32x4 rx[IT], ry[IT];
-  for (b = b_first; b < b_last; ++b) {
-  if (h0 < h1) {
-    if (b > b_first) __syncthreads();  // the previous image's last row has been read
+  for (int bb = 0; bb < img_iters; ++bb) {
+  b = b_first + bb;
+  const bool live_img = b < b_last && h0 < h1;
+  if (bb > 0) __syncthreads();  // the previous image's last row has been read
+  if (live_img) {
     load_x(h0 - 1, rx); stash_x(h0 - 1, rx);
     load_x(h0, rx);     stash_x(h0, rx);
     load_x(h0 + 1, rx); stash_x(h0 + 1, rx);
@@ -953,23 +968,27 @@ __global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(co
     load_x(h0 + 2, rx);
     load_y(h0 + 1, ry);
   }
-  for (int h = h0; h < h1; ++h) {
+  for (int hh = 0; hh < row_iters; ++hh) {
+    const int h = h0 + hh;
+    const bool live = live_img && h < h1;   // uniform over the half: the padded iterations only keep the barrier count
     __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const unsigned char* slot = xs + ((h + ky - 1 + 3) % 3) * XROW;
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* slot = xs + ((h + ky - 1 + 3) % 3) * XROW;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const bf16x8 bq = tr_fragment(slot, SX, wk * 32, ks * 16 + kx, lane);
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+          for (int kx = 0; kx < 3; ++kx) {
+            const bf16x8 bq = tr_fragment(slot, SX, wk * 32, ks * 16 + kx, lane);
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+          }
         }
       }
     }
     __syncthreads();
-    if (h + 1 < h1) {
+    if (live && h + 1 < h1) {
       stash_x(h + 2, rx);  // into the slot row h - 1 just left
       stash_y(ry);
       load_x(h + 3, rx);
@@ -978,7 +997,28 @@ __global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(co
   }
   }
 
-  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice][n][tap][k]
+  if (PAIR) {  // upper half -> LDS -> lower half, three taps at a time (4 waves x 3 x 16 registers x 256 B = 48 KB)
+    float* fold = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * 16 * 64;
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) {
+      __syncthreads();   // the rings (first pass) / the previous pass's reads are done
+      if (half == 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fold[(t * 16 + r) * 64 + lane] = acc[p3 * 3 + t][r];
+      }
+      __syncthreads();
+      if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p3 * 3 + t][r] += fold[(t * 16 + r) * 64 + lane];
+      }
+    }
+    if (half == 1) return;
+  }
+  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice group][n][tap][k]
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
   const int k = k0 + wk * 32 + (lane & 31);
   const int nb = n0 + wn * 32 + 4 * (lane >> 5);
@@ -992,37 +1032,43 @@ __global__ __launch_bounds__(256, (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(co
 // row is stored de-interleaved — even pixels E[j] = x[2 j] and odd pixels O[j] = x[2 j + 1], each with the one-pixel zero
 // halo — so the three column taps are again contiguous views: kx = 0 -> O[wo - 1], kx = 1 -> E[wo], kx = 2 -> O[wo].  The
 // ring holds input rows 2 ho - 1, 2 ho, 2 ho + 1; advancing one output row brings in two input rows.  H, W: OUTPUT size.
-template <int W>
-__global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(const unsigned short* __restrict__ dY, long long ld_dy,
-                                                              const unsigned short* __restrict__ X, long long ld_x, int B, int H,
-                                                              int N, int K, int rows_per_slice, int images_per_slice,
-                                                              float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
+template <int W, bool PAIR>   // PAIR: as for conv3x3_wgrad_kernel
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(
+    const unsigned short* __restrict__ dY, long long ld_dy, const unsigned short* __restrict__ X, long long ld_x, int B, int H,
+    int N, int K, int rows_per_slice, int images_per_slice, float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
   __shared__ float4 s_part[16][17];
   constexpr int WP = (W + 15) / 16 * 16, KS = WP / 16;
   constexpr int SX = 64 * 2 + 64;
   constexpr int PLANE = (WP + 2) * SX, XROW = 2 * PLANE, DYROW = WP * SX;
+  constexpr int RING = 3 * XROW + DYROW;
   constexpr int CHX = 2 * W * 8, CHY = W * 8;  // 16-byte chunks per input row / per dY row of a 64-channel tile
   constexpr int ITX = (CHX + 255) / 256, ITY = (CHY + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 input rows (E | O planes) | dY row]
-  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
-    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per half: [3 input rows (E | O planes) | dY row]
+  const int n_groups = PAIR ? (n_slices + 1) / 2 : n_slices;
+  if ((int)blockIdx.y >= n_groups) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    if (PAIR && threadIdx.x >= 256) return;
+    const long long blk = (long long)(blockIdx.y - n_groups) * gridDim.x + blockIdx.x;
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  unsigned char* xs = smem;
-  unsigned char* ys = smem + 3 * XROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = PAIR ? (int)(threadIdx.x >> 8) : 0;
+  unsigned char* xs = smem + half * RING;
+  unsigned char* ys = xs + 3 * XROW;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = K / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   const int Hi = 2 * H, Wi = 2 * W;
+  const int slice = PAIR ? (int)blockIdx.y * 2 + half : (int)blockIdx.y;
+  const bool live_slice = slice < n_slices;
   const int spi = (H + rows_per_slice - 1) / rows_per_slice;
-  const int b_first = spi > 1 ? blockIdx.y / spi : blockIdx.y * images_per_slice;
-  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
-  const int h0 = spi > 1 ? (blockIdx.y % spi) * rows_per_slice : 0;
+  const int b_first = spi > 1 ? slice / spi : slice * images_per_slice;
+  const int b_last = !live_slice ? b_first : (spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice));
+  const int h0 = spi > 1 ? (slice % spi) * rows_per_slice : 0;
   const int h1 = min(H, h0 + rows_per_slice);
+  const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
-  for (int i = tid; i < (3 * XROW + DYROW) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -1072,9 +1118,11 @@ __global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   u32x4 ra[ITX], rb[ITX], ry[ITY];
-  for (b = b_first; b < b_last; ++b) {
-    if (h0 < h1) {
-      if (b > b_first) __syncthreads();
+  for (int bb = 0; bb < img_iters; ++bb) {
+    b = b_first + bb;
+    const bool live_img = b < b_last && h0 < h1;
+    if (bb > 0) __syncthreads();
+    if (live_img) {
       load_x(2 * h0 - 1, ra); stash_x(2 * h0 - 1, ra);
       load_x(2 * h0, ra);     stash_x(2 * h0, ra);
       load_x(2 * h0 + 1, ra); stash_x(2 * h0 + 1, ra);
@@ -1083,24 +1131,28 @@ __global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(
       load_x(2 * h0 + 3, rb);
       load_y(h0 + 1, ry);
     }
-    for (int h = h0; h < h1; ++h) {
+    for (int hh = 0; hh < row_iters; ++hh) {
+      const int h = h0 + hh;
+      const bool live = live_img && h < h1;   // uniform over the half
       __syncthreads();
+      if (live) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const unsigned char* slot = xs + ((2 * h + ky - 1 + 3) % 3) * XROW;
+          for (int ky = 0; ky < 3; ++ky) {
+            const unsigned char* slot = xs + ((2 * h + ky - 1 + 3) % 3) * XROW;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            // kx = 0: O[wo - 1] (pixel row wo), kx = 1: E[wo] (pixel row wo + 1), kx = 2: O[wo] (pixel row wo + 1)
-            const bf16x8 bq = tr_fragment(slot + (kx == 1 ? 0 : PLANE), SX, wk * 32, ks * 16 + (kx == 0 ? 0 : 1), lane);
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+            for (int kx = 0; kx < 3; ++kx) {
+              // kx = 0: O[wo - 1] (pixel row wo), kx = 1: E[wo] (pixel row wo + 1), kx = 2: O[wo] (pixel row wo + 1)
+              const bf16x8 bq = tr_fragment(slot + (kx == 1 ? 0 : PLANE), SX, wk * 32, ks * 16 + (kx == 0 ? 0 : 1), lane);
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
+            }
           }
         }
       }
       __syncthreads();
-      if (h + 1 < h1) {
+      if (live && h + 1 < h1) {
         stash_x(2 * h + 2, ra);  // into the slots input rows 2 h - 1 and 2 h just left
         stash_x(2 * h + 3, rb);
         stash_y(ry);
@@ -1111,6 +1163,27 @@ __global__ __launch_bounds__(256, (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(
     }
   }
 
+  if (PAIR) {  // upper half -> LDS -> lower half, three taps at a time
+    float* fold = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * 16 * 64;
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) {
+      __syncthreads();
+      if (half == 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fold[(t * 16 + r) * 64 + lane] = acc[p3 * 3 + t][r];
+      }
+      __syncthreads();
+      if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p3 * 3 + t][r] += fold[(t * 16 + r) * 64 + lane];
+      }
+    }
+    if (half == 1) return;
+  }
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
   const int k = k0 + wk * 32 + (lane & 31);
   const int nb = n0 + wn * 32 + 4 * (lane >> 5);
@@ -1310,8 +1383,16 @@ static inline bool conv3x3_width_ok(int W) { return W == 20 || W == 26 || W == 4
 
 struct Wgrad3Plan {
   int tiles, rows_per_slice, images_per_slice, slices;
+  bool pair;     // two consecutive slices per 512-thread workgroup, folded in LDS: the slab holds (slices + 1) / 2 partials
+  int partials;  // slab partials = grid rows that multiply
 };
-inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout) {
+static bool wgrad3_pair_fits(int W, int stride) {   // two rings (+ the static reduce area) within 160 KB of LDS
+  const int WP = (W + 15) / 16 * 16;
+  const size_t ring = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
+  static const bool off = [] { const char* e = getenv("HD_WGRAD3_PAIR"); return e && e[0] == '0'; }();
+  return !off && 2 * ring + 4608 <= 160 * 1024;
+}
+inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout, int W = 0, int stride = 1) {
   // Every workgroup writes a 64 x 9 x 64 float32 partial (147 KB) that the reduce kernel reads back, so the slab traffic
   // grows with the workgroup count while the operands do not (75 MB for the 128-channel 40 x 40 layer at 512 workgroups
   // against 13 MB of operands): the partial kernel is bound by that write.  Measured per launch in the step, W = 40 / 80 / 20
@@ -1333,6 +1414,8 @@ inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout) {
     p.images_per_slice = (B + want - 1) / want;
     p.slices = (B + p.images_per_slice - 1) / p.images_per_slice;
   }
+  p.pair = W > 0 && p.slices >= 2 && wgrad3_pair_fits(W, stride);
+  p.partials = p.pair ? (p.slices + 1) / 2 : p.slices;
   return p;
 }
 
@@ -1621,7 +1704,7 @@ extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout
 
 extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride) {
   if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return 0;
-  return (size_t)wgrad3_plan(B, H, Cin, Cout).slices * Cout * 9 * Cin * sizeof(float);
+  return (size_t)wgrad3_plan(B, H, Cin, Cout, W, stride).partials * Cout * 9 * Cin * sizeof(float);
 }
 
 extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B,
@@ -1634,8 +1717,8 @@ extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_str
   if (x_row_stride == 0) x_row_stride = Cin;
   if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
   if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
-  const Wgrad3Plan p = wgrad3_plan(B, H, Cin, Cout);
-  if (workspace_bytes < (size_t)p.slices * Cout * 9 * Cin * sizeof(float)) return HD_ERR_WORKSPACE;
+  const Wgrad3Plan p = wgrad3_plan(B, H, Cin, Cout, W, stride);
+  if (workspace_bytes < (size_t)p.partials * Cout * 9 * Cin * sizeof(float)) return HD_ERR_WORKSPACE;
   hdfuse::ReduceJob jv;
   const hd_status js = make_job_view(piggyback, &jv);
   if (js != HD_OK) return js;
@@ -1643,31 +1726,37 @@ extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_str
   const auto* a = static_cast<const unsigned short*>(dy);
   const auto* b = static_cast<const unsigned short*>(x);
   float* slab = static_cast<float*>(workspace);
-  const dim3 grid((unsigned)p.tiles, (unsigned)p.slices + piggyback_rows(jv, (unsigned)p.tiles));
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.partials + piggyback_rows(jv, (unsigned)p.tiles));
   const int WP = (W + 15) / 16 * 16;
-  const size_t lds = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
-#define HD_WGRAD3_CASE(WW)                                                                                              \
+  const size_t ring = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
+  const size_t lds = p.pair ? (2 * ring > 49152 ? 2 * ring : 49152) : ring;
+  const dim3 block(p.pair ? 512 : 256);
+  // HD_WG3(WW, S2, PR): one instantiation; the pair form only where two rings fit (wgrad3_pair_fits)
+#define HD_WG3(WW, KERNEL, PR)                                                                                          \
+  (void)hd_launch(KERNEL<WW, PR>, grid, block, lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, p.rows_per_slice, \
+                  p.images_per_slice, slab, p.slices, jv)
+#define HD_WGRAD3_CASE(WW, S1PAIR, S2PAIR)                                                                              \
   case WW:                                                                                                              \
-    if (stride == 2)                                                                                                    \
-      (void)hd_launch(conv3x3s2_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, \
-                      p.rows_per_slice, p.images_per_slice, slab, p.slices, jv);                                       \
-    else                                                                                                                \
-      (void)hd_launch(conv3x3_wgrad_kernel<WW>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin,   \
-                      p.rows_per_slice, p.images_per_slice, slab, p.slices, jv);                                       \
+    if (stride == 2) {                                                                                                  \
+      if (S2PAIR && p.pair) HD_WG3(WW, conv3x3s2_wgrad_kernel, S2PAIR); else HD_WG3(WW, conv3x3s2_wgrad_kernel, false);      \
+    } else {                                                                                                            \
+      if (S1PAIR && p.pair) HD_WG3(WW, conv3x3_wgrad_kernel, S1PAIR); else HD_WG3(WW, conv3x3_wgrad_kernel, false);          \
+    }                                                                                                                   \
     break;
   switch (W) {
-    HD_WGRAD3_CASE(20)
-    HD_WGRAD3_CASE(26)
-    HD_WGRAD3_CASE(40)
-    HD_WGRAD3_CASE(52)
-    HD_WGRAD3_CASE(80)
-    HD_WGRAD3_CASE(104)
+    HD_WGRAD3_CASE(20, true, true)
+    HD_WGRAD3_CASE(26, true, true)
+    HD_WGRAD3_CASE(40, true, true)
+    HD_WGRAD3_CASE(52, true, false)
+    HD_WGRAD3_CASE(80, true, false)
+    HD_WGRAD3_CASE(104, false, false)
     default: return HD_ERR_SHAPE;
   }
 #undef HD_WGRAD3_CASE
+#undef HD_WG3
   HD_RETURN_IF_LAUNCH_FAILED();
   job_out->slab = slab;
-  job_out->slices = p.slices;
+  job_out->slices = p.partials;
   job_out->count = (int64_t)Cout * 9 * Cin;
   job_out->dw = dw;
   return HD_OK;
