@@ -136,6 +136,12 @@ SIGNATURES = {
     "hd_pointwise_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
     "hd_pointwise_bwd_tune": (None, [_I]),
     "hd_pointwise_bwd": (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _L, _P, _L, _P, _P, _Z, _P, _P, _P]),
+    "hd_head_conv_pitch": (_I, [_I]),
+    "hd_head_conv_fwd_supported": (_I, [_L, _I, _I]),
+    "hd_head_conv_fwd": (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "hd_head_conv_bwd_supported": (_I, [_L, _I, _I]),
+    "hd_head_conv_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
+    "hd_head_conv_bwd": (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _L, _P, _P, _Z, _P, _P, _P]),
     "hd_stem_conv_supported": (_I, [_I, _I, _I, _I, _I]),
     "hd_stem_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "hd_stem_conv_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P]),

@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256, (KR <= 64 ? 2 : 1)) void pointwise_bwd_kernel(
                                                             const unsigned short* __restrict__ X, long long ld_x,
                                                             unsigned short* __restrict__ dX, long long ld_dx, int M, int N,
                                                             const unsigned short* __restrict__ radd, long long ld_r,
-                                                            float* __restrict__ slab, int G, const hdfuse::ReduceJob job) {
+                                                            float* __restrict__ slab, int G, const hdfuse::ReduceJob job,
+                                                            int kr_real) {
+  // kr_real <= KR: the weight has only kr_real rows (output channels); the rest of the reduction is padding — dY's columns
+  // past kr_real must be ZERO (hd_head_conv_bwd: the 255 -> 256 Detect convolution), the slab rows read as zeros and the
+  // partials of dW keep kr_real rows per slice
   using L = BwdLds<KR, TN, TM>;
   constexpr int BN = TN * 32, KS = KR / 16, CPR = KR / 8, NTL = KR / 32;
   constexpr int NLD = TM * KS;           // 16-byte dY loads per lane per row block
@@ -174,7 +178,9 @@ __global__ __launch_bounds__(256, (KR <= 64 ? 2 : 1)) void pointwise_bwd_kernel(
 #pragma unroll
     for (int p = 0; p < WIT; ++p) {
       const int id = p * 256 + tid;
-      if (NCH % 256 == 0 || id < NCH) wreg[p] = *reinterpret_cast<const u32x4*>(Wt + (long long)(id / XCPR) * N + n0 + (id % XCPR) * 8);
+      wreg[p] = u32x4{0u, 0u, 0u, 0u};
+      if ((NCH % 256 == 0 || id < NCH) && id / XCPR < kr_real)
+        wreg[p] = *reinterpret_cast<const u32x4*>(Wt + (long long)(id / XCPR) * N + n0 + (id % XCPR) * 8);
     }
 #pragma unroll
     for (int p = 0; p < WIT; ++p) {
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(256, (KR <= 64 ? 2 : 1)) void pointwise_bwd_kernel(
       for (int r = 0; r < 16; ++r) fold[((n * TN + j) * 16 + r) * 64 + lane] = wacc[n][j][r];
   __syncthreads();
   const float* f0 = reinterpret_cast<const float*>(smem);
-  float* out = slab + (size_t)slice * KR * N;
-  for (int e = tid; e < KR * BN / 4; e += 256) {
+  float* out = slab + (size_t)slice * kr_real * N;
+  for (int e = tid; e < kr_real * (BN / 4); e += 256) {
     const int row = e / (BN / 4), c = (e % (BN / 4)) * 4;        // dW row (output channel), first of 4 columns of the tile
     const int n = row >> 5, rr = row & 31;
     const int r = (rr & 3) + 4 * (rr >> 3), h = (rr >> 2) & 1;   // C/D map inverted: row = (r & 3) + 8 (r >> 2) + 4 h
@@ -406,12 +412,13 @@ extern "C" size_t hd_pointwise_bwd_workspace_bytes(int64_t R, int Cin, int Cout)
   return (size_t)p.slices * Cin * Cout * sizeof(float);
 }
 
-extern "C" hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride,
-                                      int64_t R, int Cin, int Cout, const void* add, int64_t add_row_stride, void* dx,
-                                      int64_t dx_row_stride, void* dw, void* workspace, size_t workspace_bytes,
-                                      const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream) {
+// Cout: the reduction the kernel runs (32 / 64 / 128 / 256); cout_real <= Cout: the rows the weight and its gradient have
+static hd_status bwd_launch(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride,
+                            int64_t R, int Cin, int Cout, int cout_real, const void* add, int64_t add_row_stride, void* dx,
+                            int64_t dx_row_stride, void* dw, void* workspace, size_t workspace_bytes,
+                            const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream) {
   if (!dy || !w || !x || !dx || !dw || !workspace || !job_out) return HD_ERR_NULL;
-  if (!bwd_shape_ok(R, Cin, Cout)) return HD_ERR_SHAPE;
+  if (!bwd_shape_ok(R, Cin, Cout) || cout_real < 1 || cout_real > Cout) return HD_ERR_SHAPE;
   if (dy_row_stride == 0) dy_row_stride = Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
   if (dx_row_stride == 0) dx_row_stride = Cin;
@@ -453,10 +460,11 @@ extern "C" hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, con
     const size_t lds = BwdLds<KRR, TNN, TMM>::TOTAL;                                                                          \
     if (add)                                                                                                                  \
       (void)hd_launch(pointwise_bwd_kernel<KRR, TNN, TMM, true>, grid, dim3(256), lds, s, a, (long long)dy_row_stride, b, c,  \
-                      (long long)x_row_stride, o, (long long)dx_row_stride, M, Cin, r, (long long)add_row_stride, slab, p.grid, jv); \
+                      (long long)x_row_stride, o, (long long)dx_row_stride, M, Cin, r, (long long)add_row_stride, slab, p.grid, jv, \
+                      cout_real);                                                                                              \
     else                                                                                                                      \
       (void)hd_launch(pointwise_bwd_kernel<KRR, TNN, TMM, false>, grid, dim3(256), lds, s, a, (long long)dy_row_stride, b, c, \
-                      (long long)x_row_stride, o, (long long)dx_row_stride, M, Cin, r, 0ll, slab, p.grid, jv);                \
+                      (long long)x_row_stride, o, (long long)dx_row_stride, M, Cin, r, 0ll, slab, p.grid, jv, cout_real);     \
   } while (0)
   if (Cout == 256) HD_BWD_LAUNCH(256, 1, 1);
   else if (Cout == 128) { if (p.tn == 2) HD_BWD_LAUNCH(128, 2, 1); else HD_BWD_LAUNCH(128, 1, 1); }
@@ -466,7 +474,46 @@ extern "C" hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, con
   HD_RETURN_IF_LAUNCH_FAILED();
   job_out->slab = slab;
   job_out->slices = p.slices;
-  job_out->count = (int64_t)Cin * Cout;
+  job_out->count = (int64_t)Cin * cout_real;
   job_out->dw = dw;
   return HD_OK;
+}
+
+extern "C" hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride,
+                                      int64_t R, int Cin, int Cout, const void* add, int64_t add_row_stride, void* dx,
+                                      int64_t dx_row_stride, void* dw, void* workspace, size_t workspace_bytes,
+                                      const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream) {
+  return bwd_launch(dy, dy_row_stride, w, x, x_row_stride, R, Cin, Cout, Cout, add, add_row_stride, dx, dx_row_stride, dw, workspace,
+                    workspace_bytes, piggyback, job_out, stream);
+}
+
+// ---- the Detect convolution's backward: Cout = na (5 + nc) is not a tile multiple (255 for 80 classes) ------------------------
+// dY arrives as rows of `hd_head_conv_pitch(Cout)` bf16 columns whose padding columns are ZERO (the loss kernels write the
+// padded gradient, ops.head_conv casts it); the kernel runs the padded reduction against weight rows that read as zeros past
+// Cout, and the weight gradient keeps Cout rows.
+extern "C" int hd_head_conv_pitch(int Cout) {
+  for (int p = 32; p <= 256; p <<= 1)
+    if (Cout <= p) return p;
+  return 0;
+}
+
+extern "C" int hd_head_conv_bwd_supported(int64_t R, int Cin, int Cout) {
+  const int p = Cout >= 1 ? hd_head_conv_pitch(Cout) : 0;
+  return p && bwd_shape_ok(R, Cin, p) ? 1 : 0;
+}
+
+extern "C" size_t hd_head_conv_bwd_workspace_bytes(int64_t R, int Cin, int Cout) {
+  const int p = Cout >= 1 ? hd_head_conv_pitch(Cout) : 0;
+  return p ? hd_pointwise_bwd_workspace_bytes(R, Cin, p) : 0;
+}
+
+extern "C" hd_status hd_head_conv_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride,
+                                      int64_t R, int Cin, int Cout, void* dx, int64_t dx_row_stride, void* dw, void* workspace,
+                                      size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
+                                      hd_stream stream) {
+  const int p = Cout >= 1 ? hd_head_conv_pitch(Cout) : 0;
+  if (!p) return HD_ERR_SHAPE;
+  if (dy_row_stride == 0) dy_row_stride = p;
+  return bwd_launch(dy, dy_row_stride, w, x, x_row_stride, R, Cin, p, Cout, nullptr, 0, dx, dx_row_stride, dw, workspace,
+                    workspace_bytes, piggyback, job_out, stream);
 }

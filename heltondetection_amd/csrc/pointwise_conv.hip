@@ -252,12 +252,18 @@ struct StreamLds {
 // lookahead with the loads issued behind the previous block's stores, every memory instruction of the steady-state loop
 // unconditional, operand fragments requested two k-steps ahead.  The short form (DEEP = false) is the round-2 kernel: on the
 // 640^2 pyramid a wave owns 1-4 blocks, the steady-state loop never runs and the deeper prologue costs 1-8 us per launch.
-template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false, bool ACC = false, bool DEEP = false>
+// HEAD: the Detect convolution (hd_head_conv_fwd): the weight has n_real <= N rows (the rest of the column range is padding and
+// reads as zeros), `stats` is the float32 bias [n_real], and the result leaves as FLOAT32 rows (Cmat: float*, ldc in floats)
+// = accumulator + bias, unrounded; padding columns are written as zeros.  Reductions
+// longer than the resident slab run as K-slices: ld_r is the weight's row stride (the slice starts at Bw), and with `radd`
+// non-null the launch ADDS its product to what the previous slice left in y (no bias: `stats` null).
+template <int K, int TN, int TM, bool STATS, bool TRB, bool BNB = false, bool ACC = false, bool DEEP = false, bool HEAD = false>
 __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned short* __restrict__ A, long long lda,
                                                                const unsigned short* __restrict__ Bw,
                                                                unsigned short* __restrict__ Cmat, long long ldc, int M, int N,
                                                                float* __restrict__ stats, const hdfuse::BnBwd bn,
-                                                               const unsigned short* __restrict__ radd, long long ld_r) {
+                                                               const unsigned short* __restrict__ radd, long long ld_r,
+                                                               int n_real) {
   using L = StreamLds<K, TN, TM, TRB>;
   constexpr int BN = TN * 32, KS = K / 16, CPR = K / 8;
   constexpr int NLD = TM * KS;  // 16-byte loads per lane per row block: 32 TM rows x CPR chunks over 64 lanes
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
           wreg[p] = *reinterpret_cast<const u32x4*>(Bw + (long long)row * N + n0 + c * 8);
         } else {
           const int row = id / CPR, c = id % CPR;
-          wreg[p] = *reinterpret_cast<const u32x4*>(Bw + (long long)(n0 + row) * K + c * 8);
+          if (HEAD && n0 + row >= n_real) wreg[p] = u32x4{0u, 0u, 0u, 0u};
+          else wreg[p] = *reinterpret_cast<const u32x4*>(Bw + (long long)(n0 + row) * (HEAD ? ld_r : (long long)K) + c * 8);
         }
       }
     }
@@ -330,12 +337,19 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
   }
   __syncthreads();
 
-  unsigned char* area = smem + L::SLAB_BYTES + wave * L::WAVE_BYTES;  // wave-private: row-block stage, then output patch
+  constexpr int HEAD_PATCH = 32 * (BN * 4 + 32);   // HEAD: the patch holds float32 rows
+  constexpr int WAVE_BYTES = (HEAD && HEAD_PATCH > L::WAVE_BYTES) ? HEAD_PATCH : L::WAVE_BYTES;
+  unsigned char* area = smem + L::SLAB_BYTES + wave * WAVE_BYTES;  // wave-private: row-block stage, then output patch
   float s_sum[TN], s_sq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s_sum[j] = s_sq[j] = 0.0f;
   hdfuse::Coef8 cf;
   if (BNB) cf.load(s_bn, K, (lane % CPR) * 8);  // behind the barrier above
+  float hbias[HEAD ? TN : 1];
+  if (HEAD) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) hbias[j] = (stats && n0 + j * 32 + frow < n_real) ? stats[n0 + j * 32 + frow] : 0.0f;
+  }
 
   // One row block.  GUARD: rows past M exist in this block (or it is one of the wave's last blocks): stores and the next
   // loads are conditional.  Without it every memory instruction of the block is issued unconditionally, which is what lets the
@@ -417,6 +431,39 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage reads done before the patch overwrites the area
+    if constexpr (HEAD) {
+      // float32 rows through the wave's patch ([32][BN] floats, rows padded by 32 bytes: the two half-waves' rows, 4 apart, land
+      // 32 banks apart), then 16 bytes per lane along full rows — as the bf16 epilogue below.  (Stored straight from the
+      // accumulator layout, 4 bytes per lane, the 80 x 80 level took 87 us for 130 MB.)
+      constexpr int PR = BN * 4 + 32;
+      float* Cf = reinterpret_cast<float*>(Cmat);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m0 = (rt * TM + i) * 32;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            *reinterpret_cast<float*>(area + row * PR + (j * 32 + frow) * 4) = acc[i][j][r] + hbias[j];
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < BN / 8; ++q) {  // 32 rows x BN/4 chunks of 16 bytes over 64 lanes
+          const int id = q * 64 + lane, row = id / (BN / 4), c = id % (BN / 4);
+          float4 v = *reinterpret_cast<const float4*>(area + row * PR + c * 16);
+          if (!GUARD || m0 + row < M) {
+            float4* dst = reinterpret_cast<float4*>(Cf + (long long)(m0 + row) * ldc + n0 + c * 4);
+            if (radd) {
+              const float4 o = *dst;
+              v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+            }
+            *dst = v;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before it is overwritten
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m0 = (rt * TM + i) * 32;
@@ -458,6 +505,7 @@ __global__ __launch_bounds__(256) void pointwise_stream_kernel(const unsigned sh
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before it is overwritten
+    }
     }
     // D == 2: the loads of row block it + 2 are issued BEHIND this block's stores, so that everything older than the loads a
     // block waits for is a full block old (vmcnt retires in issue order); rows past M are clamped inside load_rows
@@ -528,7 +576,7 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
   if (bn) {
     if constexpr (TRB)
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c,
-                      ldc, M, N, (float*)nullptr, *bn, no_add, 0ll);
+                      ldc, M, N, (float*)nullptr, *bn, no_add, 0ll, 0);
     else
       return HD_ERR_SHAPE;
   } else if (radd) {
@@ -536,27 +584,27 @@ hd_status launch_stream(const void* A, int64_t lda, const void* Bw, void* Cmat, 
       const auto* r = static_cast<const unsigned short*>(radd);
       if (deep)
         (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
-                        a, lda, b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r);
+                        a, lda, b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r, 0);
       else
         (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, true, false, true>, dim3((unsigned)g), dim3(256), lds, s, a, lda,
-                        b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r);
+                        b, c, ldc, M, N, (float*)nullptr, none, r, (long long)ld_r, 0);
     } else {
       return HD_ERR_SHAPE;
     }
   } else if (stats && !TRB) {
     if (deep)
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false, false, false, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
-                      a, lda, b, c, ldc, M, N, stats, none, no_add, 0ll);
+                      a, lda, b, c, ldc, M, N, stats, none, no_add, 0ll, 0);
     else
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, true, false>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                      N, stats, none, no_add, 0ll);
+                      N, stats, none, no_add, 0ll, 0);
   } else {
     if (deep)
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB, false, false, (K >= 128)>, dim3((unsigned)g), dim3(256), lds, s,
-                      a, lda, b, c, ldc, M, N, (float*)nullptr, none, no_add, 0ll);
+                      a, lda, b, c, ldc, M, N, (float*)nullptr, none, no_add, 0ll, 0);
     else
       (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, TRB>, dim3((unsigned)g), dim3(256), lds, s, a, lda, b, c, ldc, M,
-                      N, (float*)nullptr, none, no_add, 0ll);
+                      N, (float*)nullptr, none, no_add, 0ll, 0);
   }
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
@@ -1480,6 +1528,78 @@ extern "C" hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, cons
   if (Cin == 256 && try_stream<256>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
   if (Cin % 64 == 0) return launch_bk<64>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
   return launch_bk<32>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
+}
+
+// ---- the Detect convolution forward: y[R, pitch] (float32) = x[R, Cin] . w[Cout, Cin]^T + bias ------------------------------
+// Cout = na (5 + nc) is no tile multiple (255 for 80 classes): the column range is padded to hd_head_conv_pitch(Cout) and the
+// padding columns are written as zeros, so that the rows stay 16-byte aligned and the loss kernels stream them (yolo.hip).
+template <int K, int TN, int TM>
+static hd_status launch_head(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy, int M,
+                             int Np, int n_real, bool accumulate, hipStream_t s) {
+  constexpr int BN = TN * 32;
+  const int NT = Np / BN;
+  const long long RT = ((long long)M + 32 * TM - 1) / (32 * TM);
+  using SL = StreamLds<K, TN, TM, false>;
+  constexpr int head_patch = 32 * (BN * 4 + 32);  // as in the kernel
+  const size_t lds = SL::SLAB_BYTES + 4 * (size_t)(head_patch > SL::WAVE_BYTES ? head_patch : SL::WAVE_BYTES);
+  const long long cap = lds > 80 * 1024 ? 256 : 512;
+  long long g = (RT + 3) / 4 * NT;
+  long long L = 8;
+  while (L % NT) L += 8;
+  g = (g + L - 1) / L * L;
+  if (g > cap) g = cap / L * L;
+  const auto* a = static_cast<const unsigned short*>(x);
+  const auto* b = static_cast<const unsigned short*>(w);
+  auto* c = static_cast<unsigned short*>(y);
+  const hdfuse::BnBwd none = {};
+  const unsigned short* flag = accumulate ? c : nullptr;  // only tested against null
+  const bool deep = K >= 128 && RT * NT >= kDeepBlocks * g * 4;
+  if (deep)
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, false, false, false, (K >= 128), true>, dim3((unsigned)g), dim3(256),
+                    lds, s, a, (long long)ldx, b, c, (long long)ldy, M, Np, const_cast<float*>(bias), none, flag, (long long)ldw,
+                    n_real);
+  else
+    (void)hd_launch(pointwise_stream_kernel<K, TN, TM, false, false, false, false, false, true>, dim3((unsigned)g), dim3(256), lds,
+                    s, a, (long long)ldx, b, c, (long long)ldy, M, Np, const_cast<float*>(bias), none, flag, (long long)ldw,
+                    n_real);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" int hd_head_conv_fwd_supported(int64_t R, int Cin, int Cout) {
+  const int p = Cout >= 1 ? hd_head_conv_pitch(Cout) : 0;
+  return p && R >= 1 && R <= 0x7fffffff && (Cin == 32 || Cin == 64 || Cin == 128 || (Cin % 256 == 0 && Cin >= 256 && Cin <= 2048));
+}
+
+extern "C" hd_status hd_head_conv_fwd(const void* x, int64_t x_row_stride, const void* w, const float* bias, int64_t R, int Cin,
+                                      int Cout, float* y, int64_t y_row_stride, hd_stream stream) {
+  if (!x || !w || !bias || !y) return HD_ERR_NULL;
+  if (!hd_head_conv_fwd_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
+  const int Np = hd_head_conv_pitch(Cout);
+  if (x_row_stride == 0) x_row_stride = Cin;
+  if (y_row_stride == 0) y_row_stride = Np;
+  if (x_row_stride < Cin || y_row_stride < Np || x_row_stride % 8 || y_row_stride % 4) return HD_ERR_SHAPE;
+  if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int M = (int)R;
+  // column tile: 64 (float32 patch rows of 256 + 32 bytes: 9 KB per wave), 32 for the narrowest head
+  const int bn = Np % 64 == 0 ? 64 : 32;
+#define HD_HEAD(KK, XX, WW, BIAS, ACCUM)                                                                                          \
+  (bn == 64 ? launch_head<KK, 2, (KK <= 64 ? 2 : 1)>(XX, x_row_stride, WW, Cin, BIAS, y, y_row_stride, M, Np, Cout, ACCUM, s)      \
+            : launch_head<KK, 1, (KK <= 64 ? 2 : 1)>(XX, x_row_stride, WW, Cin, BIAS, y, y_row_stride, M, Np, Cout, ACCUM, s))
+  if (Cin == 32) return HD_HEAD(32, x, w, bias, false);
+  if (Cin == 64) return HD_HEAD(64, x, w, bias, false);
+  if (Cin == 128) return HD_HEAD(128, x, w, bias, false);
+  // Cin = 256 k: k slices of the reduction, each with its 256 columns of the weight resident; slice 0 adds the bias, the others
+  // add their product to y (float32: the partial sums are not rounded in between)
+  const auto* xs = static_cast<const unsigned short*>(x);
+  const auto* ws = static_cast<const unsigned short*>(w);
+  for (int k0 = 0; k0 < Cin; k0 += 256) {
+    const hd_status st = HD_HEAD(256, xs + k0, ws + k0, (k0 == 0 ? bias : (const float*)nullptr), (k0 != 0));
+    if (st != HD_OK) return st;
+  }
+  return HD_OK;
+#undef HD_HEAD
 }
 
 extern "C" int hd_pointwise_wgrad_supported(int64_t R, int Cin, int Cout) {

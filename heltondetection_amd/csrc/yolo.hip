@@ -323,14 +323,20 @@ __global__ __launch_bounds__(256) void yolo_assign_kernel(const hd_yolo_levels l
 // otherwise.  Forward and backward derive the flag from the same `lv`, so they always agree.
 
 struct LevelFlags {
-  int pred_dense[HD_MAX_LEVELS];  // prediction tensor is dense channels-last
-  int grad_dense[HD_MAX_LEVELS];  // gradient tensor is dense channels-last (bwd only)
+  int pred_dense[HD_MAX_LEVELS];  // prediction tensor: 0 strided, 1 dense channels-last, 2 dense with PADDED pixel rows
+  int grad_dense[HD_MAX_LEVELS];  // the same of the gradient tensor (bwd only)
 };
 
-inline bool is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
-  const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l];
-  return g.so[l] == 1 && g.sa[l] == no && g.sx[l] == na * no && g.sy[l] == W * na * no &&
-         (B == 1 || g.sb[l] == H * W * na * no) && hd_aligned16(g.pred[l]);
+// 1: [B,H,W,na,no] contiguous.  2: the same with every pixel's na*no floats followed by padding up to a pitch of sx floats
+// (sx % 4 == 0: the rows of hd_head_conv_fwd, 255 -> 256) — cell m = pixel * na + a then sits at pixel * sx + a * no, the
+// dense kernels stream whole padded rows (the gradient's padding columns are written as zeros), and tobj keeps the dense
+// cell order.  0: anything else (generic strided code).
+inline int is_dense_nhwc(const hd_yolo_levels& g, int l, int B) {
+  const long long no = g.no, na = g.na, W = g.w[l], H = g.h[l], P = g.sx[l];
+  if (!(g.so[l] == 1 && g.sa[l] == no && g.sy[l] == W * P && (B == 1 || g.sb[l] == H * W * P) && hd_aligned16(g.pred[l])))
+    return 0;
+  if (P == na * no) return 1;
+  return (P > na * no && P % 4 == 0) ? 2 : 0;
 }
 
 // Loss accumulators (sum(1-ciou), n_pos, sum bce_cls, sum bce_obj per level).  The totals sit in the
@@ -557,12 +563,20 @@ __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels 
     // independent (logit, target) pairs in flight
     const int no = lv.no;
     const int step = gridDim.x * blockDim.x;
+    const bool padded = fl.pred_dense[l] == 2;
+    const unsigned na = (unsigned)lv.na;
+    const long long pitch = lv.sx[l];
+    auto logit = [&](int m) -> float {
+      if (!padded) return pr[(long long)m * no + 4];
+      const unsigned pix = (unsigned)m / na, a = (unsigned)m - pix * na;
+      return pr[pix * pitch + a * no + 4];
+    };
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     for (; m + 3 * step < cells; m += 4 * step) {
       float x[4], t[4], d[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        x[u] = pr[(long long)(m + u * step) * no + 4];
+        x[u] = logit(m + u * step);
         t[u] = to[m + u * step];
       }
 #pragma unroll
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(256) void yolo_obj_fwd_kernel(const hd_yolo_levels 
     }
     for (; m < cells; m += step) {
       float d;
-      sum += term(pr[(long long)m * no + 4], to[m], &d);
+      sum += term(logit(m), to[m], &d);
       to[m] = d;
     }
   } else {
@@ -642,7 +656,37 @@ __global__ __launch_bounds__(256) void yolo_grad_dense_kernel(const hd_yolo_leve
   float* g = glv.pred[l];
   if (threadIdx.x < HD_MAX_ANCHORS) s_gb[threadIdx.x] = 0.0f;
   __syncthreads();
-  if (fl.grad_dense[l] && fl.pred_dense[l]) {
+  if (fl.grad_dense[l] == 2 && fl.pred_dense[l]) {
+    // padded pixel rows: a lane produces one 16-byte word of a row of `pitch` floats; the words that hold an objectness
+    // channel (a * no + 4, one per anchor) load tobj's derivative, everything else — the padding included — is zeros
+    const uint32_t pitch = (uint32_t)glv.sx[l], wpp = pitch >> 2;
+    const uint32_t pixels = cells / (uint32_t)na, words = pixels * wpp;
+    const bool pow2 = (wpp & (wpp - 1u)) == 0u;
+    const uint32_t sh = (uint32_t)__builtin_ctz(wpp);
+    uint32_t wa[4];  // word of a pixel row that holds anchor a's objectness channel (wave-uniform); more anchors: the loop
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wa[a] = a < na ? (uint32_t)(a * no + 4) >> 2 : 0xffffffffu;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < words; q += gridDim.x * blockDim.x) {
+      const uint32_t pix = pow2 ? q >> sh : q / wpp;
+      const uint32_t t = q - pix * wpp;
+      int a = -1;
+#pragma unroll
+      for (int a2 = 0; a2 < 4; ++a2) a = t == wa[a2] ? a2 : a;
+      for (int a2 = 4; a2 < na; ++a2) a = t == ((uint32_t)(a2 * no + 4) >> 2) ? a2 : a;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a >= 0) {
+        const float v = gobj * to[pix * (uint32_t)na + (uint32_t)a];
+        const uint32_t k = (uint32_t)(a * no + 4) & 3u;
+        r.x = k == 0u ? v : 0.f;
+        r.y = k == 1u ? v : 0.f;
+        r.z = k == 2u ? v : 0.f;
+        r.w = k == 3u ? v : 0.f;
+        if (grad_bias) atomicAdd(&s_gb[a], v);
+      }
+      g4[q] = r;
+    }
+  } else if (fl.grad_dense[l] == 1 && fl.pred_dense[l]) {
     const uint32_t units = cells >> 2;
     const uint32_t words = units * (uint32_t)no;
     float4* g4 = reinterpret_cast<float4*>(g);
@@ -705,12 +749,14 @@ __global__ __launch_bounds__(256) void yolo_grad_dense_kernel(const hd_yolo_leve
 constexpr int kDenseMaxBlocks = 4096;  // 16 workgroups per CU per level, grid-stride beyond
 
 // Workgroups per level of the dense-gradient launch: 256 work items per workgroup sweep.
-inline unsigned dense_grid_x(const hd_yolo_levels& lv, const LevelFlags& fl, const LevelIndex& ix) {
+inline unsigned dense_grid_x(const hd_yolo_levels& lv, const hd_yolo_levels& glv, const LevelFlags& fl, const LevelIndex& ix) {
   long long max_items = 0;
   for (int l = 0; l < lv.n_levels; ++l) {
-    const long long total = (ix.first_cell[l + 1] - ix.first_cell[l]) * lv.no;
+    const long long cells = ix.first_cell[l + 1] - ix.first_cell[l];
+    const long long total = cells * lv.no;
     const bool fast = fl.grad_dense[l] && fl.pred_dense[l];
-    max_items = std::max(max_items, fast ? (total + 3) / 4 : total);
+    const long long words = fl.grad_dense[l] == 2 ? cells / lv.na * (glv.sx[l] / 4) : (total + 3) / 4;
+    max_items = std::max(max_items, fast ? words : total);
   }
   long long gx = (max_items + 255) / 256;
   if (gx > kDenseMaxBlocks) gx = kDenseMaxBlocks;
@@ -728,8 +774,8 @@ inline unsigned cap_grid(long long work_items, int per_block) {
 inline LevelFlags make_flags(const hd_yolo_levels& lv, const hd_yolo_levels* glv, int B) {
   LevelFlags f;
   for (int l = 0; l < HD_MAX_LEVELS; ++l) {
-    f.pred_dense[l] = (l < lv.n_levels && is_dense_nhwc(lv, l, B)) ? 1 : 0;
-    f.grad_dense[l] = (glv && l < lv.n_levels && is_dense_nhwc(*glv, l, B)) ? 1 : 0;
+    f.pred_dense[l] = l < lv.n_levels ? is_dense_nhwc(lv, l, B) : 0;
+    f.grad_dense[l] = (glv && l < lv.n_levels) ? is_dense_nhwc(*glv, l, B) : 0;
   }
   return f;
 }
@@ -895,7 +941,7 @@ extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_y
       reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + kAccBytes + part_bytes(lv));
   float* part = grad_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes)
                           : nullptr;
-  const unsigned gx = dense_grid_x(*lv, fl, ix);
+  const unsigned gx = dense_grid_x(*lv, *grad_lv, fl, ix);
   (void)hd_launch(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
                      B, *cfg, grad_scale, tobj, part);
   HD_RETURN_IF_LAUNCH_FAILED();
@@ -923,11 +969,11 @@ extern "C" hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yol
   if (cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1))
     hipLaunchKernelGGL((yolo_pos_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
                        B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
-                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
+                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, *grad_lv, fl, ix));
   else
     hipLaunchKernelGGL((yolo_pos_kernel<true, false>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
                        B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
-                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, fl, ix));
+                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, *grad_lv, fl, ix));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }

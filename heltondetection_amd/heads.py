@@ -56,6 +56,21 @@ class YOLOv5Head(nn.Module):
 
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         views = []
+        self._roots = None
+        if (self.training and self.bias_grad_in_loss
+                and all(ops.head_conv_supported(f, conv.lp_weight()) for conv, f in zip(self.m, feats))):
+            # training on the HIP Detect convolution (ops.head_conv): float32 rows padded to a 16-byte pitch (255 -> 256 channels),
+            # read by the loss through [B, na, H, W, no] views; inside ops.yolo_loss autograd differentiates the padded rows
+            # themselves (`_roots`, handed over by loss() below), so no cast, bias add, permute or slice runs in either
+            # direction (a caller that differentiates the views directly still gets gradients, through as_strided's backward)
+            roots = []
+            for conv, f in zip(self.m, feats):
+                y = ops.head_conv(f, conv.lp_weight(), conv.bias)
+                B, P, H, W = y.shape
+                roots.append(y)
+                views.append(y.as_strided((B, self.na, H, W, self.no), (H * W * P, self.no, W * P, P, 1), y.storage_offset()))
+            self._roots = roots
+            return views
         for conv, f in zip(self.m, feats):
             # bias.detach(): the bias gradient comes from the loss kernels (ops.yolo_loss(biases=...)),
             # not from a framework reduction over the dense [B, na*no, H, W] gradient
@@ -71,8 +86,12 @@ class YOLOv5Head(nn.Module):
         shapes = [(self.na, p.shape[2], p.shape[3], self.no) for p in preds]
         slots = self.assigner(shapes, self.strides, self.anchors, gt_boxes, gt_cls, m_valid)
         biases = [c.bias for c in self.m] if (self.training and self.bias_grad_in_loss) else None
+        roots, self._roots = getattr(self, "_roots", None), None
+        if roots is not None and not all(p.data_ptr() == r.data_ptr() for p, r in zip(preds, roots)):
+            roots = None   # predictions that did not come from the last forward (a caller's own tensors)
+        extra = dict(roots=roots) if roots is not None else {}
         return ops.yolo_loss(preds, self.strides, self.anchors, slots, gt_cls.shape[1], self.box_gain, self.obj_gain,
-                             self.cls_gain, self.balance, biases=biases, focal=self.focal)
+                             self.cls_gain, self.balance, biases=biases, focal=self.focal, **extra)
 
     @torch.no_grad()
     def predict(self, preds, conf_thr=0.25, iou_thr=0.45, max_nms=30000, max_det=300):

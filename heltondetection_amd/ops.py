@@ -11,6 +11,7 @@ CIoU, per-class NMS, WBF.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -517,9 +518,9 @@ class _YoloLossFn(torch.autograd.Function):
     inside the HIP kernels, so autograd never reduces the dense gradient for the bias)."""
 
     @staticmethod
-    def forward(ctx, strides, anchors, slots, M, gains, balance, n_pred, *tensors):
+    def forward(ctx, strides, anchors, slots, M, gains, balance, n_pred, n_root, *tensors):
         lib = _lib.load()
-        preds, biases = tensors[:n_pred], tensors[n_pred:]
+        preds, roots, biases = tensors[:n_pred], tensors[n_pred:n_pred + n_root], tensors[n_pred + n_root:]
         preds_d = [p.detach() for p in preds]
         st = _yolo_levels(preds_d, strides, anchors)
         B = preds[0].shape[0]
@@ -532,8 +533,11 @@ class _YoloLossFn(torch.autograd.Function):
             check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
                                        C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
         ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d)
+        # roots: the tensors autograd differentiates when the predictions are (detached) strided views of padded rows
+        # (ops.head_conv): gradient buffers then take the root's geometry and the views are re-derived on them
+        root_meta = [(tuple(r.shape), tuple(r.stride()), p.storage_offset() - r.storage_offset()) for r, p in zip(roots, preds)]
         ctx.meta = (strides, anchors, int(M), gains, balance, wsb, n_pred,
-                    [(tuple(b.shape), b.dtype) for b in biases])
+                    [(tuple(b.shape), b.dtype) for b in biases], root_meta)
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
@@ -541,10 +545,20 @@ class _YoloLossFn(torch.autograd.Function):
     def backward(ctx, grad_total, _grad_parts):
         lib = _lib.load()
         slot_cell, slot_tbox, slot_cls, ws, *preds = ctx.saved_tensors
-        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta = ctx.meta
+        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta, root_meta = ctx.meta
         st = _yolo_levels(preds, strides, anchors)
         # gradient tensors keep the producer's memory order (dense channels-last fast path)
-        grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=p.device) for p in preds]
+        groots = None
+        if root_meta:
+            # padded rows: the dense kernel writes whole rows, padding included, when they are 16-byte words (yolo.hip,
+            # is_dense_nhwc kind 2); any other geometry gets a zeroed buffer
+            groots = []
+            for sh, sd, _ in root_meta:
+                g = torch.empty_strided(sh, sd, dtype=_F32, device=preds[0].device)
+                groots.append(g if (sd[1] == 1 and sh[1] % 4 == 0) else g.zero_())
+            grads = [g.as_strided(p.shape, p.stride(), off) for g, p, (_, _, off) in zip(groots, preds, root_meta)]
+        else:
+            grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=p.device) for p in preds]
         gst = _yolo_levels(grads, strides, anchors)
         B = preds[0].shape[0]
         cfg = _loss_cfg(gains[0], gains[1], gains[2], balance, gains[3] if len(gains) > 3 else None)
@@ -559,12 +573,15 @@ class _YoloLossFn(torch.autograd.Function):
                                        _ptr(slot_cls), C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws), wsb,
                                        _stream(gs)), "hd_yolo_loss_bwd_pos")
         bias_grads = tuple(gbias[l].view(shape).to(dtype) for l, (shape, dtype) in enumerate(bias_meta))
-        return (None,) * 7 + tuple(grads) + bias_grads
+        if groots is not None:
+            return (None,) * 8 + (None,) * n_pred + tuple(groots) + bias_grads
+        return (None,) * 8 + tuple(grads) + bias_grads
 
 
 def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, box_gain: float = 0.05,
               obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4),
-              biases: Optional[Sequence[torch.Tensor]] = None, focal=None):
+              biases: Optional[Sequence[torch.Tensor]] = None, focal=None,
+              roots: Optional[Sequence[torch.Tensor]] = None):
     """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached).
 
     ``focal``: None, or dict(gamma=1.5, alpha=0.25, terms=("cls", "obj")) / the same as a tuple — the
@@ -572,11 +589,18 @@ def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, bo
 
     ``biases``: optionally the per-level Detect-conv bias parameters ([na*no] each) whose values are
     already folded into ``preds`` (the conv ran with ``bias.detach()``); their gradients are then
-    produced by the loss kernels."""
+    produced by the loss kernels.
+
+    ``roots``: one tensor per level of which ``preds[l]`` is a DETACHED strided view (the padded float32 rows of
+    ops.head_conv: [B, pitch, H, W] channels-last, viewed as [B, na, H, W, no]); the gradient then flows to the roots,
+    allocated with their geometry and written through the same views, padding columns zero."""
     biases = tuple(biases) if biases is not None else ()
+    roots = tuple(roots) if roots is not None else ()
+    if roots and len(roots) != len(preds):
+        raise _lib.HdError("yolo_loss: `roots` needs one tensor per prediction level")
     return _YoloLossFn.apply(tuple(strides), tuple(tuple(tuple(a) for a in lv) for lv in anchors), slots, int(M),
-                             (box_gain, obj_gain, cls_gain, _focal_tuple(focal)), tuple(balance), len(preds), *preds,
-                             *biases)
+                             (box_gain, obj_gain, cls_gain, _focal_tuple(focal)), tuple(balance), len(preds), len(roots),
+                             *[p.detach() for p in preds] if roots else preds, *roots, *biases)
 
 
 def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,
@@ -1272,6 +1296,110 @@ def pointwise_bwd_rows(dy: torch.Tensor, w2: torch.Tensor, x: torch.Tensor, add:
                                    C.byref(job), _stream(dy)), "hd_pointwise_bwd")
     _WgradChain.submit(dy.device, job, (ws,), leaf)
     return dx, dw
+
+
+# ------------------------------------------------------------------------------- Detect convolution (YOLOv5 head)
+class HeadConvSwitch:
+    """The Detect convolutions on the HIP kernels (hd_head_conv_fwd / hd_head_conv_bwd, padded float32 rows).  HD_HEAD_CONV=0:
+    the library's biased convolution + cast, as in rounds 1-3."""
+    enabled = os.environ.get("HD_HEAD_CONV", "1") != "0"
+
+
+def head_conv_pitch(cout: int) -> int:
+    """Columns per row of the padded head output (the next of 32 / 64 / 128 / 256 >= cout; 0 = unsupported)."""
+    return int(_lib.load().hd_head_conv_pitch(int(cout)))
+
+
+def head_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """bf16 channels-last rows, a dense bf16 [Cout, Cin, 1, 1] weight, Cout <= 256 and a backward the fused kernel takes.
+    (A forward the streaming kernel does not take — Cin not 32/64/128/256k — runs on the library with padded weights.)"""
+    if not (HeadConvSwitch.enabled and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1)
+            and weight.shape[1] == x.shape[1] and weight.is_contiguous() and _cl_row_stride(x, 8) is not None):
+        return False
+    B, K, H, W = x.shape
+    return bool(_lib.load().hd_head_conv_bwd_supported(B * H * W, K, int(weight.shape[0])))
+
+
+def head_conv_rows(x: torch.Tensor, w2: torch.Tensor, bias: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y [B, pitch, H, W] float32 channels-last = x . w2^T + bias in the first Cout channels, zeros in the rest; no autograd."""
+    lib = _lib.load()
+    B, K, H, W = x.shape
+    N = w2.shape[0]
+    P = head_conv_pitch(N)
+    ld_x = _cl_row_stride(x, 8)
+    if (ld_x is None or x.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or tuple(w2.shape) != (N, K) or not w2.is_contiguous()
+            or bias.dtype != _F32 or bias.numel() != N or not bias.is_contiguous() or P == 0):
+        raise _lib.HdError("head_conv: needs bf16 channels-last rows, a dense bf16 [Cout <= 256, Cin] weight and a float32 bias")
+    if out is None:
+        out = torch.empty((B, P, H, W), dtype=_F32, device=x.device, memory_format=torch.channels_last)
+    ld_y = _cl_row_stride(out, 4)
+    if ld_y is None or tuple(out.shape) != (B, P, H, W) or out.dtype != _F32:
+        raise _lib.HdError("head_conv: `out` must be a float32 channels-last tensor [B, pitch, H, W]")
+    R = B * H * W
+    if K <= 256:   # one launch: timed and priced per launch (bench.py); longer reductions run as K / 256 launches, left unpriced
+        _note_bytes("head_conv", 2 * R * K + 4 * R * P + 2 * N * K, {"flops": 2 * R * K * P, "shape": (R, K, N)})
+    with (_ktimed("head_conv") if K <= 256 else contextlib.nullcontext()):
+        check(lib.hd_head_conv_fwd(_ptr(x), int(ld_x), _ptr(w2), _ptr(bias), R, K, N, _ptr(out), int(ld_y), _stream(x)),
+              "hd_head_conv_fwd")
+    return out
+
+
+class _HeadConvFn(torch.autograd.Function):
+    """Detect convolution: x [B, Cin, H, W] bf16 rows -> y [B, pitch, H, W] FLOAT32 rows (accumulator + bias, unrounded; padding
+    channels zero).  backward takes the float32 gradient of y whose padding channels are zero (the loss kernels write them),
+    rounds it to bf16 once — what `.float()`'s backward did — and runs hd_head_conv_bwd: dx and the weight-gradient partials
+    from one staging.  The bias takes no gradient here: ops.yolo_loss(biases=...) produces it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape[0], weight.shape[1]
+        B, _, H, W = x.shape
+        if bool(_lib.load().hd_head_conv_fwd_supported(B * H * W, K, N)):
+            y = head_conv_rows(x, weight.view(N, K), bias.detach().contiguous())
+        else:  # the library's convolution on the padded weights: the same rows, rounded to bf16 before the bias
+            P = head_conv_pitch(N)
+            wp = torch.cat([weight, weight.new_zeros((P - N, K, 1, 1))], 0) if P > N else weight
+            bp = torch.cat([bias.detach(), bias.new_zeros(P - N)], 0) if P > N else bias.detach()
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            y = torch.nn.functional.conv2d(xd, wp).float().add_(bp.view(1, P, 1, 1))
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape[0], weight.shape[1]
+        B, _, H, W = x.shape
+        R = B * H * W
+        dy = gy.to(torch.bfloat16)
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
+        if ld_dy is None or ld_x is None or dy.shape[1] != head_conv_pitch(N):
+            raise _lib.HdError("head_conv backward: the gradient must have the padded channels-last rows of the output")
+        dx = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        dw = torch.empty((N, K), dtype=torch.bfloat16, device=x.device)
+        nbytes = lib.hd_head_conv_bwd_workspace_bytes(R, K, N)
+        ws = _wgrad_workspace(x.device, nbytes)
+        pend = _WgradChain.piggyback(x.device)
+        job = _lib.WgradJob()
+        P = dy.shape[1]
+        _note_bytes("head_conv_bwd", 2 * (R * (P + 2 * K) + 2 * N * K), {"flops": 4 * R * K * P, "shape": (R, K, N)})
+        with _ktimed("head_conv_bwd"):
+            check(lib.hd_head_conv_bwd(_ptr(dy), int(ld_dy), _ptr(weight), _ptr(x), int(ld_x), R, K, N, _ptr(dx), K, _ptr(dw),
+                                       _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
+                                       _stream(x)), "hd_head_conv_bwd")
+        _WgradChain.submit(x.device, job, (ws,), weight)
+        return dx, dw.view(N, K, 1, 1), None
+
+
+def head_conv(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """Differentiable (x, weight) Detect convolution -> padded float32 rows [B, head_conv_pitch(Cout), H, W]; see _HeadConvFn."""
+    return _HeadConvFn.apply(x, weight, bias)
 
 
 def conv3x3_wgrad_supported(x: torch.Tensor, cout: int, stride: int = 1) -> bool:

@@ -526,6 +526,28 @@ hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, const void* w,
                            void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
                            hd_stream stream);
 
+/* The Detect convolution of the YOLOv5 head (README.md:9: "Head: YOLOv5Head"; one biased 1x1 convolution per pyramid level
+ * to Cout = na (5 + nc) channels — 255 for 80 classes, no tile multiple).  Rows of the raw head output are PADDED to
+ * hd_head_conv_pitch(Cout) columns (the next of 32 / 64 / 128 / 256; 0 = Cout > 256, unsupported) so that they stay 16-byte
+ * aligned and both convolution and loss kernels stream them; the loss reads the first Cout columns through the
+ * [B, na, H, W, no] strided view (hd_yolo_levels with sx = pitch), the padding columns are written as zeros.
+ *   fwd: y[R, pitch] (float32, y_row_stride >= pitch elements, 0 = dense) = x[R, Cin] . w[Cout, Cin]^T + bias[Cout];
+ *        x, w bfloat16, bias float32; Cin 32 / 64 / 128 / 256 (the resident-weight streaming kernel of hd_pointwise_conv,
+ *        float32 epilogue: accumulator + bias is stored unrounded).
+ *   bwd: as hd_pointwise_bwd with dy[R, pitch] bfloat16 whose padding columns are ZERO: dx[R, Cin] = dy . w and the
+ *        row-sliced partials of dw[Cout, Cin] (bfloat16 after the slice sum; job_out / piggyback as there), one launch.
+ *        Cin a multiple of 32 with at most 32 column tiles.  The bias gradient comes from the loss kernels
+ *        (hd_yolo_loss_bwd_*: grad_bias). */
+int hd_head_conv_pitch(int Cout);
+int hd_head_conv_fwd_supported(int64_t R, int Cin, int Cout);
+hd_status hd_head_conv_fwd(const void* x, int64_t x_row_stride, const void* w, const float* bias, int64_t R, int Cin, int Cout,
+                           float* y, int64_t y_row_stride, hd_stream stream);
+int hd_head_conv_bwd_supported(int64_t R, int Cin, int Cout);
+size_t hd_head_conv_bwd_workspace_bytes(int64_t R, int Cin, int Cout);
+hd_status hd_head_conv_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride, int64_t R,
+                           int Cin, int Cout, void* dx, int64_t dx_row_stride, void* dw, void* workspace, size_t workspace_bytes,
+                           const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream);
+
 /* The YOLOv5 v6.x stem, Conv2d(3, Cout, kernel 6, stride 2, padding 2, no bias), on channels-last images (csrc/stem_conv.hip;
  * the reference's backbone list, README.md:9).  x: [B, H, W, 3] float32 (x_dtype 0) or bfloat16 (1), dense, H even,
  * W % 4 == 0; w: bfloat16 [Cout][6][6][3] (the channels-last memory of a [Cout, 3, 6, 6] weight); Cout 32 or 64;
