@@ -116,6 +116,8 @@ SIGNATURES = {
     "hd_yolo_loss_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "hd_yolo_loss_bwd_dense": (_I, [_P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "hd_yolo_loss_bwd_pos": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd_dense_bf16": (_I, [_P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "hd_yolo_loss_bwd_pos_bf16": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "hd_ciou_fwd": (_I, [_P, _P, _L, _P, _P]),
     "hd_ciou_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
     "hd_yolo_nms_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -390,6 +390,31 @@ __device__ __forceinline__ float4 tbox_xyxy(const float4 tb) {
   return make_float4(tb.x - tb.z * 0.5f, tb.y - tb.w * 0.5f, tb.x + tb.z * 0.5f, tb.y + tb.w * 0.5f);
 }
 
+// Gradient element types.  float: the gradient tensor of hd_yolo_levels as declared.  GradBf16 (hd_yolo_loss_bwd_*_bf16): the
+// same element strides over bfloat16 elements — the padded rows hd_head_conv_bwd consumes, written without a float32 copy in
+// between.  A matched cell's box / class terms are ADDED (a cell can be matched by several targets): float32 atomics there,
+// and for bf16 the packed bfloat16 atomic add of gfx950 on the 32-bit word holding the element, every addition rounded (what a
+// half-precision index_put_(accumulate=True) does).
+struct GradF32 {
+  typedef float elem;
+  __device__ static __forceinline__ void add(float* base, long long e, float v) { atomicAdd(base + e, v); }
+};
+struct GradBf16 {
+  typedef unsigned short elem;
+  __device__ static __forceinline__ unsigned short round_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+  __device__ static __forceinline__ void add(float* base_as_float, long long e, float v) {
+    // global_atomic_pk_add_bf16 on the 32-bit word that holds the element: the value in its half, +0 in the other (x + 0 = x),
+    // no return value, no retry loop (a compare-and-swap version made the matched-cell kernel 14 us slower: neighbouring
+    // lanes share words and every collision cost a round trip)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) s16x2 global_s16x2;
+    unsigned short* base = reinterpret_cast<unsigned short*>(base_as_float);
+    const short b = (short)round_bf16(v);
+    const s16x2 val = (e & 1ll) ? s16x2{(short)0, b} : s16x2{b, (short)0};
+    __builtin_amdgcn_global_atomic_fadd_v2bf16((global_s16x2*)(base + (e & ~1ll)), val);
+  }
+};
+
 // Matched-cell terms.  grid: (ceil(S / (4 waves * 4 slots)), n_levels).  A wave owns 4 consecutive
 // slots (short serial chain: the per-slot work is a dependent gather + CIoU), finds the matched
 // ones with one ballot and spends all 64 lanes on the `no` channels of each matched cell.
@@ -397,7 +422,7 @@ __device__ __forceinline__ float4 tbox_xyxy(const float4 tb) {
 // one global atomic per touched channel per workgroup.
 constexpr int kSlotsPerWave = 4;
 
-template <bool BWD, bool FOCAL>
+template <bool BWD, bool FOCAL, typename G = GradF32>
 __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
                                                        const LevelIndex ix, const LevelFlags fl, int B, long long S,
                                                        const int32_t* __restrict__ slot_cell,
@@ -483,7 +508,8 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
     } else {
       float gc[4];
       hd_ciou<true>(pb, tx, gc);
-      float* g = glv.pred[l] + cell_offset(glv, l, cp);
+      float* g = glv.pred[l];                       // element type G::elem behind the declared float pointer
+      const long long g0 = cell_offset(glv, l, cp);
       const long long gso = glv.so[l];
       if (lane < 4) {
         const float gpx = -(gc[0] + gc[2]), gpy = -(gc[1] + gc[3]);
@@ -493,7 +519,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
         else if (lane == 1) v = gbox * gpy * 2.0f * sg[1] * (1.0f - sg[1]);
         else if (lane == 2) v = gbox * gpw * 8.0f * sg[2] * sg[2] * (1.0f - sg[2]) * aw;
         else v = gbox * gph * 8.0f * sg[3] * sg[3] * (1.0f - sg[3]) * ah;
-        atomicAdd(g + lane * gso, v);
+        G::add(g, g0 + lane * gso, v);
         if (do_bias) atomicAdd(&s_gb[cp.a * no + lane], v);
       }
       if (nc > 1)
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(const hd_yolo_levels lv, 
           if (focal_cls) hd_focal_bce(p[(5 + c) * so], c == tc ? 1.0f : 0.0f, cfg.focal_gamma, cfg.focal_alpha, &d);
           else d = hd_sigmoid(p[(5 + c) * so]) - (c == tc ? 1.0f : 0.0f);
           const float v = gcls * d;
-          atomicAdd(g + (5 + c) * gso, v);
+          G::add(g, g0 + (5 + c) * gso, v);
           if (do_bias) atomicAdd(&s_gb[cp.a * no + 5 + c], v);
         }
     }
@@ -746,16 +772,66 @@ __global__ __launch_bounds__(256) void yolo_grad_dense_kernel(const hd_yolo_leve
   }
 }
 
+// The same for a bfloat16 gradient in padded pixel rows (pitch % 8 == 0): a lane produces one 16-byte word = 8 channels.
+__global__ __launch_bounds__(256) void yolo_grad_dense_bf16_kernel(const hd_yolo_levels lv, const hd_yolo_levels glv,
+                                                                   const LevelIndex ix, int B, const hd_yolo_loss_cfg cfg,
+                                                                   const float* __restrict__ grad_scale,
+                                                                   const float* __restrict__ tobj,
+                                                                   float* __restrict__ grad_bias /* partials */) {
+  __shared__ float s_gb[HD_MAX_ANCHORS];
+  const int l = blockIdx.y;
+  const int no = lv.no, na = lv.na;
+  const uint32_t cells = (uint32_t)(ix.first_cell[l + 1] - ix.first_cell[l]);
+  const float gobj = grad_scale[0] * (float)B * cfg.obj_gain * cfg.balance[l] / (float)cells;
+  const float* to = tobj + ix.first_cell[l];
+  if (threadIdx.x < HD_MAX_ANCHORS) s_gb[threadIdx.x] = 0.0f;
+  __syncthreads();
+  const uint32_t pitch = (uint32_t)glv.sx[l], wpp = pitch >> 3;
+  const uint32_t pixels = cells / (uint32_t)na, words = pixels * wpp;
+  const bool pow2 = (wpp & (wpp - 1u)) == 0u;
+  const uint32_t sh = (uint32_t)__builtin_ctz(wpp);
+  uint32_t wa[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) wa[a] = a < na ? (uint32_t)(a * no + 4) >> 3 : 0xffffffffu;
+  uint4* g4 = reinterpret_cast<uint4*>(glv.pred[l]);
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < words; q += gridDim.x * blockDim.x) {
+    const uint32_t pix = pow2 ? q >> sh : q / wpp;
+    const uint32_t t = q - pix * wpp;
+    int a = -1;
+#pragma unroll
+    for (int a2 = 0; a2 < 4; ++a2) a = t == wa[a2] ? a2 : a;
+    for (int a2 = 4; a2 < na; ++a2) a = t == ((uint32_t)(a2 * no + 4) >> 3) ? a2 : a;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (a >= 0) {
+      const float v = gobj * to[pix * (uint32_t)na + (uint32_t)a];
+      const uint32_t k = (uint32_t)(a * no + 4) & 7u;
+      const uint32_t h = (uint32_t)GradBf16::round_bf16(v) << ((k & 1u) * 16u);
+      r.x = (k >> 1) == 0u ? h : 0u;
+      r.y = (k >> 1) == 1u ? h : 0u;
+      r.z = (k >> 1) == 2u ? h : 0u;
+      r.w = (k >> 1) == 3u ? h : 0u;
+      if (grad_bias) atomicAdd(&s_gb[a], v);   // the bias gradient sums the unrounded terms
+    }
+    g4[q] = r;
+  }
+  if (grad_bias) {
+    __syncthreads();
+    if (threadIdx.x < na) grad_bias[((size_t)l * gridDim.x + blockIdx.x) * na + threadIdx.x] = s_gb[threadIdx.x];
+  }
+}
+
 constexpr int kDenseMaxBlocks = 4096;  // 16 workgroups per CU per level, grid-stride beyond
 
 // Workgroups per level of the dense-gradient launch: 256 work items per workgroup sweep.
-inline unsigned dense_grid_x(const hd_yolo_levels& lv, const hd_yolo_levels& glv, const LevelFlags& fl, const LevelIndex& ix) {
+inline unsigned dense_grid_x(const hd_yolo_levels& lv, const hd_yolo_levels& glv, const LevelFlags& fl, const LevelIndex& ix,
+                             int grad_dtype = 0) {
   long long max_items = 0;
   for (int l = 0; l < lv.n_levels; ++l) {
     const long long cells = ix.first_cell[l + 1] - ix.first_cell[l];
     const long long total = cells * lv.no;
     const bool fast = fl.grad_dense[l] && fl.pred_dense[l];
-    const long long words = fl.grad_dense[l] == 2 ? cells / lv.na * (glv.sx[l] / 4) : (total + 3) / 4;
+    const long long words = grad_dtype == 1 ? cells / lv.na * (glv.sx[l] / 8)
+                            : fl.grad_dense[l] == 2 ? cells / lv.na * (glv.sx[l] / 4) : (total + 3) / 4;
     max_items = std::max(max_items, fast ? words : total);
   }
   long long gx = (max_items + 255) / 256;
@@ -928,22 +1004,89 @@ static hd_status bwd_common_checks(const hd_yolo_levels* lv, const hd_yolo_level
   return HD_OK;
 }
 
-extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
-                                            const hd_yolo_loss_cfg* cfg, const float* grad_scale,
-                                            float* grad_bias, const void* workspace, size_t workspace_bytes,
-                                            hd_stream stream) {
+// grad_dtype 1: bfloat16 gradient elements in padded pixel rows (so == 1, sa == no, sx % 8 == 0, rows contiguous, 16-byte
+// aligned), predictions dense (either kind) so that tobj is in pixel order — what ops.head_conv produces.
+static hd_status bf16_grad_checks(const hd_yolo_levels* lv, const hd_yolo_levels* g, const LevelFlags& fl, int B) {
+  for (int l = 0; l < lv->n_levels; ++l) {
+    const long long no = g->no, na = g->na, W = g->w[l], H = g->h[l], P = g->sx[l];
+    if (!fl.pred_dense[l]) return HD_ERR_SHAPE;
+    if (!(g->so[l] == 1 && g->sa[l] == no && P >= na * no && P % 8 == 0 && g->sy[l] == W * P && (B == 1 || g->sb[l] == H * W * P)))
+      return HD_ERR_SHAPE;
+    if (!hd_aligned16(g->pred[l])) return HD_ERR_ALIGN;
+  }
+  return HD_OK;
+}
+
+static hd_status bwd_dense_impl(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, const hd_yolo_loss_cfg* cfg,
+                                const float* grad_scale, float* grad_bias, const void* workspace, size_t workspace_bytes,
+                                hd_stream stream, int grad_dtype) {
   hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
   if (st != HD_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   const LevelIndex ix = make_index(*lv, B);
-  const LevelFlags fl = make_flags(*lv, grad_lv, B);
+  const LevelFlags fl = make_flags(*lv, grad_dtype ? nullptr : grad_lv, B);
+  if (grad_dtype && (st = bf16_grad_checks(lv, grad_lv, fl, B)) != HD_OK) return st;
   const float* tobj =
       reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + kAccBytes + part_bytes(lv));
   float* part = grad_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + kAccBytes)
                           : nullptr;
-  const unsigned gx = dense_grid_x(*lv, *grad_lv, fl, ix);
-  (void)hd_launch(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
-                     B, *cfg, grad_scale, tobj, part);
+  const unsigned gx = dense_grid_x(*lv, *grad_lv, fl, ix, grad_dtype);
+  if (grad_dtype)
+    (void)hd_launch(yolo_grad_dense_bf16_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, B, *cfg,
+                    grad_scale, tobj, part);
+  else
+    (void)hd_launch(yolo_grad_dense_kernel, dim3(gx, (unsigned)lv->n_levels), dim3(256), 0, s, *lv, *grad_lv, ix, fl,
+                    B, *cfg, grad_scale, tobj, part);
+  HD_RETURN_IF_LAUNCH_FAILED();
+  return HD_OK;
+}
+
+extern "C" hd_status hd_yolo_loss_bwd_dense(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                            const hd_yolo_loss_cfg* cfg, const float* grad_scale,
+                                            float* grad_bias, const void* workspace, size_t workspace_bytes,
+                                            hd_stream stream) {
+  return bwd_dense_impl(lv, grad_lv, B, cfg, grad_scale, grad_bias, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" hd_status hd_yolo_loss_bwd_dense_bf16(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                                 const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                                                 const void* workspace, size_t workspace_bytes, hd_stream stream) {
+  return bwd_dense_impl(lv, grad_lv, B, cfg, grad_scale, grad_bias, workspace, workspace_bytes, stream, 1);
+}
+
+static hd_status bwd_pos_impl(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                              const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
+                              const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                              const void* workspace, size_t workspace_bytes, hd_stream stream, int grad_dtype) {
+  hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
+  if (st != HD_OK) return st;
+  if (M < 0) return HD_ERR_SHAPE;
+  if (M == 0 && !grad_bias) return HD_OK;
+  if (M > 0 && (!slot_cell || !slot_tbox || !slot_cls)) return HD_ERR_NULL;
+  const LevelIndex ix = make_index(*lv, B);
+  const LevelFlags fl = make_flags(*lv, grad_dtype ? nullptr : grad_lv, B);
+  if (grad_dtype && (st = bf16_grad_checks(lv, grad_lv, fl, B)) != HD_OK) return st;
+  char* wsb = reinterpret_cast<char*>(const_cast<void*>(workspace));
+  float* acc = reinterpret_cast<float*>(wsb);
+  const float* part = reinterpret_cast<const float*>(wsb + kAccBytes);
+  float* tobj = reinterpret_cast<float*>(wsb + kAccBytes + part_bytes(lv));
+  const long long S = (long long)5 * lv->na * B * M;
+  const size_t lds = grad_bias ? (size_t)lv->na * lv->no * sizeof(float) : 0;
+  dim3 grid = S > 0 ? pos_grid(S, lv->n_levels) : dim3(1, (unsigned)lv->n_levels);  // M == 0: partial reduce only
+  const bool focal = cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1);
+  const int n_part = (int)dense_grid_x(*lv, *grad_lv, fl, ix, grad_dtype);
+#define HD_POS(FOCAL, GT)                                                                                                  \
+  hipLaunchKernelGGL((yolo_pos_kernel<true, FOCAL, GT>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl, B, S, \
+                     slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc, tobj, grad_bias, \
+                     grad_bias ? part : nullptr, n_part)
+  if (grad_dtype) {
+    if (focal) HD_POS(true, GradBf16);
+    else HD_POS(false, GradBf16);
+  } else {
+    if (focal) HD_POS(true, GradF32);
+    else HD_POS(false, GradF32);
+  }
+#undef HD_POS
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
 }
@@ -952,30 +1095,16 @@ extern "C" hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yol
                                           const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
                                           const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
                                           const void* workspace, size_t workspace_bytes, hd_stream stream) {
-  hd_status st = bwd_common_checks(lv, grad_lv, B, cfg, grad_scale, workspace, workspace_bytes);
-  if (st != HD_OK) return st;
-  if (M < 0) return HD_ERR_SHAPE;
-  if (M == 0 && !grad_bias) return HD_OK;
-  if (M > 0 && (!slot_cell || !slot_tbox || !slot_cls)) return HD_ERR_NULL;
-  const LevelIndex ix = make_index(*lv, B);
-  const LevelFlags fl = make_flags(*lv, grad_lv, B);
-  char* wsb = reinterpret_cast<char*>(const_cast<void*>(workspace));
-  float* acc = reinterpret_cast<float*>(wsb);
-  const float* part = reinterpret_cast<const float*>(wsb + kAccBytes);
-  float* tobj = reinterpret_cast<float*>(wsb + kAccBytes + part_bytes(lv));
-  const long long S = (long long)5 * lv->na * B * M;
-  const size_t lds = grad_bias ? (size_t)lv->na * lv->no * sizeof(float) : 0;
-  dim3 grid = S > 0 ? pos_grid(S, lv->n_levels) : dim3(1, (unsigned)lv->n_levels);  // M == 0: partial reduce only
-  if (cfg->focal_gamma > 0.0f && (cfg->focal_terms & 1))
-    hipLaunchKernelGGL((yolo_pos_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
-                       B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
-                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, *grad_lv, fl, ix));
-  else
-    hipLaunchKernelGGL((yolo_pos_kernel<true, false>), grid, dim3(256), lds, (hipStream_t)stream, *lv, *grad_lv, ix, fl,
-                       B, S, slot_cell, reinterpret_cast<const float4*>(slot_tbox), slot_cls, *cfg, grad_scale, acc,
-                       tobj, grad_bias, grad_bias ? part : nullptr, (int)dense_grid_x(*lv, *grad_lv, fl, ix));
-  HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
+  return bwd_pos_impl(lv, grad_lv, B, M, slot_cell, slot_tbox, slot_cls, cfg, grad_scale, grad_bias, workspace, workspace_bytes,
+                      stream, 0);
+}
+
+extern "C" hd_status hd_yolo_loss_bwd_pos_bf16(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                                               const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
+                                               const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                                               const void* workspace, size_t workspace_bytes, hd_stream stream) {
+  return bwd_pos_impl(lv, grad_lv, B, M, slot_cell, slot_tbox, slot_cls, cfg, grad_scale, grad_bias, workspace, workspace_bytes,
+                      stream, 1);
 }
 
 extern "C" hd_status hd_yolo_loss_bwd(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,

@@ -56,18 +56,19 @@ class YOLOv5Head(nn.Module):
 
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         views = []
-        self._roots = None
+        self._roots = self._head_in = None
         if (self.training and self.bias_grad_in_loss
                 and all(ops.head_conv_supported(f, conv.lp_weight()) for conv, f in zip(self.m, feats))):
             # training on the HIP Detect convolution (ops.head_conv): float32 rows padded to a 16-byte pitch (255 -> 256 channels),
             # read by the loss through [B, na, H, W, no] views; inside ops.yolo_loss autograd differentiates the padded rows
             # themselves (`_roots`, handed over by loss() below), so no cast, bias add, permute or slice runs in either
             # direction (a caller that differentiates the views directly still gets gradients, through as_strided's backward)
-            roots = []
+            roots, self._head_in = [], []
             for conv, f in zip(self.m, feats):
                 y = ops.head_conv(f, conv.lp_weight(), conv.bias)
                 B, P, H, W = y.shape
                 roots.append(y)
+                self._head_in.append((f, conv.lp_weight()))
                 views.append(y.as_strided((B, self.na, H, W, self.no), (H * W * P, self.no, W * P, P, 1), y.storage_offset()))
             self._roots = roots
             return views
@@ -89,7 +90,15 @@ class YOLOv5Head(nn.Module):
         roots, self._roots = getattr(self, "_roots", None), None
         if roots is not None and not all(p.data_ptr() == r.data_ptr() for p, r in zip(preds, roots)):
             roots = None   # predictions that did not come from the last forward (a caller's own tensors)
-        extra = dict(roots=roots) if roots is not None else {}
+        extra = {}
+        if roots is not None:
+            # bf16 logit gradient straight into the Detect convolutions' backward (ops.yolo_loss(heads=...)), or — with
+            # HD_HEAD_GRAD_BF16=0 — a float32 gradient of the padded rows that autograd hands to ops.head_conv's backward
+            if ops.HeadConvSwitch.bf16_grad and all(r.shape[1] % 8 == 0 for r in roots):
+                extra = dict(heads=self._head_in)
+            else:
+                extra = dict(roots=roots)
+        self._head_in = None
         return ops.yolo_loss(preds, self.strides, self.anchors, slots, gt_cls.shape[1], self.box_gain, self.obj_gain,
                              self.cls_gain, self.balance, biases=biases, focal=self.focal, **extra)
 

@@ -518,9 +518,10 @@ class _YoloLossFn(torch.autograd.Function):
     inside the HIP kernels, so autograd never reduces the dense gradient for the bias)."""
 
     @staticmethod
-    def forward(ctx, strides, anchors, slots, M, gains, balance, n_pred, n_root, *tensors):
+    def forward(ctx, strides, anchors, slots, M, gains, balance, n_pred, n_root, n_head, *tensors):
         lib = _lib.load()
-        preds, roots, biases = tensors[:n_pred], tensors[n_pred:n_pred + n_root], tensors[n_pred + n_root:]
+        preds, roots = tensors[:n_pred], tensors[n_pred:n_pred + n_root]
+        heads, biases = tensors[n_pred + n_root:n_pred + n_root + 2 * n_head], tensors[n_pred + n_root + 2 * n_head:]
         preds_d = [p.detach() for p in preds]
         st = _yolo_levels(preds_d, strides, anchors)
         B = preds[0].shape[0]
@@ -532,21 +533,26 @@ class _YoloLossFn(torch.autograd.Function):
         with _timed("yolo_loss_fwd"):
             check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
                                        C.byref(cfg), _ptr(out), _ptr(ws), wsb, _stream(out)), "hd_yolo_loss_fwd")
-        ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d)
+        # heads: (x, weight) of the Detect convolution that produced each level's padded rows (ops.head_conv): backward then
+        # writes the logit gradient as BF16 padded rows and runs the convolutions' backward itself (see yolo_loss)
+        ctx.save_for_backward(slot_cell, slot_tbox, slot_cls, ws, *preds_d, *heads)
         # roots: the tensors autograd differentiates when the predictions are (detached) strided views of padded rows
         # (ops.head_conv): gradient buffers then take the root's geometry and the views are re-derived on them
         root_meta = [(tuple(r.shape), tuple(r.stride()), p.storage_offset() - r.storage_offset()) for r, p in zip(roots, preds)]
         ctx.meta = (strides, anchors, int(M), gains, balance, wsb, n_pred,
-                    [(tuple(b.shape), b.dtype) for b in biases], root_meta)
+                    [(tuple(b.shape), b.dtype) for b in biases], root_meta, n_head)
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
     @staticmethod
     def backward(ctx, grad_total, _grad_parts):
         lib = _lib.load()
-        slot_cell, slot_tbox, slot_cls, ws, *preds = ctx.saved_tensors
-        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta, root_meta = ctx.meta
+        slot_cell, slot_tbox, slot_cls, ws, *saved = ctx.saved_tensors
+        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta, root_meta, n_head = ctx.meta
+        preds, heads = saved[:n_pred], saved[n_pred:]
         st = _yolo_levels(preds, strides, anchors)
+        if n_head:
+            return _YoloLossFn._backward_through_heads(ctx, grad_total, st, preds, heads, slot_cell, slot_tbox, slot_cls, ws)
         # gradient tensors keep the producer's memory order (dense channels-last fast path)
         groots = None
         if root_meta:
@@ -574,14 +580,47 @@ class _YoloLossFn(torch.autograd.Function):
                                        _stream(gs)), "hd_yolo_loss_bwd_pos")
         bias_grads = tuple(gbias[l].view(shape).to(dtype) for l, (shape, dtype) in enumerate(bias_meta))
         if groots is not None:
-            return (None,) * 8 + (None,) * n_pred + tuple(groots) + bias_grads
-        return (None,) * 8 + tuple(grads) + bias_grads
+            return (None,) * 9 + (None,) * n_pred + tuple(groots) + bias_grads
+        return (None,) * 9 + tuple(grads) + bias_grads
+
+    @staticmethod
+    def _backward_through_heads(ctx, grad_total, st, preds, heads, slot_cell, slot_tbox, slot_cls, ws):
+        """The logit gradient as bf16 padded rows (hd_yolo_loss_bwd_*_bf16) and, from them, the Detect convolutions' data and
+        weight gradients (hd_head_conv_bwd): no float32 gradient tensor, no cast."""
+        lib = _lib.load()
+        strides, anchors, M, gains, balance, wsb, n_pred, bias_meta, root_meta, n_head = ctx.meta
+        dev = preds[0].device
+        B = preds[0].shape[0]
+        dys = []
+        gst = YoloLevels()
+        C.memmove(C.byref(gst), C.byref(st), C.sizeof(YoloLevels))
+        for l, p in enumerate(preds):
+            _, na, H, W, no = p.shape
+            P = p.stride(3)
+            dy = torch.empty((B, P, H, W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            dys.append(dy)
+            gst.pred[l] = dy.data_ptr()
+        cfg = _loss_cfg(gains[0], gains[1], gains[2], balance, gains[3] if len(gains) > 3 else None)
+        gs = grad_total.detach().to(_F32).reshape(1).contiguous()
+        gbias = torch.zeros((len(preds), st.na * st.no), dtype=_F32, device=dev) if bias_meta else None
+        with _timed("yolo_loss_bwd_dense"):
+            check(lib.hd_yolo_loss_bwd_dense_bf16(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws),
+                                                  wsb, _stream(gs)), "hd_yolo_loss_bwd_dense_bf16")
+        check(lib.hd_yolo_loss_bwd_pos_bf16(C.byref(st), C.byref(gst), B, M, _ptr(slot_cell), _ptr(slot_tbox), _ptr(slot_cls),
+                                            C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws), wsb, _stream(gs)),
+              "hd_yolo_loss_bwd_pos_bf16")
+        head_grads = []
+        for l, dy in enumerate(dys):
+            dx, dw = head_conv_bwd_rows(dy, heads[2 * l], heads[2 * l + 1])
+            head_grads += [dx, dw]
+        bias_grads = tuple(gbias[l].view(shape).to(dtype) for l, (shape, dtype) in enumerate(bias_meta))
+        return (None,) * 9 + (None,) * n_pred + tuple(head_grads) + bias_grads
 
 
 def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, box_gain: float = 0.05,
               obj_gain: float = 1.0, cls_gain: float = 0.5, balance=(4.0, 1.0, 0.4),
               biases: Optional[Sequence[torch.Tensor]] = None, focal=None,
-              roots: Optional[Sequence[torch.Tensor]] = None):
+              roots: Optional[Sequence[torch.Tensor]] = None, heads: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None):
     """Returns (total, parts[4] = (total, lbox, lobj, lcls) detached).
 
     ``focal``: None, or dict(gamma=1.5, alpha=0.25, terms=("cls", "obj")) / the same as a tuple — the
@@ -593,14 +632,31 @@ def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, bo
 
     ``roots``: one tensor per level of which ``preds[l]`` is a DETACHED strided view (the padded float32 rows of
     ops.head_conv: [B, pitch, H, W] channels-last, viewed as [B, na, H, W, no]); the gradient then flows to the roots,
-    allocated with their geometry and written through the same views, padding columns zero."""
+    allocated with their geometry and written through the same views, padding columns zero.
+
+    ``heads``: instead of ``roots``, per level the (x, weight) the padded rows were computed from by ops.head_conv
+    (x [B, Cin, H, W] bf16 channels-last rows, weight the bf16 [Cout, Cin, 1, 1] leaf).  The loss then differentiates the
+    Detect convolutions itself: its backward writes the logit gradient as BF16 padded rows (rounded once; cells matched by
+    several targets accumulate in bf16 — hd_yolo_loss_bwd_*_bf16) and hands them to hd_head_conv_bwd, so the gradient flows
+    to x and weight without a float32 gradient tensor or a cast.  ``preds`` must be the padded-row views of those outputs."""
     biases = tuple(biases) if biases is not None else ()
     roots = tuple(roots) if roots is not None else ()
+    heads = tuple(heads) if heads is not None else ()
     if roots and len(roots) != len(preds):
         raise _lib.HdError("yolo_loss: `roots` needs one tensor per prediction level")
+    if heads:
+        if roots or len(heads) != len(preds):
+            raise _lib.HdError("yolo_loss: `heads` needs one (x, weight) pair per prediction level and excludes `roots`")
+        for p, (x, w) in zip(preds, heads):
+            P = p.stride(3)
+            if (p.dim() != 5 or p.stride(4) != 1 or P != head_conv_pitch(int(w.shape[0])) or P % 8
+                    or p.shape[1] * p.shape[4] != w.shape[0] or not head_conv_supported(x, w)):
+                raise _lib.HdError("yolo_loss: `heads` needs predictions that are views of ops.head_conv's padded rows")
+    flat_heads = [t for pair in heads for t in pair]
+    detached = bool(roots) or bool(heads)
     return _YoloLossFn.apply(tuple(strides), tuple(tuple(tuple(a) for a in lv) for lv in anchors), slots, int(M),
                              (box_gain, obj_gain, cls_gain, _focal_tuple(focal)), tuple(balance), len(preds), len(roots),
-                             *[p.detach() for p in preds] if roots else preds, *roots, *biases)
+                             len(heads), *[p.detach() for p in preds] if detached else preds, *roots, *flat_heads, *biases)
 
 
 def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,
@@ -1303,6 +1359,8 @@ class HeadConvSwitch:
     """The Detect convolutions on the HIP kernels (hd_head_conv_fwd / hd_head_conv_bwd, padded float32 rows).  HD_HEAD_CONV=0:
     the library's biased convolution + cast, as in rounds 1-3."""
     enabled = os.environ.get("HD_HEAD_CONV", "1") != "0"
+    # the loss writes its logit gradient as bf16 padded rows and runs the Detect convolutions' backward itself (yolo_loss(heads=))
+    bf16_grad = os.environ.get("HD_HEAD_GRAD_BF16", "1") != "0"
 
 
 def head_conv_pitch(cout: int) -> int:
@@ -1370,31 +1428,40 @@ class _HeadConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        lib = _lib.load()
         x, weight = ctx.saved_tensors
-        N, K = weight.shape[0], weight.shape[1]
-        B, _, H, W = x.shape
-        R = B * H * W
         dy = gy.to(torch.bfloat16)
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
-        if ld_dy is None or ld_x is None or dy.shape[1] != head_conv_pitch(N):
-            raise _lib.HdError("head_conv backward: the gradient must have the padded channels-last rows of the output")
-        dx = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-        dw = torch.empty((N, K), dtype=torch.bfloat16, device=x.device)
-        nbytes = lib.hd_head_conv_bwd_workspace_bytes(R, K, N)
-        ws = _wgrad_workspace(x.device, nbytes)
-        pend = _WgradChain.piggyback(x.device)
-        job = _lib.WgradJob()
-        P = dy.shape[1]
-        _note_bytes("head_conv_bwd", 2 * (R * (P + 2 * K) + 2 * N * K), {"flops": 4 * R * K * P, "shape": (R, K, N)})
-        with _ktimed("head_conv_bwd"):
-            check(lib.hd_head_conv_bwd(_ptr(dy), int(ld_dy), _ptr(weight), _ptr(x), int(ld_x), R, K, N, _ptr(dx), K, _ptr(dw),
-                                       _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
-                                       _stream(x)), "hd_head_conv_bwd")
-        _WgradChain.submit(x.device, job, (ws,), weight)
-        return dx, dw.view(N, K, 1, 1), None
+        dx, dw = head_conv_bwd_rows(dy, x, weight)
+        return dx, dw, None
+
+
+def head_conv_bwd_rows(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor):
+    """(dx [B, Cin, H, W] bf16, dw like `weight` bf16) of the Detect convolution from dy [B, pitch, H, W] bf16 channels-last
+    rows whose padding channels are zero; one launch, the weight gradient's slice sum chained as for every other layer
+    (_WgradChain; complete after the next weight-gradient launch or flush_wgrad())."""
+    lib = _lib.load()
+    N, K = weight.shape[0], weight.shape[1]
+    B, _, H, W = x.shape
+    R = B * H * W
+    ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
+    if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or dy.shape[1] != head_conv_pitch(N)
+            or tuple(dy.shape[2:]) != (H, W) or dy.shape[0] != B):
+        raise _lib.HdError("head_conv backward: the gradient must have the padded bf16 channels-last rows of the output")
+    dx = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=x.device)
+    nbytes = lib.hd_head_conv_bwd_workspace_bytes(R, K, N)
+    ws = _wgrad_workspace(x.device, nbytes)
+    pend = _WgradChain.piggyback(x.device)
+    job = _lib.WgradJob()
+    P = dy.shape[1]
+    _note_bytes("head_conv_bwd", 2 * (R * (P + 2 * K) + 2 * N * K), {"flops": 4 * R * K * P, "shape": (R, K, N)})
+    with _ktimed("head_conv_bwd"):
+        check(lib.hd_head_conv_bwd(_ptr(dy), int(ld_dy), _ptr(weight), _ptr(x), int(ld_x), R, K, N, _ptr(dx), K, _ptr(dw),
+                                   _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
+                                   _stream(x)), "hd_head_conv_bwd")
+    _WgradChain.submit(x.device, job, (ws,), weight)
+    return dx, dw.view(weight.shape)
 
 
 def head_conv(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

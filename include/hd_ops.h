@@ -308,6 +308,21 @@ hd_status hd_yolo_loss_bwd_pos(const hd_yolo_levels* lv, const hd_yolo_levels* g
                                const float* grad_scale, float* grad_bias, const void* workspace,
                                size_t workspace_bytes, hd_stream stream);
 
+/* The same two stages for a BFLOAT16 gradient: grad_lv->pred[l] points at bfloat16 elements (behind the declared float
+ * pointer) with grad_lv's element strides, which must describe padded pixel rows — so == 1, sa == no, sx = pitch with
+ * pitch % 8 == 0, rows contiguous, 16-byte aligned — and lv must be dense channels-last (plain or padded): the layout of
+ * hd_head_conv_fwd's output, whose backward (hd_head_conv_bwd) takes exactly these rows, padding columns zero.  The
+ * objectness term is rounded once; the box / class terms of a matched cell are added with the packed bfloat16 atomic add
+ * (global_atomic_pk_add_bf16) on the element's 32-bit word, every addition rounded (cells matched by several targets
+ * accumulate in bfloat16, as a half-precision index_put_(accumulate) would).  grad_bias sums the unrounded terms in float32 as before. */
+hd_status hd_yolo_loss_bwd_dense_bf16(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B,
+                                      const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                                      const void* workspace, size_t workspace_bytes, hd_stream stream);
+hd_status hd_yolo_loss_bwd_pos_bf16(const hd_yolo_levels* lv, const hd_yolo_levels* grad_lv, int B, int M,
+                                    const int32_t* slot_cell, const float* slot_tbox, const int32_t* slot_cls,
+                                    const hd_yolo_loss_cfg* cfg, const float* grad_scale, float* grad_bias,
+                                    const void* workspace, size_t workspace_bytes, hd_stream stream);
+
 /* ---- CIoU on matched pairs (SURVEY.md §8a "CIoU loss fwd + bwd") ----------- */
 
 /* pred, target [P,4] xyxy; ciou [P]; loss = 1 - ciou is left to the caller.

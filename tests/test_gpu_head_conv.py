@@ -146,9 +146,10 @@ def test_yolov5_head_trains_through_head_conv_like_the_library_path(gpu):
     cls = torch.randint(0, 80, (B, 5), generator=g, dtype=torch.int32).to(gpu)
     valid = torch.full((B,), 5, dtype=torch.int32, device=gpu)
     out, root_grads = {}, []
-    was_on, was = layers.LowpWeights.on, ops.HeadConvSwitch.enabled
+    was_on, was, was16 = layers.LowpWeights.on, ops.HeadConvSwitch.enabled, ops.HeadConvSwitch.bf16_grad
     try:
         layers.LowpWeights.on = True
+        ops.HeadConvSwitch.bf16_grad = False    # the float32 logit gradient flows through the padded rows, where the hooks sit
         for ours in (False, True):
             ops.HeadConvSwitch.enabled = ours
             fs = [f.clone().requires_grad_(True) for f in feats]
@@ -167,7 +168,7 @@ def test_yolov5_head_trains_through_head_conv_like_the_library_path(gpu):
             out[ours] = (float(total.detach()), [f.grad.float().clone() for f in fs],
                          [m.weight_lp.grad.float().clone() for m in head.m], [m.bias.grad.clone() for m in head.m])
     finally:
-        layers.LowpWeights.on, ops.HeadConvSwitch.enabled = was_on, was
+        layers.LowpWeights.on, ops.HeadConvSwitch.enabled, ops.HeadConvSwitch.bf16_grad = was_on, was, was16
     assert abs(out[True][0] - out[False][0]) <= 2e-3 * abs(out[False][0])
     assert len(root_grads) == 3
     by_hw = {tuple(g_.shape[2:]): g_ for g_ in root_grads}
@@ -187,3 +188,52 @@ def test_yolov5_head_trains_through_head_conv_like_the_library_path(gpu):
         for a, b in zip(out[True][k], out[False][k]):
             cos = float((a * b).sum() / (a.norm() * b.norm()))
             assert cos >= 0.95, (k, cos)
+
+
+def test_bf16_logit_gradient_rows_match_the_float32_gradient_path(gpu):
+    """ops.yolo_loss(heads=...) — the loss backward writes bf16 padded rows and runs hd_head_conv_bwd itself — against
+    ops.yolo_loss(roots=...) (float32 rows, cast once by ops.head_conv's backward) on the same logits.  The two round the same
+    float32 value once, except in cells matched by several targets, whose box / class terms accumulate in bf16 (one extra
+    rounding, 2^-9 relative, per addition).  Bounds: same loss (same forward kernels, sums differ by atomic order: 1e-6); dx, dw
+    within 2^-7 of the tensor's max and 2e-3 rel-L2; bias gradients (float32 sums of unrounded terms in both) 1e-5."""
+    from heltondetection_amd import ops
+    from heltondetection_amd.heads import YOLOV5_ANCHORS
+    torch.manual_seed(11)
+    B, nc, na = 8, 80, 3
+    no, N = nc + 5, na * (nc + 5)
+    strides, sizes, chans = (8.0, 16.0, 32.0), ((16, 16), (8, 8), (4, 4)), (128, 256, 512)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M = 12                                                   # many targets on a 128 px image: cells matched more than once
+    cxy = torch.rand(B, M, 2, generator=g) * 128
+    wh = torch.rand(B, M, 2, generator=g) * 40 + 6
+    boxes = torch.cat([cxy - wh / 2, cxy + wh / 2], -1).clamp(0, 128).to(gpu)
+    cls = torch.randint(0, nc, (B, M), generator=g, dtype=torch.int32).to(gpu)
+    valid = torch.full((B,), M, dtype=torch.int32, device=gpu)
+    slots = ops.yolo_assign([(na, h, w, no) for h, w in sizes], strides, YOLOV5_ANCHORS, boxes, cls, valid)
+    assert int((slots[0] >= 0).sum()) > 0
+    feats = [_rows(B, c, h, w, gpu) for c, (h, w) in zip(chans, sizes)]
+    ws = [(torch.randn(N, c, 1, 1, device=gpu) / c ** 0.5).to(torch.bfloat16) for c in chans]
+    bs = [torch.randn(N, device=gpu) * 0.1 - 3.0 for _ in chans]
+    out = {}
+    for lowp in (False, True):
+        xs = [f.clone().requires_grad_(True) for f in feats]
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        bl = [b.clone().requires_grad_(True) for b in bs]
+        roots, preds = [], []
+        for x, w, b in zip(xs, wl, bl):
+            y = ops.head_conv(x, w, b)
+            Bn, P, H, W = y.shape
+            roots.append(y)
+            preds.append(y.as_strided((Bn, na, H, W, no), (H * W * P, no, W * P, P, 1)))
+        kw = dict(heads=list(zip(xs, wl))) if lowp else dict(roots=roots)
+        total, parts = ops.yolo_loss(preds, strides, YOLOV5_ANCHORS, slots, M, biases=bl, **kw)
+        total.backward()
+        ops.flush_wgrad()
+        out[lowp] = (parts.clone(), [x.grad.float() for x in xs], [w.grad.float() for w in wl], [b.grad.clone() for b in bl])
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=0.0)
+    for k in (1, 2):
+        for a, b in zip(out[True][k], out[False][k]):
+            assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+            assert float((a - b).norm() / b.norm()) <= 2e-3
+    for a, b in zip(out[True][3], out[False][3]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
