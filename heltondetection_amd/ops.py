@@ -1097,6 +1097,57 @@ def _fwd_sums(slot: "_StatSlot", channels: int) -> torch.Tensor:
     return sums
 
 
+class WgradOverlap:
+    """The 3x3 weight gradients on a SECOND stream.  In backward the data gradient is the critical path (the next layer's
+    BatchNorm backward waits for it); a 3x3 layer's weight gradient (MFMA-bound, 20-60 us) is needed only when its bucket is
+    reduced or the optimizer runs.  With `active` (set by train.Trainer around backward) ops.conv3x3_wgrad_rows forks a side
+    stream at the point of the call — the side stream waits for everything enqueued so far, i.e. for dy and x — launches there
+    and returns; the main stream goes on with the data gradient and the HBM-bound BatchNorm kernels of the following layers,
+    which leave the matrix pipes idle.  `join()` (from flush_wgrad(): before a bucket is packed, at the end of backward) makes
+    the current stream wait for the side stream.  Under hipGraph capture the fork / join become graph edges: the captured
+    step holds two branches.  The side lane has its own slice-sum chain and slabs (_WgradChain lane 1): a job never rides in a
+    launch of the other stream.  Tensors handed to the side stream stay referenced until the join (the caching allocator may
+    hand a freed block to the main stream at once).
+    OFF by default (HD_WGRAD_OVERLAP=1 switches it on): measured on the YOLOv5s 640^2 bs16 step, hipGraph replay, the 15 forks
+    and joins made the step SLOWER, 5.28 -> 5.62 ms — every cross-branch edge of a replayed hipGraph is a barrier packet between
+    hardware queues, and the concurrent MFMA-bound weight gradient takes CUs from the data gradient it was meant to hide
+    behind."""
+    enabled = os.environ.get("HD_WGRAD_OVERLAP", "0") == "1"
+    active = False
+    _side: dict = {}
+    _forked: set = set()
+    _keep: list = []
+
+    @classmethod
+    def lane(cls, device) -> int:
+        return 1 if (cls.enabled and cls.active and device.type == "cuda") else 0
+
+    @classmethod
+    def side_stream(cls, device):
+        key = _WgradChain._key(device)
+        st = cls._side.get(key)
+        if st is None:
+            st = cls._side[key] = torch.cuda.Stream(torch.device(key[0], key[1]))
+        return st
+
+    @classmethod
+    def fork(cls, device, *keep):
+        """-> the side stream, ordered behind everything enqueued on the current stream so far."""
+        st = cls.side_stream(device)
+        st.wait_stream(torch.cuda.current_stream(device))
+        cls._forked.add(_WgradChain._key(device))
+        cls._keep.extend(keep)
+        return st
+
+    @classmethod
+    def join(cls) -> None:
+        for key in list(cls._forked):
+            dev = torch.device(key[0], key[1])
+            torch.cuda.current_stream(dev).wait_stream(cls._side[key])
+        cls._forked.clear()
+        cls._keep.clear()
+
+
 class _WgradChain:
     """Weight gradients are computed as row-sliced float32 partial products (a slab) plus their sum over the slices.  Inside
     a training step (`enabled`, set by train.Trainer around backward) the sum of layer L does not get a launch of its own:
@@ -1119,9 +1170,10 @@ class _WgradChain:
         return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
     @classmethod
-    def slab(cls, device, nbytes: int) -> torch.Tensor:
-        """A slab of >= nbytes that is NOT the one the pending job's partial products live in."""
-        key = cls._key(device)
+    def slab(cls, device, nbytes: int, lane: int = 0) -> torch.Tensor:
+        """A slab of >= nbytes that is NOT the one the pending job's partial products live in.  lane 1: the side stream's own
+        pair and chain (WgradOverlap)."""
+        key = cls._key(device) + ((lane,) if lane else ())
         pair = cls._slabs.setdefault(key, [None, None])
         pend = cls._pending.get(key)
         busy = pend[1][0] if pend is not None else None
@@ -1143,19 +1195,19 @@ class _WgradChain:
                   "hd_wgrad_reduce")
 
     @classmethod
-    def piggyback(cls, device):
+    def piggyback(cls, device, lane: int = 0):
         """The pending job of `device` (to ride in the launch being prepared), or None."""
-        pend = cls._pending.pop(cls._key(device), None)
+        pend = cls._pending.pop(cls._key(device) + ((lane,) if lane else ()), None)
         return pend
 
     @classmethod
-    def submit(cls, device, job, keep, leaf=None) -> None:
+    def submit(cls, device, job, keep, leaf=None, lane: int = 0) -> None:
         """`job` (a filled WgradJob) has been launched: chain it, or sum it right away.  Chained only inside a training step
         AND when the gradient goes to an autograd LEAF (the bf16 weight shadow): AccumulateGrad takes a leaf's first gradient
         as it is and nothing reads it before the bucket is packed; a non-leaf weight (autocast's cast of a float32 master)
         has its gradient cast back by the very next autograd node, which must see the finished sum."""
         if cls.enabled and leaf is not None and leaf.is_leaf:
-            cls._pending[cls._key(device)] = (job, keep)
+            cls._pending[cls._key(device) + ((lane,) if lane else ())] = (job, keep)
             if leaf is not None:
                 import weakref
                 cls._handed.append((weakref.ref(leaf), int(job.dw)))
@@ -1177,12 +1229,20 @@ class _WgradChain:
         aborted step are lost, which is what an aborted step means."""
         cls._pending.clear()
         cls._handed.clear()
+        WgradOverlap._forked.clear()
+        WgradOverlap._keep.clear()
 
     @classmethod
     def flush(cls) -> None:
         for key, (job, keep) in list(cls._pending.items()):
-            cls._reduce_now(job, torch.device(key[0], key[1]))
+            dev = torch.device(key[0], key[1])
+            if len(key) > 2:   # the side lane's last job: summed on the side stream, behind the launch that produced it
+                with torch.cuda.stream(WgradOverlap.side_stream(dev)):
+                    cls._reduce_now(job, dev)
+            else:
+                cls._reduce_now(job, dev)
         cls._pending.clear()
+        WgradOverlap.join()
         # a chained gradient is complete only after the launch that carried its sum: autograd must have taken the returned
         # tensor as it is (AccumulateGrad steals a fresh dense gradient); a copy taken earlier would hold unsummed bytes
         for ref, ptr in cls._handed:
@@ -1200,9 +1260,9 @@ def flush_wgrad() -> None:
     _WgradChain.flush()
 
 
-def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
+def _wgrad_workspace(device, nbytes: int, lane: int = 0) -> torch.Tensor:
     """One of the device's two float32 slabs (see _WgradChain), at least `nbytes` long."""
-    return _WgradChain.slab(device, nbytes)
+    return _WgradChain.slab(device, nbytes, lane)
 
 
 def _bn_bwd_struct(st: "_BNState", y_raw: torch.Tensor, g_: "_BNGrad", dg: Optional[torch.Tensor]):
@@ -1492,19 +1552,23 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: 
     nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N, int(stride))
     if nbytes == 0:
         raise _lib.HdError("conv3x3_wgrad: output W must be 20, 40 or 80, channel counts multiples of 64, stride 1 or 2")
-    ws = _wgrad_workspace(dy.device, nbytes)   # the other slab of the pair: a pending chained job stays intact
+    # inside a training step with a leaf to hand the gradient to: the side stream (WgradOverlap), with its own chain
+    lane = WgradOverlap.lane(dy.device) if (_WgradChain.enabled and leaf is not None and leaf.is_leaf) else 0
+    ws = _wgrad_workspace(dy.device, nbytes, lane)   # the other slab of the pair: a pending chained job stays intact
     dw = out if out is not None else torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     if dw.dtype != torch.bfloat16 or tuple(dw.shape) != (N, K, 3, 3) or not dw.is_contiguous(memory_format=torch.channels_last):
         raise _lib.HdError("conv3x3_wgrad: `out` must be a channels-last bf16 [Cout, Cin, 3, 3] tensor")
-    pend = _WgradChain.piggyback(dy.device)
+    pend = _WgradChain.piggyback(dy.device, lane)
     job = _lib.WgradJob()
     _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K),
                 {"flops": 18 * B * H * W * K * N, "shape": (B, H, W, K, N, stride)})
-    with _ktimed("conv3x3_wgrad"):
+    # (dw is NOT among the tensors kept until the join: a second reference would make autograd copy it; the leaf holds it)
+    where = torch.cuda.stream(WgradOverlap.fork(dy.device, dy, x, ws)) if lane else contextlib.nullcontext()
+    with where, _ktimed("conv3x3_wgrad"):
         check(lib.hd_conv3x3_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
                                            ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job), _stream(dy)),
               "hd_conv3x3_wgrad_partial")
-    _WgradChain.submit(dy.device, job, (ws,), leaf)
+    _WgradChain.submit(dy.device, job, (ws,), leaf, lane)
     return dw
 
 

@@ -128,3 +128,41 @@ def test_flipped_weights_of_all_layers_in_one_launch_equal_flip_permute():
             assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
             assert torch.equal(got, want)
     assert ops.FlippedWeights.get(ws[0]) is None
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones():
+    """ops.WgradOverlap (off by default, HD_WGRAD_OVERLAP=1): three chained 3x3 weight gradients launched on the side stream,
+    interleaved with main-stream work that overwrites nothing they read, joined by flush_wgrad() — bit-identical to the same
+    three launched in line (same kernels, same slices; the side lane has its own slabs and slice-sum chain)."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4, 64, 40, 40, 64), (4, 128, 20, 20, 128), (4, 64, 80, 80, 64)]
+    data = []
+    for B, K, H, W, N in shapes:
+        x = torch.randn((B, K, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn((B, N, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        data.append((dy, x))
+    out = {}
+    was = (ops.WgradOverlap.enabled, ops.WgradOverlap.active, ops._WgradChain.enabled)
+    try:
+        for side in (False, True):
+            ops.WgradOverlap.enabled = ops.WgradOverlap.active = side
+            ops._WgradChain.enabled = True
+            leaves = [torch.empty((s[4], s[1], 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+                      .requires_grad_(True) for s in shapes]
+            dws = []
+            for (dy, x), leaf in zip(data, leaves):
+                dws.append(ops.conv3x3_wgrad_rows(dy, x, leaf=leaf))
+                (x.float() * 2).sum()                      # unrelated main-stream work between the launches
+            assert (len(ops.WgradOverlap._forked) > 0) == side
+            ops._WgradChain._handed.clear()                # no autograd here: nobody takes the tensors as .grad
+            ops.flush_wgrad()
+            assert len(ops.WgradOverlap._forked) == 0 and not ops.WgradOverlap._keep
+            torch.cuda.synchronize()
+            out[side] = [d.clone() for d in dws]
+    finally:
+        ops.WgradOverlap.enabled, ops.WgradOverlap.active, ops._WgradChain.enabled = was
+        ops._WgradChain.reset()
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
