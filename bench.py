@@ -601,19 +601,31 @@ def family_rooflines(model, batch, args, device, trainer=None):
 
 
 def yolo_dense_grad_roofline(model, batch, args):
+    """The dense pass of the loss backward in the form the measured step runs it: with bf16 weight shadows (the default) the
+    gradient leaves as bf16 rows padded to the Detect convolution's pitch (hd_yolo_loss_bwd_dense_bf16: 2 * B * pixels * pitch
+    bytes written + the 4-byte objectness residual per cell read); --fp32: float32 rows of the predictions' own layout."""
     from heltondetection_amd import ops
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
         preds = model.head(model.extract(batch[0]))
     head = model.head
     shapes = [(head.na, p.shape[2], p.shape[3], head.no) for p in preds]
     slots = head.assigner(shapes, head.strides, head.anchors, batch[1], batch[2], batch[3])
+    pitch = ops.head_conv_pitch(head.na * head.no)
+    lowp = (not args.fp32) and ops.HeadConvSwitch.enabled and ops.HeadConvSwitch.bf16_grad and pitch > 0 and pitch % 8 == 0
     ms_list = ops.time_yolo_loss_bwd_dense(preds, head.strides, head.anchors, slots, batch[2].shape[1],
-                                           (head.box_gain, head.obj_gain, head.cls_gain), head.balance, iters=20)
+                                           (head.box_gain, head.obj_gain, head.cls_gain), head.balance, iters=20, bf16_rows=lowp)
     k_ms = sum(ms_list) / max(len(ms_list), 1)
-    nbytes = loss_bwd_bytes(args.batch, args.size, args.classes + 5)
-    return _hbm_entry("yolo_grad_dense_kernel (hd_yolo_loss_bwd_dense)", k_ms * len(ms_list), nbytes * len(ms_list), len(ms_list),
+    if lowp:
+        cells = sum(head.na * p.shape[2] * p.shape[3] for p in preds) * args.batch
+        nbytes = 2 * (cells // head.na) * pitch + 4 * cells
+        name = "yolo_grad_dense_bf16_kernel (hd_yolo_loss_bwd_dense_bf16: bf16 rows padded to %d channels)" % pitch
+    else:
+        nbytes = loss_bwd_bytes(args.batch, args.size, args.classes + 5)
+        name = "yolo_grad_dense_kernel (hd_yolo_loss_bwd_dense)"
+    return _hbm_entry(name, k_ms * len(ms_list), nbytes * len(ms_list), len(ms_list),
                       {"timed": "every launch stamps its own HIP event pair (kernel begin / end) on this workload's head outputs"},
-                      traffic=pmc_traffic("yolo_grad_dense_kernel") if (args.size == 640 and args.batch == 16 and args.classes == 80) else None)
+                      traffic=pmc_traffic("yolo_grad_dense_bf16_kernel" if lowp else "yolo_grad_dense_kernel")
+                      if (args.size == 640 and args.batch == 16 and args.classes == 80) else None)
 
 
 def roi_touched_elements(rois5, feats, scales, k_min, n_levels):

@@ -660,30 +660,50 @@ def yolo_loss(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, bo
 
 
 def time_yolo_loss_bwd_dense(preds: Sequence[torch.Tensor], strides, anchors, slots, M: int, gains, balance,
-                             iters: int = 20) -> List[float]:
-    """Measurement helper for bench.py: runs the loss forward once on `preds`, then launches
-    hd_yolo_loss_bwd_dense `iters` times on the current stream, each launch stamping its own HIP event pair with
-    the kernel's begin / end (hd_profile_time_next_launch).  Returns the per-launch milliseconds."""
+                             iters: int = 20, bf16_rows: bool = False) -> List[float]:
+    """Measurement helper for bench.py: runs the loss forward once on `preds`, then launches the dense gradient pass `iters`
+    times on the current stream, each launch stamping its own HIP event pair with the kernel's begin / end
+    (hd_profile_time_next_launch).  Returns the per-launch milliseconds.  bf16_rows: the form the training step runs —
+    the predictions re-laid as float32 rows padded to head_conv_pitch, the gradient as bf16 padded rows
+    (hd_yolo_loss_bwd_dense_bf16); otherwise float32 gradient tensors with the predictions' own strides."""
     lib = _lib.load()
     preds = [p.detach() for p in preds]
+    dev = preds[0].device
+    if bf16_rows:
+        padded = []
+        for p in preds:
+            B, na, H, W, no = p.shape
+            P = head_conv_pitch(na * no)
+            root = torch.zeros((B, H, W, P), dtype=_F32, device=dev)
+            root[..., : na * no] = p.permute(0, 2, 3, 1, 4).reshape(B, H, W, na * no)
+            padded.append(root.as_strided((B, na, H, W, no), (H * W * P, no, W * P, P, 1)))
+        preds = padded
     st = _yolo_levels(preds, strides, anchors)
     B = preds[0].shape[0]
     cfg = _loss_cfg(gains[0], gains[1], gains[2], balance)
-    dev = preds[0].device
     out = torch.empty((4,), dtype=_F32, device=dev)
     ws, wsb = _ws(lib.hd_yolo_loss_workspace_bytes(C.byref(st), B), dev)
     s = _stream(out)
     check(lib.hd_yolo_loss_fwd(C.byref(st), B, int(M), _ptr(slots[0]), _ptr(slots[1]), _ptr(slots[2]), C.byref(cfg),
                                _ptr(out), _ptr(ws), wsb, s), "hd_yolo_loss_fwd")
-    grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=dev) for p in preds]
-    gst = _yolo_levels(grads, strides, anchors)
+    if bf16_rows:
+        grads = [torch.empty((B, p.stride(3), p.shape[2], p.shape[3]), dtype=torch.bfloat16, device=dev,
+                             memory_format=torch.channels_last) for p in preds]
+        gst = YoloLevels()
+        C.memmove(C.byref(gst), C.byref(st), C.sizeof(YoloLevels))
+        for l, g in enumerate(grads):
+            gst.pred[l] = g.data_ptr()
+        fn, name = lib.hd_yolo_loss_bwd_dense_bf16, "hd_yolo_loss_bwd_dense_bf16"
+    else:
+        grads = [torch.empty_strided(p.shape, p.stride(), dtype=_F32, device=dev) for p in preds]
+        gst = _yolo_levels(grads, strides, anchors)
+        fn, name = lib.hd_yolo_loss_bwd_dense, "hd_yolo_loss_bwd_dense"
     gs = torch.ones(1, dtype=_F32, device=dev)
     gbias = torch.zeros((len(preds), st.na * st.no), dtype=_F32, device=dev)
     evs = []
     for i in range(iters + 3):
         pair = _arm_kernel_timing()
-        check(lib.hd_yolo_loss_bwd_dense(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws),
-                                         wsb, s), "hd_yolo_loss_bwd_dense")
+        check(fn(C.byref(st), C.byref(gst), B, C.byref(cfg), _ptr(gs), _ptr(gbias), _ptr(ws), wsb, s), name)
         if i >= 3:
             evs.append(pair)
     torch.cuda.synchronize(dev)
