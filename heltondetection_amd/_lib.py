@@ -160,6 +160,9 @@ SIGNATURES = {
     "hd_adamw_multi": (_I, [_P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "hd_maxpool5_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_maxpool5_bwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "hd_sppf_pools_supported": (_I, [_I, _I, _I, _I, _I]),
+    "hd_sppf_pools_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P]),
+    "hd_sppf_pools_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "hd_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_bn_act_replicas": (C.c_int, []),

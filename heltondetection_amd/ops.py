@@ -903,6 +903,79 @@ def maxpool5(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return _MaxPool5Fn.apply(x, _OutSlot(out) if out is not None else None)
 
 
+class SppfPoolsSwitch:
+    """SPPF's three chained 5x5 pools as one launch each way (csrc/pool.hip: sppf_pools_*), the image plane in LDS.
+    OFF by default (HD_SPPF_FUSED=1 switches it on): exact (tests/test_gpu_sppf_pools.py) but slower on the 20 x 20 level of
+    YOLOv5s 640^2 bs16 — forward 57 us against 3 x 13 us, backward 105 us against 3 x 17 us + three 6 us adds, step 5.28 ->
+    5.32 ms.  One workgroup per (image, 16 channels) is 256 workgroups of 4 waves: one wave per SIMD runs the 25-tap compare
+    chains (1000 VALU operations per output vector) with nothing to overlap its LDS and dependency latency, while the separate
+    kernels put 12 waves on every CU; the HBM bytes saved (every map read once) were never the bound — the unfused kernels
+    are bound by L1 / L2 re-reads and VALU in equal parts."""
+    enabled = os.environ.get("HD_SPPF_FUSED", "0") == "1"
+
+
+class _SppfPoolsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s1, s2, s3):
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        dt = {torch.float32: 0, torch.bfloat16: 1}[x.dtype]
+        vec = 4 if dt == 0 else 8
+        outs = []
+        for s_ in (s1, s2, s3):
+            outs.append(s_.t if s_ is not None else torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device,
+                                                                  memory_format=torch.channels_last))
+        lds = [_cl_row_stride(t, vec) for t in (x, *outs)]
+        if any(l is None for l in lds):
+            raise _lib.HdError("sppf_pools: input / outputs must be (channel slices of) channels-last tensors")
+        idx = [torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device) for _ in range(3)]
+        check(lib.hd_sppf_pools_fwd(_ptr(x), int(lds[0]), dt, B, H, W, Cc, _ptr(outs[0]), int(lds[1]), _ptr(outs[1]), int(lds[2]),
+                                    _ptr(outs[2]), int(lds[3]), _ptr(idx[0]), _ptr(idx[1]), _ptr(idx[2]), _stream(x)),
+              "hd_sppf_pools_fwd")
+        ctx.save_for_backward(*idx)
+        ctx.meta = (dt, B, H, W, Cc)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        lib = _lib.load()
+        idx = ctx.saved_tensors
+        dt, B, H, W, Cc = ctx.meta
+        want = torch.float32 if dt == 0 else torch.bfloat16
+        vec = 4 if dt == 0 else 8
+        gs, lds = [], []
+        for g in (g1, g2, g3):
+            if g is None:
+                g = torch.zeros((B, Cc, H, W), dtype=want, device=idx[0].device, memory_format=torch.channels_last)
+            ld = _cl_row_stride(g, vec)
+            if ld is None or g.dtype != want:
+                g = g.to(want).contiguous(memory_format=torch.channels_last)
+                ld = Cc
+            gs.append(g)
+            lds.append(ld)
+        dx = torch.empty((B, Cc, H, W), dtype=want, device=gs[0].device, memory_format=torch.channels_last)
+        check(lib.hd_sppf_pools_bwd(_ptr(gs[0]), int(lds[0]), _ptr(gs[1]), int(lds[1]), _ptr(gs[2]), int(lds[2]), _ptr(idx[0]),
+                                    _ptr(idx[1]), _ptr(idx[2]), dt, B, H, W, Cc, _ptr(dx), _stream(dx)), "hd_sppf_pools_bwd")
+        return dx, None, None, None
+
+
+def sppf_pools_supported(x: torch.Tensor) -> bool:
+    if not (SppfPoolsSwitch.enabled and maxpool5_supported(x)):
+        return False
+    B, Cc, H, W = x.shape
+    return bool(_lib.load().hd_sppf_pools_supported(0 if x.dtype == torch.float32 else 1, B, H, W, Cc))
+
+
+def sppf_pools(x: torch.Tensor, outs: Optional[Sequence[Optional[torch.Tensor]]] = None):
+    """(y1, y2, y3) = the three chained 5x5 / stride 1 / pad 2 max-pools of SPPF in one launch (one more for the backward of all
+    three, branch gradients included); outs: three CatBuffer slots (or None) to write them into.  Values, tap indices and —
+    up to the float32 intermediate sums — gradients equal maxpool5(maxpool5(maxpool5(x)))'s."""
+    if not sppf_pools_supported(x):
+        raise _lib.HdError("sppf_pools: needs a channels-last float32 / bfloat16 HIP tensor whose plane fits LDS")
+    outs = tuple(outs) if outs is not None else (None, None, None)
+    return _SppfPoolsFn.apply(x, *[_OutSlot(o) if o is not None else None for o in outs])
+
+
 class _MaxPool3s2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

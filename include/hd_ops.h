@@ -383,6 +383,20 @@ hd_status hd_maxpool5_fwd(const void* in, int64_t in_row_stride, int dtype, int 
                           void* out, int64_t out_row_stride, uint8_t* idx, hd_stream stream);
 hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, const uint8_t* idx, int dtype,
                           int B, int H, int W, int C, void* grad_in, hd_stream stream);
+/* SPPF's chain of three 5x5 pools (reference README.md:9, CSPDarknet's SPPF block) in ONE launch each way: y1 = pool(x),
+ * y2 = pool(y1), y3 = pool(y2), with the tap indices of all three (idx1..3, dense [B,H,W,C] uint8 as for hd_maxpool5_fwd).
+ * A workgroup keeps one image's H x W plane of 16 (bfloat16) / 8 (float32) channels in LDS, so every value is read from HBM
+ * once; values and indices equal three hd_maxpool5_fwd calls bit for bit.  Backward: dx = gather(g1 + gather(g2 +
+ * gather(g3, idx3), idx2), idx1) with the two intermediate sums kept in float32 (the separate calls round them to the tensor's
+ * dtype and leave the two additions to the caller).  Row strides as for hd_maxpool5_*; dx is dense.
+ * hd_sppf_pools_supported: C % 16 (bfloat16) / C % 8 (float32) == 0 and the planes fit the 160 KB of LDS (H x W <= 1241). */
+int hd_sppf_pools_supported(int dtype, int B, int H, int W, int C);
+hd_status hd_sppf_pools_fwd(const void* x, int64_t x_row_stride, int dtype, int B, int H, int W, int C, void* y1,
+                            int64_t y1_row_stride, void* y2, int64_t y2_row_stride, void* y3, int64_t y3_row_stride,
+                            uint8_t* idx1, uint8_t* idx2, uint8_t* idx3, hd_stream stream);
+hd_status hd_sppf_pools_bwd(const void* g1, int64_t g1_row_stride, const void* g2, int64_t g2_row_stride, const void* g3,
+                            int64_t g3_row_stride, const uint8_t* idx1, const uint8_t* idx2, const uint8_t* idx3, int dtype, int B,
+                            int H, int W, int C, void* dx, hd_stream stream);
 /* 3x3 / stride 2 / pad 1 max-pool (the ResNet50 stem, reference README.md:8) on DENSE channels-last tensors: in [B, H, W, C]
  * -> out [B, Ho, Wo, C] with Ho = (H - 1) / 2 + 1; idx: one byte per OUTPUT element (winning tap 0..8), dense.  Backward is
  * the gather form (an input pixel sits under at most 2 x 2 windows): grad_in [B, H, W, C] from grad_out / idx, no atomics. */
