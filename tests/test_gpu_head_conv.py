@@ -237,3 +237,30 @@ def test_bf16_logit_gradient_rows_match_the_float32_gradient_path(gpu):
             assert float((a - b).norm() / b.norm()) <= 2e-3
     for a, b in zip(out[True][3], out[False][3]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_head_conv_takes_a_channel_slice_as_input(gpu):
+    """x as a channel slice of a wider channels-last tensor (row stride 2 Cin — a concatenation's slot): forward and backward
+    must equal the dense copy's bit for bit (same kernels, another row stride)."""
+    from heltondetection_amd import ops
+    torch.manual_seed(4)
+    B, K, H, W, N = 2, 128, 9, 11, 255
+    wide = _rows(B, 2 * K, H, W, gpu)
+    xs = wide[:, K:]
+    xd = xs.contiguous(memory_format=torch.channels_last)
+    assert xs.stride(3) == 2 * K and not xs.is_contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(N, K, 1, 1, device=gpu) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=gpu)
+    gy = torch.zeros((B, ops.head_conv_pitch(N), H, W), device=gpu).contiguous(memory_format=torch.channels_last)
+    gy[:, :N] = torch.randn(B, N, H, W, device=gpu)
+    out = []
+    for x in (xs, xd):
+        xx = x.detach().requires_grad_(True)
+        ww = w.clone().requires_grad_(True)
+        assert ops.head_conv_supported(xx, ww)
+        y = ops.head_conv(xx, ww, b)
+        y.backward(gy)
+        ops.flush_wgrad()
+        out.append((y.detach().clone(), xx.grad.clone(), ww.grad.clone()))
+    for a, c in zip(out[0], out[1]):
+        assert torch.equal(a, c)
