@@ -42,24 +42,36 @@ class YOLOv5PAFPN(nn.Module):
         self.out_channels = (c3, c4, c5)
 
     @staticmethod
-    def _down_cat(down: ConvBNAct, x: torch.Tensor, lateral: torch.Tensor) -> torch.Tensor:
+    def _down_cat(down: ConvBNAct, x: torch.Tensor, lateral: torch.Tensor, cb=None) -> torch.Tensor:
         """cat(down(x), lateral): the strided conv's fused BN+act writes its half of the concatenation in place; the
-        lateral (which has other consumers) is copied in, as torch.cat would."""
-        cb = cat_buffer(x, (down.conv.out_channels, lateral.shape[1]), lateral.shape[2:])
+        lateral (which has other consumers) is copied in, as torch.cat would — unless the caller made the buffer `cb` before
+        the lateral was computed and had it written into slot 1 then (YOLOv5PAFPN.forward): join() finds it in place."""
+        if cb is None:
+            cb = cat_buffer(x, (down.conv.out_channels, lateral.shape[1]), lateral.shape[2:])
         if cb is None:
             return torch.cat((down(x), lateral), 1)
         return cb.join((down(x, None, cb.slot(0)), lateral))
+
+    @staticmethod
+    def _lateral_into_cat(lat: ConvBNAct, down: ConvBNAct, x: torch.Tensor):
+        """lat(x) written straight into slot 1 of the bottom-up concatenation cat(down(.), lat(x)) it will join later — the
+        top-down path reads it there as a channel slice (hd_upsample2x_cat takes row strides), so the copy torch.cat would make
+        (6.9 + 5.4 us per YOLOv5s step) never runs.  -> (lateral, buffer or None)."""
+        cb = cat_buffer(x, (down.conv.out_channels, lat.conv.out_channels), x.shape[2:])
+        if cb is None:
+            return lat(x), None
+        return lat(x, None, cb.slot(1)), cb
 
     _up_cat = staticmethod(lambda small, big: up_cat(small, big))
 
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         p3, p4, p5 = feats
-        l5 = self.lat5(p5)
+        l5, cb5 = self._lateral_into_cat(self.lat5, self.down4, p5)
         t4 = self.td4(self._up_cat(l5, p4))
-        l4 = self.lat4(t4)
+        l4, cb4 = self._lateral_into_cat(self.lat4, self.down3, t4)
         o3 = self.td3(self._up_cat(l4, p3))
-        o4 = self.bu4(self._down_cat(self.down3, o3, l4))
-        o5 = self.bu5(self._down_cat(self.down4, o4, l5))
+        o4 = self.bu4(self._down_cat(self.down3, o3, l4, cb4))
+        o5 = self.bu5(self._down_cat(self.down4, o4, l5, cb5))
         return [self.drop(o3), self.drop(o4), self.drop(o5)]
 
 
