@@ -492,6 +492,7 @@ extern "C" hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, con
 // padded gradient, ops.head_conv casts it); the kernel runs the padded reduction against weight rows that read as zeros past
 // Cout, and the weight gradient keeps Cout rows.
 extern "C" int hd_head_conv_pitch(int Cout) {
+  if (Cout < 1) return 0;
   for (int p = 32; p <= 256; p <<= 1)
     if (Cout <= p) return p;
   return 0;

@@ -84,3 +84,21 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in txt and "import oracle" not in txt and "hd_oracle" not in txt.replace(
                     "oracle/hd_oracle.c", ""), f"{f} references the oracle"
+
+
+def test_detect_convolution_host_arithmetic_and_validation():
+    """hd_head_conv_*: the padded pitch, the support predicates and the argument checks are host code (no GPU touched)."""
+    from heltondetection_amd import _lib
+    lib = _lib.load()
+    assert [lib.hd_head_conv_pitch(c) for c in (1, 18, 32, 33, 75, 128, 129, 255, 256)] == [32, 32, 32, 64, 128, 128, 256, 256, 256]
+    assert lib.hd_head_conv_pitch(257) == 0 and lib.hd_head_conv_pitch(0) == 0
+    assert lib.hd_head_conv_fwd_supported(102400, 128, 255) == 1
+    assert lib.hd_head_conv_fwd_supported(6400, 512, 255) == 1          # two K-slices of 256
+    assert lib.hd_head_conv_fwd_supported(6400, 192, 255) == 0          # no resident-weight form: the library runs the forward
+    assert lib.hd_head_conv_bwd_supported(6400, 192, 255) == 1
+    assert lib.hd_head_conv_bwd_supported(6400, 128, 300) == 0
+    assert lib.hd_head_conv_bwd_workspace_bytes(102400, 128, 255) == lib.hd_pointwise_bwd_workspace_bytes(102400, 128, 256) > 0
+    assert lib.hd_head_conv_fwd(None, 0, None, None, 64, 128, 255, None, 0, None) == -1          # HD_ERR_NULL
+    assert lib.hd_sppf_pools_supported(1, 16, 20, 20, 256) == 1
+    assert lib.hd_sppf_pools_supported(1, 16, 80, 80, 256) == 0         # the planes do not fit LDS
+    assert lib.hd_sppf_pools_supported(1, 16, 20, 20, 24) == 0          # 16 channels per workgroup
