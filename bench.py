@@ -15,7 +15,12 @@ Two guards keep a corrupted graph run from being reported (finite loss, replay-v
 steps are re-timed eagerly and config.hip_graph_error says so.  A graph run that is merely SLOW (replays slower
 than the eager steps they replace) is reported as measured and flagged (config.hip_graph_slow_replay), never hidden.
 
-Extra objects in that line:
+The stdout line is COMPACT (< 4 KB, compact_line): the contract's keys, the headline `roofline` (every kernel of the family as
+[fraction of its bound, summed ms per step]), `cpu_baseline`, one short entry per secondary roofline and per companion leg.  It
+is printed once as soon as the headline, its rooflines and the CPU baseline are in hand and again, completed, as the last thing
+the process writes.  The full record described below goes to bench_detail.json (next to this file and under gpurun_out/).
+
+Objects of the full record:
   roofline      the hand-written kernel FAMILY with the largest summed launch time in the step (the convolution family:
                 1x1 forward / one-launch 1x1 backward / 3x3 / stem kernels), step-weighted: algorithmic bytes of all its
                 launches / their summed HIP-event time, measured live on the model's real layer shapes; every kernel of the
@@ -227,8 +232,8 @@ def cpu_baseline(args):
         opt.step()
 
     # SURVEY.md section 8d protocol, scaled to the bounded sample the bench contract allows (about 10-30 s of CPU work):
-    # 2 untimed warm-up steps, then 20 individually timed steps (fewer only past 45 s), the MEDIAN step time is what is reported
-    warm, want, budget_s = 2, 20, 45.0   # SURVEY.md section 8d asks for >= 20 timed iterations
+    # 2 untimed warm-up steps, then 20 individually timed steps (fewer only past 30 s), the MEDIAN step time is what is reported
+    warm, want, budget_s = 2, 20, 30.0   # SURVEY.md section 8d asks for >= 20 timed iterations
     load0 = os.getloadavg()[0] if hasattr(os, "getloadavg") else None
     for i in range(warm):
         print(f"[bench cpu] warm-up step {i} ...", file=sys.stderr, flush=True)
@@ -238,7 +243,8 @@ def cpu_baseline(args):
         t0 = time.perf_counter()
         step()
         per.append(time.perf_counter() - t0)
-        print(f"[bench cpu] step {len(per)}: {per[-1]:.2f} s", file=sys.stderr, flush=True)
+        if len(per) % 5 == 0:
+            print(f"[bench cpu] {len(per)} steps timed, last {per[-1]:.2f} s", file=sys.stderr, flush=True)
     srt = sorted(per)
     med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
@@ -336,7 +342,7 @@ def micro_kernels(device):
         return ts[len(ts) // 2]
 
     def add(name, ms, nbytes, shape, bound="hbm", tkey=None):
-        print(f"[bench micro] {name} {shape}: {ms:.4f} ms", file=sys.stderr, flush=True)
+        print(f"[bench micro] {name[:40]} {shape[:48]}: {ms:.4f} ms", file=sys.stderr, flush=True)
         gbs = nbytes / ms / 1e6
         res.append({"kernel": name, "shape": shape, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 2),
                     "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / HBM_PEAK_GBS, 4), "bound": bound})
@@ -832,6 +838,99 @@ def run_leg(args, device, rank, world, log, steps, warmup, tag=""):
             "slow_replay": slow_replay, "eager_ms": eager_ms, "extra_setup": extra_setup, "steps": steps, "warmup": warmup}
 
 
+COMPACT_LIMIT = 4096   # bytes: the driver keeps only a tail of stdout + stderr, a 35 KB line lost the round-4 record
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "\u2026"
+
+
+def _compact_roofline(r):
+    """The keys of a roofline object the bench contract names (+ what locates the measurement), strings cut short."""
+    if not isinstance(r, dict):
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
+            "algorithmic_bytes_per_step", "sum_launch_ms_per_step", "traffic")
+    d = {"kernel": _short(r.get("kernel", ""), 72)}
+    d.update({k: r[k] for k in keep if k in r})
+    pk = r.get("per_kernel")
+    if isinstance(pk, dict):   # every kernel of the family against its own bound: [fraction, summed ms per step]
+        d["per_kernel_frac_ms"] = {k: [v.get("frac"), v.get("sum_ms", v.get("ms"))] for k, v in pk.items()
+                                   if isinstance(v, dict) and (v.get("sum_ms") or v.get("ms"))}
+    return d
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line of the bench contract, at most COMPACT_LIMIT bytes: the contract's keys, the headline `roofline` and
+    `cpu_baseline`, one short entry per secondary roofline and per companion leg.  Everything else (per-shape tables, the
+    micro-kernel list, the legs' full rooflines) goes to the detail file named in `detail`."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+           "dtype", "data")
+    c = {k: out[k] for k in top if k in out}
+    cfg = dict(out.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload", ""), 160)
+    c["config"] = cfg
+    for k in ("final_loss", "ms_per_step_packed", "eff_vs_packed_n1", "roofline_error", "kernels_error"):
+        if k in out:
+            c[k] = out[k] if not isinstance(out[k], str) else _short(out[k], 120)
+    if "roofline" in out:
+        c["roofline"] = _compact_roofline(out["roofline"])
+    sec = out.get("roofline_secondary") or []
+    if sec:
+        c["roofline_secondary"] = [{"kernel": _short(r.get("kernel", ""), 40), "bound": r.get("bound"), "frac": r.get("frac"),
+                                    "achieved": r.get("achieved"), "unit": r.get("unit"),
+                                    "ms": r.get("sum_launch_ms_per_step", r.get("avg_launch_ms"))} for r in sec if isinstance(r, dict)]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = {k: (_short(v, 150) if isinstance(v, str) else v) for k, v in cb.items()
+                             if k in ("value", "unit", "cores", "kind", "cpu_model", "threads", "sample", "loadavg_1min_before")}
+    legs = {}
+    for name in LEG_NAMES:
+        l = out.get(name)
+        if not isinstance(l, dict):
+            continue
+        e = {k: l[k] for k in ("ms_per_step", "value", "dtype", "hip_graph") if k in l}
+        if "skipped" in l or "error" in l:
+            e["note"] = _short(l.get("skipped", l.get("error")), 80)
+        if isinstance(l.get("roofline"), dict):
+            e["roofline_frac"] = l["roofline"].get("frac")
+            e["roofline_kernel"] = _short(l["roofline"].get("kernel", ""), 32)
+        legs[name] = e
+    if legs:
+        c["legs"] = legs
+    if detail_path:
+        c["detail"] = detail_path
+    line = json.dumps(c, separators=(",", ":"))
+    # never exceed the limit: drop the optional parts, least important first
+    for victim in ("roofline_secondary", "legs"):
+        if len(line) <= COMPACT_LIMIT:
+            break
+        c.pop(victim, None)
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT and isinstance(c.get("roofline"), dict):
+        c["roofline"].pop("per_kernel_frac_ms", None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+LEG_NAMES = ("packed", "fp32", "size_832", "frcnn_832", "frcnn_1280_visdrone")
+
+
+def write_detail(out):
+    """Full record (per-shape tables, micro kernels, the legs' rooflines) next to bench.py and, on a gpurun box, under gpurun_out/
+    so that it travels back; returns the path written into the compact line."""
+    name = "bench_detail.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    return name
+
+
 T_START = time.perf_counter()
 
 
@@ -874,7 +973,7 @@ def main():
         def _beat():
             t0 = time.time()
             while True:
-                time.sleep(45)
+                time.sleep(90)
                 log(f"heartbeat {int(time.time() - t0)} s")
         threading.Thread(target=_beat, daemon=True).start()
 
@@ -939,6 +1038,27 @@ def main():
                 out["roofline_secondary"] = fams[1:] + [roi_align_roofline(model, batches[0], args, device)]
         except Exception as e:  # never lose the headline number to a secondary measurement
             out["roofline_error"] = repr(e)[:300]
+        # The CPU baseline comes BEFORE the companion legs: everything the bench contract requires is then in hand and is printed
+        # once right away (a later time-limit kill inside a leg cannot lose the headline); the completed line follows at the end.
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args) if args.model == "yolov5" else cpu_baseline_frcnn(args)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)[:200]}
+        if world > 1:
+            # scaling efficiency is the driver's to compute; what this line adds is the N = 1 figure of the SAME per-rank program
+            # (gradients packed into buckets), if an N = 1 run on this checkout left it behind (bench_n1_packed.json)
+            try:
+                n1 = json.load(open(os.path.join(ROOT, "bench_n1_packed.json")))
+                if n1.get("workload") == out["config"]["workload"].split(" train step")[0]:
+                    out["ms_per_step_packed_n1"] = n1["ms_per_step_packed"]
+                    out["eff_vs_packed_n1"] = round(n1["ms_per_step_packed"] / out["ms_per_step"], 4)
+            except Exception:
+                pass
+        has_more = world == 1 and (not args.no_micro or not args.no_legs)
+        if has_more:
+            write_detail(out)
+            print(compact_line(out, "bench_detail.json (partial: companion legs still running)"), flush=True)
         if world == 1 and not args.no_micro:
             try:
                 out["kernels"] = micro_kernels(device)
@@ -1010,12 +1130,16 @@ def main():
                             os.environ[k] = v
             if "packed" in out and "ms_per_step" in out["packed"]:
                 out["ms_per_step_packed"] = out["packed"]["ms_per_step"]
-        if world == 1 and not args.no_cpu_baseline:
-            if args.model == "yolov5":
-                out["cpu_baseline"] = cpu_baseline(args)
-            else:
-                out["cpu_baseline"] = cpu_baseline_frcnn(args)
-        print(json.dumps(out), flush=True)
+                out["eff_vs_packed_n1"] = round(out["packed"]["ms_per_step"] / out["ms_per_step"], 4)   # N = 1: direct vs packed
+        detail = write_detail(out)
+        if world == 1 and "ms_per_step_packed" in out:
+            try:
+                with open(os.path.join(ROOT, "bench_n1_packed.json"), "w") as f:
+                    json.dump({"workload": out["config"]["workload"].split(" train step")[0],
+                               "ms_per_step_packed": out["ms_per_step_packed"], "ms_per_step": out["ms_per_step"]}, f)
+            except OSError:
+                pass
+        print(compact_line(out, detail), flush=True)   # the LAST thing this process writes
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

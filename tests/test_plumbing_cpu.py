@@ -203,3 +203,46 @@ def test_bucket_plan_overlaps_most_of_the_gradient_bytes_and_keeps_the_exposed_t
     # explicit sizes still work (tests, configs): 1 MB buckets over 10 x 0.5 MB
     plan = plan_buckets([1 << 19] * 10, 1 << 20, 1 << 19, 1 << 19)
     assert plan == [[0], [1, 2], [3, 4], [5, 6], [7, 8], [9]]
+
+
+def _load_bench():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hd_bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_stdout_line_is_compact_and_round_trips():
+    """Round 4's driver record was lost because the one JSON line had grown to 35 KB and the driver keeps a ~14 KB tail.
+    bench.compact_line must stay under 4096 bytes whatever the detail record holds, parse back, and keep every key the bench
+    contract names plus `roofline` and `cpu_baseline`.  Fed with the committed full record of round 4 and with a bloated one."""
+    import json
+    import os
+    bench, root = _load_bench()
+    full = json.loads(open(os.path.join(root, "profiles", "r04_bench_default.log")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 30000
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 5000
+    fat["roofline"]["kernel"] = "k" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["roofline_secondary"] = fat["roofline_secondary"] * 40
+    fat["frcnn_832"] = {"error": "e" * 3000}
+    for rec in (full, fat):
+        line = bench.compact_line(rec, "bench_detail.json")
+        assert "\n" not in line and len(line.encode()) < bench.COMPACT_LIMIT <= 4096
+        back = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in back, k
+        assert back["value"] == rec["value"] and back["ms_per_step"] == rec["ms_per_step"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert back["roofline"][k] == rec["roofline"][k]
+        assert back["roofline"]["frac"] == round(back["roofline"]["achieved"] / back["roofline"]["peak"], 4)
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in back["cpu_baseline"]
+        assert "workload" in back["config"]
+    legs = json.loads(bench.compact_line(full))["legs"]
+    assert set(legs) == set(bench.LEG_NAMES) and all("ms_per_step" in v for v in legs.values())
