@@ -499,8 +499,11 @@ __global__ __launch_bounds__(256) void roi_gather_prep_kernel(const hd_roi_level
   rec.img_lvl = (bi >= 0 && bi < batch) ? ((bi << 8) | l) : -1;
   // cells that can receive weight: floor(first sample) .. floor(last sample) + 1; widened by one more on both sides
   const int H = lv.h[l], W = lv.w[l];
-  const float y_lo = g.start_h, y_hi = g.start_h + (float)kGatherP * g.bin_h;
-  const float x_lo = g.start_w, x_hi = g.start_w + (float)kGatherP * g.bin_w;
+  // aligned = 1 does not clamp the RoI's extent: a malformed RoI (x2 < x1 or y2 < y1) has negative bins, its samples run
+  // DOWN from start.  The forward and the scatter backward include them, so the window is the span either way round.
+  const float y_e = g.start_h + (float)kGatherP * g.bin_h, x_e = g.start_w + (float)kGatherP * g.bin_w;
+  const float y_lo = fminf(g.start_h, y_e), y_hi = fmaxf(g.start_h, y_e);
+  const float x_lo = fminf(g.start_w, x_e), x_hi = fmaxf(g.start_w, x_e);
   const int y0 = max(0, min(H - 1, (int)floorf(fmaxf(y_lo, -4.0f)) - 1)), y1 = max(0, min(H - 1, (int)floorf(fminf(y_hi, (float)H + 4.0f)) + 2));
   const int x0 = max(0, min(W - 1, (int)floorf(fmaxf(x_lo, -4.0f)) - 1)), x1 = max(0, min(W - 1, (int)floorf(fminf(x_hi, (float)W + 4.0f)) + 2));
   rec.ywin = y0 | (y1 << 16);

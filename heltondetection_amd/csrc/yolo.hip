@@ -797,21 +797,25 @@ __global__ __launch_bounds__(256) void yolo_grad_dense_bf16_kernel(const hd_yolo
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < words; q += gridDim.x * blockDim.x) {
     const uint32_t pix = pow2 ? q >> sh : q / wpp;
     const uint32_t t = q - pix * wpp;
-    int a = -1;
-#pragma unroll
-    for (int a2 = 0; a2 < 4; ++a2) a = t == wa[a2] ? a2 : a;
-    for (int a2 = 4; a2 < na; ++a2) a = t == ((uint32_t)(a2 * no + 4) >> 3) ? a2 : a;
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (a >= 0) {
-      const float v = gobj * to[pix * (uint32_t)na + (uint32_t)a];
-      const uint32_t k = (uint32_t)(a * no + 4) & 7u;
+    // every anchor whose objectness channel a * no + 4 falls into this 8-channel word: with no < 8 (one or two classes) two
+    // anchors can share a word (no = 6: channels 16 and 22), so all of them are folded in, not just the last match
+    uint32_t r4[4] = {0u, 0u, 0u, 0u};
+    auto put = [&](int a2) {
+      const float v = gobj * to[pix * (uint32_t)na + (uint32_t)a2];
+      const uint32_t k = (uint32_t)(a2 * no + 4) & 7u;
       const uint32_t h = (uint32_t)GradBf16::round_bf16(v) << ((k & 1u) * 16u);
-      r.x = (k >> 1) == 0u ? h : 0u;
-      r.y = (k >> 1) == 1u ? h : 0u;
-      r.z = (k >> 1) == 2u ? h : 0u;
-      r.w = (k >> 1) == 3u ? h : 0u;
-      if (grad_bias) atomicAdd(&s_gb[a], v);   // the bias gradient sums the unrounded terms
-    }
+      r4[0] |= (k >> 1) == 0u ? h : 0u;
+      r4[1] |= (k >> 1) == 1u ? h : 0u;
+      r4[2] |= (k >> 1) == 2u ? h : 0u;
+      r4[3] |= (k >> 1) == 3u ? h : 0u;
+      if (grad_bias) atomicAdd(&s_gb[a2], v);   // the bias gradient sums the unrounded terms
+    };
+#pragma unroll
+    for (int a2 = 0; a2 < 4; ++a2)
+      if (t == wa[a2]) put(a2);
+    for (int a2 = 4; a2 < na; ++a2)
+      if (t == ((uint32_t)(a2 * no + 4) >> 3)) put(a2);
+    const uint4 r = make_uint4(r4[0], r4[1], r4[2], r4[3]);
     g4[q] = r;
   }
   if (grad_bias) {
@@ -829,7 +833,7 @@ inline unsigned dense_grid_x(const hd_yolo_levels& lv, const hd_yolo_levels& glv
   for (int l = 0; l < lv.n_levels; ++l) {
     const long long cells = ix.first_cell[l + 1] - ix.first_cell[l];
     const long long total = cells * lv.no;
-    const bool fast = fl.grad_dense[l] && fl.pred_dense[l];
+    const bool fast = (grad_dtype == 1 || fl.grad_dense[l]) && fl.pred_dense[l];
     const long long words = grad_dtype == 1 ? cells / lv.na * (glv.sx[l] / 8)
                             : fl.grad_dense[l] == 2 ? cells / lv.na * (glv.sx[l] / 4) : (total + 3) / 4;
     max_items = std::max(max_items, fast ? words : total);

@@ -58,7 +58,7 @@ class YOLOv5Head(nn.Module):
         views = []
         self._roots = self._head_in = None
         if (self.training and self.bias_grad_in_loss
-                and all(ops.head_conv_supported(f, conv.lp_weight()) for conv, f in zip(self.m, feats))):
+                and all(ops.head_conv_supported(f, conv.lp_weight(), conv.bias) for conv, f in zip(self.m, feats))):
             # training on the HIP Detect convolution (ops.head_conv): float32 rows padded to a 16-byte pitch (255 -> 256 channels),
             # read by the loss through [B, na, H, W, no] views; inside ops.yolo_loss autograd differentiates the padded rows
             # themselves (`_roots`, handed over by loss() below), so no cast, bias add, permute or slice runs in either

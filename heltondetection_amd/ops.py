@@ -1521,9 +1521,13 @@ def head_conv_pitch(cout: int) -> int:
     return int(_lib.load().hd_head_conv_pitch(int(cout)))
 
 
-def head_conv_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """bf16 channels-last rows, a dense bf16 [Cout, Cin, 1, 1] weight, Cout <= 256 and a backward the fused kernel takes.
+def head_conv_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> bool:
+    """bf16 channels-last rows, a dense bf16 [Cout, Cin, 1, 1] weight, Cout <= 256 and a backward the fused kernel takes;
+    `bias` (when given): float32, dense, on x's device, one entry per output channel — what hd_head_conv_fwd reads.
     (A forward the streaming kernel does not take — Cin not 32/64/128/256k — runs on the library with padded weights.)"""
+    if bias is not None and not (bias.dtype == _F32 and bias.device == x.device and bias.is_contiguous()
+                                 and bias.numel() == weight.shape[0]):
+        return False
     if not (HeadConvSwitch.enabled and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
             and weight.dtype == torch.bfloat16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1)
             and weight.shape[1] == x.shape[1] and weight.is_contiguous() and _cl_row_stride(x, 8) is not None):

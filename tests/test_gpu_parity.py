@@ -851,3 +851,223 @@ def test_roi_align_backward_gather_is_reproducible_and_equals_the_scatter(gpu, o
         assert bool((err <= tol * c.float().abs() + tol * c.float().abs().mean()).all()), float(err.max())
         assert bool((a[c == 0] == 0).all())                               # untouched cells are written as zeros
     assert any(bool((g[2, :, : g.shape[2] // 4] == 0).all()) for g in res["gather"])   # the empty region exists
+
+
+# ---- the DEFAULT training path against the oracle, directly -------------------------------------------------------------------
+# Training with bf16 weight shadows runs hd_head_conv_fwd (float32 rows padded to a pitch of 32 / 64 / 128 / 256) ->
+# hd_yolo_loss_fwd on the padded view -> hd_yolo_loss_bwd_dense_bf16 / _pos_bf16 (bf16 padded gradient rows, packed bf16 atomics
+# for cells matched more than once) -> hd_head_conv_bwd.  To compare THAT chain with co.yolo_loss on bit-identical logits, the
+# Detect convolution is given selection weights: every output channel n reads input channel(s) sel(n) with weight 1, so
+#   logits[n] = sum of the selected bf16 inputs (exact in float32, any order) + bias[n]   (one float32 rounding, as numpy's)
+#   dx[:, sel(n)] = the kernel's bf16 logit gradient of channel n, bit for bit (a sum of one non-zero product)
+# Bounds, written before the first GPU run:
+#   loss parts              1e-4 relative (TOL)
+#   logit gradient          element-wise one bf16 rounding of the oracle's float32 value: |got - g| <= 2^-8 |g| + 2^-8 median|g|
+#                           (helpers.assert_elem_close); an element of a cell matched by k >= 2 targets is summed in bf16 by k
+#                           packed atomics in any order: + k 2^-8 max|g over that cell's channels|
+#   bias gradient           float32 sums of the unrounded terms: 1e-5 of the level's max
+#   weight gradient         dY^T X with the kernel's own bf16 dY (read back through dx) in float64, one bf16 rounding: 2^-8 |dw| + 2^-8 median|dw|
+
+def _head_case(p_list, anchors_l, K_list, pieces=1, two_slice_level=None, bias_scale=0.0, seed=0):
+    """p_list: per level float32 [B, na, H, W, no] logits-before-bias; with pieces == 1 they must be bf16-representable, with
+    pieces == 3 any float32 (split into three bf16 pieces that sum back exactly).  Returns per level (x [B, K, H, W] bf16
+    channels-last, w [N, K, 1, 1] bf16 selection weights, bias [N] float32, sel [pieces][N] input channel of each piece)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for l, (p, K) in enumerate(zip(p_list, K_list)):
+        B, na, Hh, Ww, no = p.shape
+        N = na * no
+        rows = p.permute(0, 2, 3, 1, 4).reshape(B, Hh, Ww, N)           # channel n = a * no + c
+        parts, rest = [], rows.clone()
+        for _ in range(pieces):
+            hi = rest.to(torch.bfloat16)      # round to nearest: the signed remainder loses >= 8 bits per piece
+            parts.append(hi)
+            rest = rest - hi.float()
+        assert float(rest.abs().max()) == 0.0, "logits are not representable by the requested number of bf16 pieces"
+        sel = []
+        for q in range(pieces):
+            base = q * ((N + 31) // 32 * 32)
+            idx = torch.arange(N) + base
+            if two_slice_level == l:                                      # odd channels come from the second K-slice of 256
+                idx = idx + (torch.arange(N) % 2) * 256
+            sel.append(idx)
+        assert int(max(int(s.max()) for s in sel)) < K
+        x = torch.zeros(B, Hh, Ww, K, dtype=torch.bfloat16)
+        w = torch.zeros(N, K, dtype=torch.bfloat16)
+        for q in range(pieces):
+            x[..., sel[q]] = parts[q]
+            w[torch.arange(N), sel[q]] = 1.0
+        bias = (torch.randn(N, generator=g) * bias_scale).float()
+        out.append((x.permute(0, 3, 1, 2), w.view(N, K, 1, 1), bias, sel))
+    return out
+
+
+def _run_default_head_path(gpu, ops, case, strides, anchors, slots, M, na, no, gains=(0.05, 1.0, 0.5), focal=None):
+    xs, ws, bs, preds = [], [], [], []
+    for x, w, b, _ in case:
+        xd = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(gpu).requires_grad_(True)
+        bd = b.to(gpu).requires_grad_(True)
+        assert ops.head_conv_supported(xd, wd, bd)
+        y = ops.head_conv(xd, wd, bd)
+        B, P, Hh, Ww = y.shape
+        assert P == ops.head_conv_pitch(na * no) and P % 8 == 0
+        preds.append(y.as_strided((B, na, Hh, Ww, no), (Hh * Ww * P, no, Ww * P, P, 1)))
+        xs.append(xd), ws.append(wd), bs.append(bd)
+    total, parts = ops.yolo_loss(preds, strides, anchors, slots, M, *gains, biases=bs, heads=list(zip(xs, ws)), focal=focal)
+    logits = [p.detach().cpu().numpy().copy() for p in preds]
+    total.backward()
+    ops.flush_wgrad()
+    torch.cuda.synchronize()
+    return parts.cpu().numpy(), logits, [x.grad for x in xs], [w.grad for w in ws], [b.grad for b in bs]
+
+
+def _check_default_head_path(case, got, ref_loss, ref_grads, slot_cell, na, no, what):
+    parts, _, dxs, dws, dbs = got
+    assert H.max_rel_elem(parts, ref_loss, 1e-6) < TOL, (what, parts, ref_loss)
+    for l, ((x, w, b, sel), dx, dw, db, g) in enumerate(zip(case, dxs, dws, dbs, ref_grads)):
+        B, _, Hh, Ww, _ = g.shape
+        N = na * no
+        g_rows = np.ascontiguousarray(g.transpose(0, 2, 3, 1, 4)).reshape(B * Hh * Ww, N).astype(np.float64)
+        dx_rows = dx.float().permute(0, 2, 3, 1).reshape(B * Hh * Ww, -1).cpu().numpy().astype(np.float64)
+        # cells matched by k >= 2 targets: k bf16 atomic adds in any order
+        sc = slot_cell[l]
+        sc = sc[sc >= 0]
+        n_match = np.bincount(sc, minlength=B * na * Hh * Ww).reshape(B, na, Hh, Ww)
+        k_cell = np.ascontiguousarray(n_match.transpose(0, 2, 3, 1)).reshape(B * Hh * Ww, na)      # [row][anchor]
+        cell_max = np.abs(g_rows.reshape(-1, na, no)).max(-1)
+        extra = np.repeat(np.where(k_cell >= 2, k_cell, 0) * cell_max, no, axis=1) * 2.0 ** -8
+        nz = np.abs(g_rows[g_rows != 0])
+        floor = 2.0 ** -8 * float(np.median(nz))
+        for q, idx in enumerate(sel):
+            got_g = dx_rows[:, idx.numpy()]
+            tol = 2.0 ** -8 * np.abs(g_rows) + floor + extra
+            bad = np.abs(got_g - g_rows) > tol
+            assert not bad.any(), (what, l, q, int(bad.sum()), float((np.abs(got_g - g_rows) / tol).max()))
+        # input channels no output reads get no gradient
+        unused = np.ones(dx_rows.shape[1], bool)
+        for idx in sel:
+            unused[idx.numpy()] = False
+        assert float(np.abs(dx_rows[:, unused]).max() if unused.any() else 0.0) == 0.0
+        ref_b = g_rows.sum(0)
+        assert float(np.abs(db.cpu().numpy() - ref_b).max()) <= 1e-5 * float(np.abs(ref_b).max()), (what, l)
+        # weight gradient from the kernel's OWN bf16 logit gradient (as read back) and x, float64
+        dy_rows = dx_rows[:, sel[0].numpy()]
+        x_rows = x.float().permute(0, 2, 3, 1).reshape(B * Hh * Ww, -1).numpy().astype(np.float64)
+        H.assert_elem_close(dw.float().view(N, -1).cpu().numpy(), dy_rows.T @ x_rows, 2.0 ** -8, f"{what}: dw level {l}")
+    return True
+
+
+def _bf16_logits(B, size, na, no, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn((B, na, size // s, size // s, no), generator=g) * scale).to(torch.bfloat16).float() for s in H.YOLO_STRIDES]
+
+
+@pytest.mark.parametrize("nc,K_list,two_slice", [(80, (256, 256, 512), 2), (1, (32, 64, 128), None), (20, (128, 128, 256), None)])
+def test_default_training_head_path_against_the_oracle(gpu, ops, nc, K_list, two_slice):
+    """hd_head_conv_fwd -> loss on padded rows -> bf16 gradient rows -> hd_head_conv_bwd against co.yolo_assign + co.yolo_loss on
+    bit-identical float32 logits.  24 targets on a 128 px image: cells matched by three and more targets exist (asserted);
+    nc = 80: pitch 256, the 4 x 4 level with Cin = 512 (two K-slices of the forward); nc = 1: no = 6 < 8 channels per 16-byte
+    word (pitch 32); nc = 20: pitch 128."""
+    B, size, na, M = 2, 128, 3, 24
+    no = nc + 5
+    p_list = _bf16_logits(B, size, na, no, 300 + nc)
+    case = _head_case(p_list, H.YOLO_ANCHORS, K_list, 1, two_slice, bias_scale=0.5, seed=nc)
+    gtb, gtc, mv = _yolo_targets(B, size, nc, 301 + nc, "coco", M)
+    shapes = H.yolo_shapes(size, no)
+    rc, rt, rl = co.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, gtb.numpy(), gtc.numpy(), mv.numpy(), 4.0)
+    assert max(int(np.bincount(c[c >= 0]).max()) for c in rc if (c >= 0).any()) >= 3
+    slots = ops.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, dev(gtb, gpu), dev(gtc, gpu), dev(mv, gpu), 4.0)
+    got = _run_default_head_path(gpu, ops, case, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, M, na, no)
+    # the oracle's inputs: the float32 logits as numpy forms them (selected bf16 value + bias, one rounding) — and they must be
+    # the very bits hd_head_conv_fwd produced
+    logits = [(p.numpy() + c[2].numpy().reshape(1, na, 1, 1, no)).astype(np.float32) for p, c in zip(p_list, case)]
+    for a, b in zip(got[1], logits):
+        assert np.array_equal(a, b)
+    r_loss, r_grads, _, _ = co.yolo_loss(logits, H.YOLO_STRIDES, H.YOLO_ANCHORS, rc, rt, rl, M)
+    _check_default_head_path(case, got, r_loss, r_grads, rc, na, no, f"nc={nc}")
+
+
+def test_default_training_head_path_with_two_objectness_channels_in_one_word(gpu, ops):
+    """nc = 1 and FOUR anchors per level: no = 6, so anchors 2 and 3 have their objectness channels 16 and 22 in the same 8-channel
+    word of the bf16 gradient row (yolo_grad_dense_bf16_kernel must fold every anchor of a word; round 4's kernel kept the last
+    match only and dropped the other's objectness and bias gradient)."""
+    B, size, na, nc, M = 2, 128, 4, 1, 12
+    no = nc + 5
+    anchors = [[[10, 13], [16, 30], [33, 23], [20, 20]], [[30, 61], [62, 45], [59, 119], [50, 50]],
+               [[116, 90], [156, 198], [373, 326], [100, 100]]]
+    g = torch.Generator().manual_seed(77)
+    p_list = [(torch.randn((B, na, size // s, size // s, no), generator=g)).to(torch.bfloat16).float() for s in H.YOLO_STRIDES]
+    case = _head_case(p_list, anchors, (32, 32, 64), 1, None, bias_scale=0.5, seed=5)
+    gtb, gtc, mv = _yolo_targets(B, size, nc, 78, "coco", M)
+    shapes = [(na, size // s, size // s, no) for s in H.YOLO_STRIDES]
+    rc, rt, rl = co.yolo_assign(shapes, H.YOLO_STRIDES, anchors, gtb.numpy(), gtc.numpy(), mv.numpy(), 4.0)
+    slots = ops.yolo_assign(shapes, H.YOLO_STRIDES, anchors, dev(gtb, gpu), dev(gtc, gpu), dev(mv, gpu), 4.0)
+    assert np.array_equal(slots[0].cpu().numpy(), rc)
+    got = _run_default_head_path(gpu, ops, case, H.YOLO_STRIDES, anchors, slots, M, na, no)
+    logits = [(p.numpy() + c[2].numpy().reshape(1, na, 1, 1, no)).astype(np.float32) for p, c in zip(p_list, case)]
+    for a, b in zip(got[1], logits):
+        assert np.array_equal(a, b)
+    r_loss, r_grads, _, _ = co.yolo_loss(logits, H.YOLO_STRIDES, anchors, rc, rt, rl, M)
+    _check_default_head_path(case, got, r_loss, r_grads, rc, na, no, "na=4 nc=1")
+    # and specifically: every anchor's objectness gradient is there
+    for l, g_ in enumerate(r_grads):
+        dx = got[2][l].float().permute(0, 2, 3, 1).cpu().numpy()
+        for a in range(na):
+            ref = g_[:, a, :, :, 4]
+            assert np.abs(ref).max() > 0 and np.abs(dx[..., a * no + 4] - ref).max() <= 2.0 ** -7 * np.abs(ref).max(), (l, a)
+
+
+def test_golden_loss_case_through_the_default_training_head_path(gpu, ops):
+    """tests/golden/hotpath_v1.npz's loss case (arbitrary float32 logits, nc = 4) through the same chain: every logit is split into
+    three bf16 pieces that three selection weights add back exactly (Cin = 128), so hd_head_conv_fwd reproduces the fixture's
+    logits bit for bit; loss against y_loss, bf16 gradient rows against y_g*."""
+    gold = np.load(H.GOLDEN)
+    p_list = [torch.from_numpy(gold[f"y_p{l}"]) for l in range(3)]
+    B, na, _, _, no = p_list[0].shape
+    case = _head_case(p_list, H.YOLO_ANCHORS, (128, 128, 128), 3, None, bias_scale=0.0)
+    rc, rt, rl = gold["y_cell"], gold["y_tbox"], gold["y_cls"]
+    M = gold["y_gtc"].shape[1]
+    shapes = [(na, p.shape[2], p.shape[3], no) for p in p_list]
+    slots = ops.yolo_assign(shapes, H.YOLO_STRIDES, H.YOLO_ANCHORS, torch.from_numpy(gold["y_gtb"]).to(gpu),
+                            torch.from_numpy(gold["y_gtc"]).to(gpu), torch.from_numpy(gold["y_mv"]).to(gpu), 4.0)
+    assert np.array_equal(slots[0].cpu().numpy(), rc)
+    got = _run_default_head_path(gpu, ops, case, H.YOLO_STRIDES, H.YOLO_ANCHORS, slots, M, na, no)
+    for a, l in zip(got[1], range(3)):
+        assert np.array_equal(a, gold[f"y_p{l}"])
+    # the fixture was made with the default gains and grad_scale 1 (tests/golden/make_golden.py); tests/test_oracle.py pins the
+    # oracle to it on the CPU side
+    _check_default_head_path(case, got, gold["y_loss"], [gold[f"y_g{l}"] for l in range(3)], rc, na, no, "golden")
+
+
+def test_roi_align_backward_gather_takes_inverted_boxes_like_the_forward(gpu, ops):
+    """aligned = 1 does not clamp a RoI's extent: x2 < x1 or y2 < y1 gives negative bins whose samples run down from the start
+    corner.  The forward and the scatter backward include them; the gather's cell window must span them too (round 4's prep kernel
+    assumed bins >= 0 and dropped such a RoI's gradient).  Gather == scatter (float32 maps, 2e-5) and == the oracle's backward
+    (1e-4 element-wise) on a list with inverted boxes."""
+    strides = [4, 8, 16, 32]
+    B, C, size, R = 2, 64, 256, 40
+    feats, rois = _roi_case(913, B, C, size, R, strides)
+    inv = rois.clone()
+    inv[::3, 1], inv[::3, 3] = rois[::3, 3], rois[::3, 1]          # x inverted
+    inv[1::4, 2], inv[1::4, 4] = rois[1::4, 4], rois[1::4, 2]      # y inverted
+    scales = [1.0 / s for s in strides]
+    res = {}
+    go = None
+    for mode in ("gather", "scatter"):
+        ops.RoiBwdSwitch.gather = mode == "gather"
+        try:
+            fd = [dev(f, gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+            out = ops.roi_align(fd, dev(inv, gpu), 7, scales, 2, True, 2, 224.0 / 4, 4, channels_last_out=True)
+            if go is None:
+                go = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(gpu).contiguous(memory_format=torch.channels_last)
+            out.backward(go)
+            res[mode] = [f.grad.clone() for f in fd]
+        finally:
+            ops.RoiBwdSwitch.gather = True
+    ref = co.roi_align_bwd([tuple(f.shape) for f in feats], inv.numpy(), np.ascontiguousarray(go.cpu().numpy()), scales, 2, True, 2, 224.0 / 4, 4)
+    assert any(float(np.abs(r).max()) > 0 for r in ref)
+    for a, c, r in zip(res["gather"], res["scatter"], ref):
+        err = (a - c).abs()
+        assert bool((err <= 2e-5 * c.abs() + 2e-5 * c.abs().mean()).all()), float(err.max())
+        H.assert_elem_close(a.cpu().numpy(), r, TOL, "gather backward with inverted boxes")
