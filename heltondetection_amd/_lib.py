@@ -205,8 +205,38 @@ def load() -> C.CDLL:
     v = lib.hd_abi_version()
     if v != ABI_VERSION:
         raise HdError(f"libhd_ops.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
-    _lib = lib
-    return lib
+    trace = os.environ.get("HD_TRACE_CALLS")
+    _lib = _Traced(lib, trace) if trace else lib
+    return _lib
+
+
+class _Traced:
+    """HD_TRACE_CALLS=<file>: every launching hd_* call appends one line (name + its integer / float arguments) to <file> BEFORE
+    it is made.  With HIP_LAUNCH_BLOCKING=1 / AMD_SERIALIZE_KERNEL=3 the last line names the call whose kernel faulted.  Debugging
+    aid only; the queries (*_supported, *_bytes, ...) are not traced."""
+    _QUIET = ("_supported", "_bytes", "_pitch", "_resident", "_replicas", "_str", "_version", "_tune")
+
+    def __init__(self, lib, path):
+        self._lib = lib
+        self._f = open(path, "a", buffering=1)
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is not None:
+            return fn
+        raw = getattr(self._lib, name)
+        if not name.startswith("hd_") or name.endswith(self._QUIET):
+            fn = raw
+        else:
+            out = self._f
+
+            def fn(*a, _raw=raw, _name=name):
+                vals = [getattr(x, "value", x) for x in a]
+                out.write(_name + " " + " ".join(str(v) for v in vals if isinstance(v, (int, float))) + "\n")
+                return _raw(*a)
+        self._cache[name] = fn
+        return fn
 
 
 def check(status: int, what: str) -> None:
