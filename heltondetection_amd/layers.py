@@ -31,7 +31,61 @@ class ShadowConv2d(nn.Conv2d):
         return self.weight_lp if (LowpWeights.on and self.weight_lp is not None) else self.weight
 
     def forward(self, x):
-        return self._conv_forward(x, self.lp_weight(), self.bias)
+        w = self.lp_weight()
+        if (self.in_channels <= NO_SEARCH_MAX_CHANNELS and self.out_channels <= NO_SEARCH_MAX_CHANNELS and x.is_cuda
+                and torch.backends.cudnn.benchmark and self.padding_mode == "zeros"):
+            return _LibConvNoSearch.apply(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return self._conv_forward(x, w, self.bias)
+
+
+# Library convolutions whose input AND output channel counts are at most this run outside MIOpen's solver search.
+# Root cause of the round-4 / round-5 "Memory access fault by GPU" (profiles/r05_fault_hunt.md): with
+# torch.backends.cudnn.benchmark = True PyTorch calls miopenFindConvolution*Algorithm with exhaustiveSearch = true, and for a
+# problem without a perf-db record MIOpen then TUNES every applicable solver on the caller's tensors.  For YOLOv5n's
+# Conv2d(16, 16, 1) on a [2, 16, 40, 40] bf16 channels-last map the backward-data tuning of
+# ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC falls back to its "spare" set of 22 kernel configurations, one of which reads
+# past the end of an operand; it faults when that operand is the last block of a 2 MiB allocator segment (which is why the
+# same test alone passes).  No hand-written kernel is involved.  Such layers are a few microseconds either way, so they take
+# the library's immediate-mode choice instead.
+NO_SEARCH_MAX_CHANNELS = 16
+
+
+class _LibConvNoSearch(torch.autograd.Function):
+    """F.conv2d / convolution_backward with MIOpen's solver search switched off for the duration of the two calls."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation, groups):
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            xc, wc = x.to(dt), w.to(dt)
+            bc = bias.to(dt) if bias is not None else None
+        else:
+            xc, wc, bc = x, w, bias
+        ctx.save_for_backward(xc, wc)
+        ctx.conf = (tuple(stride), tuple(padding), tuple(dilation), int(groups), x.dtype, w.dtype,
+                    None if bias is None else bias.dtype)
+        was = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = False
+        try:
+            with torch.autocast("cuda", enabled=False):
+                return torch.nn.functional.conv2d(xc, wc, bc, stride, padding, dilation, groups)
+        finally:
+            torch.backends.cudnn.benchmark = was
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc = ctx.saved_tensors
+        stride, padding, dilation, groups, xdt, wdt, bdt = ctx.conf
+        mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], bdt is not None and ctx.needs_input_grad[2])
+        was = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = False
+        try:
+            gx, gw, gb = torch.ops.aten.convolution_backward(gy.to(xc.dtype), xc, wc, [wc.shape[0]] if bdt is not None else None,
+                                                             stride, padding, dilation, False, (0, 0), groups, mask)
+        finally:
+            torch.backends.cudnn.benchmark = was
+        return (gx.to(xdt) if gx is not None else None, gw.to(wdt) if gw is not None else None,
+                gb.to(bdt) if gb is not None else None, None, None, None, None)
 
 
 class FusedBNAct:
