@@ -136,7 +136,6 @@ def _worker_overlap(rank, world, port, tmp, use_graph):
     model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=128)).to(dev)
     model.load_state_dict(torch.load(os.path.join(tmp, "pretrained.pt")))   # off the chaotic random-init point (see the test)
     model = model.to(memory_format=torch.channels_last).train()
-    model.head.box_gain = 0.0   # the compared step runs without the box term: its gradient is DIScontinuous (see the test)
     # the SHIPPED bucket policy (dist.plan_buckets: VERDICT r03 #7 — the tests used to run with their own small buckets)
     tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=40, warmup_steps=0, device=dev,
                  use_graph=use_graph, graph_warmup=2, graph_sync=False)
@@ -237,13 +236,13 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     # first run of this form: every bucket's averaged gradient within 0.33 relative L2 (cosine >= 0.9) of the eager run's.  A
     # bucket that missed its all-reduce, was reduced before its segment finished, or lost a tensor is off by >= 1.0: it
     # cannot pass by a factor of three.
-    # The compared step runs with box_gain = 0 (pre-training keeps the box term): d(CIoU)/d(box) jumps where an edge of the
-    # predicted box crosses the target's (the min / max of intersection and enclosing box), so two runs whose logits differ by
-    # rounding noise occasionally sit on different sides of such a kink for one of the ~100 positives of this small batch.
-    # Seen in 1 of 5 runs of this test with the box term on: bucket 0 (the Detect layers) at 0.351 / cosine 0.94, every other
-    # bucket <= 0.1 as usual (typical bucket 0: 0.01 - 0.10); tests/test_gpu_head_conv.py measures the same jump in isolation
-    # (a 2^-9 perturbation of the logits moves the 4 x 4 level's logit gradient by 0.21).  The box term's own parity is
-    # tests/test_gpu_parity.py's business; objectness and class terms are smooth.
+    # The box term stays in the compared step (round 4 had switched it off after a 1-in-5 failure; ADVICE r04: then a missing
+    # or mis-ordered reduction that only touches the Detect bucket's box gradient would pass).  d(CIoU)/d(box) jumps where an
+    # edge of the predicted box crosses the target's, so two runs whose logits differ by rounding noise occasionally sit on
+    # different sides of such a kink for one of the ~100 positives of this small batch: seen once in five runs as bucket 0 (the
+    # Detect layers) at 0.351 / cosine 0.94, every other bucket <= 0.1 (typical bucket 0: 0.01 - 0.10).  Bound for bucket 0 ONLY,
+    # stated before this form first ran: 0.5 relative L2, cosine >= 0.85 (a Detect bucket that was not reduced is one shard's
+    # gradient against the two-shard mean; the ranks' parameters, shadows and gradients are also compared bit for bit above).
     assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"]), (g0["loss"], e0["loss"])
     assert len(g0["buckets"]) == len(e0["buckets"]) >= 6
     worst = []
@@ -252,5 +251,5 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
         cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
         worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
     print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst)   # shown with pytest -s / on failure
-    assert all(rel < 0.33 and cos >= 0.9 for rel, cos, _, _ in worst), worst
+    assert all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst), worst
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing
