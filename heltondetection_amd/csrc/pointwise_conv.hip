@@ -1891,15 +1891,11 @@ extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, con
   return st != HD_OK ? st : hd_wgrad_reduce(&job, stream);
 }
 
-extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {
-  return B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 &&
-         Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff;
-}
-
-extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout,
-                                    void* y, int64_t y_row_stride, float* stats, hd_stream stream) {
+// the round-4 forward kernel, reachable through hd_conv3x3_fwd with HD_CONV3_V1=1 (csrc/conv3x3.hip holds the current one)
+hd_status hd_conv3x3_fwd_v1(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout,
+                            void* y, int64_t y_row_stride, float* stats, hd_stream stream) {
   if (!x || !w || !y) return HD_ERR_NULL;
-  if (!hd_conv3x3_fwd_supported(B, H, W, Cin, Cout)) return HD_ERR_SHAPE;
+  if (!(conv3x3_width_ok(W) && Cin % 64 == 0 && Cout % 64 == 0)) return HD_ERR_SHAPE;
   if (x_row_stride == 0) x_row_stride = Cin;
   if (y_row_stride == 0) y_row_stride = Cout;
   if (x_row_stride < Cin || y_row_stride < Cout || x_row_stride % 8 || y_row_stride % 8) return HD_ERR_SHAPE;

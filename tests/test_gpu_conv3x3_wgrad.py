@@ -109,6 +109,33 @@ def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
     assert torch.equal(dx.float(), dref.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 9, 40, 64), (1, 32, 6, 20, 64), (2, 160, 4, 80, 128), (1, 32, 3, 104, 64), (2, 96, 5, 26, 64)])
+def test_conv3x3_forward_takes_input_channels_in_multiples_of_32_and_channel_slices(shape):
+    """Round 5: the kernel walks Cin in 32-channel chunks, so Cin = 32, 96, 160 run (the round-4 kernel needed multiples of 64);
+    x and y as channel slices of wider channels-last tensors (row stride > channels), the neighbours of y untouched."""
+    from heltondetection_amd import _lib, ops
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    B, K, H, W, N = shape
+    g = torch.Generator().manual_seed(K + N + H + W)
+    xw = torch.randint(-2, 3, (B, K + 32, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = xw[:, 16:16 + K] if K % 16 == 0 else xw[:, :K]
+    w = torch.randint(-1, 2, (N, K, 3, 3), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.conv3x3_fwd_supported(x, N)
+    y = ops.conv3x3_fwd_rows(x, w)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1)
+    assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
+    # output into a channel slice
+    buf = torch.full((B, N + 64, H, W), 5.0, dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    out = buf[:, 32:32 + N]
+    ops.check(lib.hd_conv3x3_fwd(ops._ptr(x), int(x.stride(3)), ops._ptr(w), B, H, W, K, N, ops._ptr(out), int(out.stride(3)), None,
+                                 ops._stream(x)), "hd_conv3x3_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), ref.to(torch.bfloat16).float())
+    assert bool((buf[:, :32] == 5.0).all()) and bool((buf[:, 32 + N:] == 5.0).all())
+
+
 def test_flipped_weights_of_all_layers_in_one_launch_equal_flip_permute():
     """hd_conv3x3_flip_weights (ops.FlippedWeights): wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c] for a batch of layers with
     different (ragged) channel counts, bit for bit what flip + permute + contiguous builds; consulted only inside `with`."""
