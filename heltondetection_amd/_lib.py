@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -37,13 +37,6 @@ class RoiLevels(C.Structure):
 class Rows2(C.Structure):
     """hd_rows2: optional second place of a [R, C] operand of the fused BN kernels."""
     _fields_ = [("p2", C.c_void_p), ("ld2", C.c_int64), ("split", C.c_int)]
-
-
-class BnBwd(C.Structure):
-    """hd_bn_bwd: the fused BatchNorm + activation backward folded into a convolution gradient call."""
-    _fields_ = [("y", C.c_void_p), ("y_row_stride", C.c_int64), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
-                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dsums", C.c_void_p), ("rows", C.c_int64), ("act", C.c_int),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 class WgradJob(C.Structure):
@@ -132,11 +125,9 @@ SIGNATURES = {
     "hd_pointwise_wgrad": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _Z, _P]),
     "hd_wgrad_reduce": (_I, [_P, _P]),
     "hd_pointwise_conv_dgrad_add": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
-    "hd_pointwise_conv_dgrad_bn": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
-    "hd_pointwise_wgrad_partial": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _P, _P, _Z, _P, _P, _P]),
+    "hd_pointwise_wgrad_partial": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _Z, _P, _P, _P]),
     "hd_pointwise_bwd_supported": (_I, [_L, _I, _I]),
     "hd_pointwise_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
-    "hd_pointwise_bwd_tune": (None, [_I]),
     "hd_pointwise_bwd": (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _L, _P, _L, _P, _P, _Z, _P, _P, _P]),
     "hd_head_conv_pitch": (_I, [_I]),
     "hd_head_conv_fwd_supported": (_I, [_L, _I, _I]),
@@ -153,6 +144,7 @@ SIGNATURES = {
     "hd_conv3x3_fwd_supported": (_I, [_I, _I, _I, _I, _I]),
     "hd_conv3x3_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_conv3x3_wgrad_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "hd_conv3x3_wgrad_select": (None, [_I]),
     "hd_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "hd_conv3x3_wgrad": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "hd_conv3x3_wgrad_partial": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _P, _P]),
@@ -160,9 +152,6 @@ SIGNATURES = {
     "hd_adamw_multi": (_I, [_P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "hd_maxpool5_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_maxpool5_bwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "hd_sppf_pools_supported": (_I, [_I, _I, _I, _I, _I]),
-    "hd_sppf_pools_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P]),
-    "hd_sppf_pools_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "hd_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hd_bn_act_replicas": (C.c_int, []),
@@ -214,7 +203,7 @@ class _Traced:
     """HD_TRACE_CALLS=<file>: every launching hd_* call appends one line (name + its integer / float arguments) to <file> BEFORE
     it is made.  With HIP_LAUNCH_BLOCKING=1 / AMD_SERIALIZE_KERNEL=3 the last line names the call whose kernel faulted.  Debugging
     aid only; the queries (*_supported, *_bytes, ...) are not traced."""
-    _QUIET = ("_supported", "_bytes", "_pitch", "_resident", "_replicas", "_str", "_version", "_tune")
+    _QUIET = ("_supported", "_bytes", "_pitch", "_resident", "_replicas", "_str", "_version", "_tune", "_select")
 
     def __init__(self, lib, path):
         self._lib = lib

@@ -1,7 +1,7 @@
 // conv3x3.hip — 3x3 / pad 1 / stride 1 convolution on channels-last bf16 rows as an implicit GEMM on the matrix cores: the
 // forward of the CSP bottlenecks' second convolution and, with flipped + transposed weights, its data gradient
-// (hd_conv3x3_fwd).  Round 5 rewrite of the kernel that used to live in pointwise_conv.hip (one workgroup per CU, 32-pixel
-// tiles per image row: 20 - 26 us per layer of the YOLOv5s step at 0.12 of the dense bf16 peak):
+// (hd_conv3x3_fwd).  Round 5 rewrite of the round-4 kernel (one workgroup per CU, 32-pixel tiles per image row: 20 - 26 us per
+// layer of the YOLOv5s step at 0.12 of the dense bf16 peak; measured side by side in profiles/r05_conv3.md):
 //
 //   * FLAT pixel tiles.  The workgroup's ROWS + 2 input rows sit in LDS as ONE image of (W + 2)-pixel rows (one zero pixel
 //     of halo on both sides; rows outside the picture stay zero), so an output position q = row (W + 2) + x reads its tap
@@ -184,32 +184,58 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_tap_kernel(const unsigned sh
 
   HD_STAMP(3);
   // ---- epilogue.  C/D map: column (channel) = lane & 31, row (position) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  __syncthreads();   // every wave is past its last slab read: the slab area becomes the four patches
+  // BatchNorm statistics FIRST, straight from the accumulators (of the bf16-rounded values, the ones the normalisation will read):
+  // per-lane sums -> LDS -> (behind the barrier the patches need anyway) one global atomic per channel and workgroup, issued
+  // BEFORE the tile stores so that the atomics' round trip (the tail of the kernel when they came last: 3 - 4 us per launch
+  // against the same kernel without statistics) runs under the stores.
+  if (STATS) {
+    float s_sum[2] = {0.0f, 0.0f}, s_sq[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int q0 = mbase + i * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {   // q0 is wave-uniform: the two half-waves' flags are scalar arithmetic, a lane picks its own
+        const int qa = q0 + (r & 3) + 8 * (r >> 2), qb = qa + 4;
+        const int rwa = qa / WP, rwb = qb / WP;
+        const bool oka = qa - rwa * WP < W && rwa < ROWS && r0 + rwa < H, okb = qb - rwb * WP < W && rwb < ROWS && r0 + rwb < H;
+        const bool ok = fh ? okb : oka;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)acc[i][j][r]);
+          const float f = ok ? bf16_bits_to_float(v) : 0.0f;
+          s_sum[j] += f;
+          s_sq[j] = fmaf(f, f, s_sq[j]);
+        }
+      }
+    }
+    float* s_st = reinterpret_cast<float*>(smem + G::STAT_OFF);  // [2][64], zeroed with the ring
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = s_sum[j] + __shfl_xor(s_sum[j], 32);
+      const float q = s_sq[j] + __shfl_xor(s_sq[j], 32);
+      if (fh == 0) {
+        atomicAdd(&s_st[j * 32 + frow], a);
+        atomicAdd(&s_st[64 + j * 32 + frow], q);
+      }
+    }
+  }
+  __syncthreads();   // every wave is past its last slab read: the slab area becomes the four patches; the statistics are in LDS
+  if (STATS && tid < 128) {
+    const float* s_st = reinterpret_cast<const float*>(smem + G::STAT_OFF);
+    float* dst = stats + (size_t)((blockIdx.x + blockIdx.y) % kStatReplicas) * 2 * Cout;
+    atomicAdd(&dst[(tid / 64) * Cout + n0 + (tid % 64)], s_st[tid]);
+  }
   unsigned char* patch = ws + wave * G::PATCH;
-  float s_sum[2] = {0.0f, 0.0f}, s_sq[2] = {0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int q0 = mbase + i * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int prow = (r & 3) + 8 * (r >> 2) + 4 * fh;
-      bool ok = true;
-      if (STATS) {   // q0 is wave-uniform: the two half-waves' flags are scalar arithmetic, a lane picks its own
-        const int qa = q0 + (r & 3) + 8 * (r >> 2), qb = qa + 4;
-        const int rwa = qa / WP, rwb = qb / WP;
-        const bool oka = qa - rwa * WP < W && rwa < ROWS && r0 + rwa < H, okb = qb - rwb * WP < W && rwb < ROWS && r0 + rwb < H;
-        ok = fh ? okb : oka;
-      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)acc[i][j][r]);
-        *reinterpret_cast<unsigned short*>(patch + prow * G::PATCH_ROW + (j * 32 + frow) * 2) = v;
-        if (STATS) {
-          const float f = ok ? bf16_bits_to_float(v) : 0.0f;
-          s_sum[j] += f;
-          s_sq[j] = fmaf(f, f, s_sq[j]);
-        }
-      }
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<unsigned short*>(patch + prow * G::PATCH_ROW + (j * 32 + frow) * 2) =
+            __builtin_bit_cast(unsigned short, (__bf16)acc[i][j][r]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -222,23 +248,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_tap_kernel(const unsigned sh
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-
   HD_STAMP(4);
-  if (STATS) {
-    float* s_st = reinterpret_cast<float*>(smem + G::STAT_OFF);  // [2][64], zeroed with the ring
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float a = s_sum[j] + __shfl_xor(s_sum[j], 32);
-      const float q = s_sq[j] + __shfl_xor(s_sq[j], 32);
-      if (fh == 0) {
-        atomicAdd(&s_st[j * 32 + frow], a);
-        atomicAdd(&s_st[64 + j * 32 + frow], q);
-      }
-    }
-    __syncthreads();
-    float* dst = stats + (size_t)((blockIdx.x + blockIdx.y) % kStatReplicas) * 2 * Cout;
-    for (int i = tid; i < 128; i += 256) atomicAdd(&dst[(i / 64) * Cout + n0 + (i % 64)], s_st[i]);
-  }
   HD_STAMP(5);
 }
 
@@ -273,9 +283,6 @@ extern "C" int hd_conv3_stamps_read(unsigned long long* host, int n) {
 #endif
 
 extern "C" int hd_bn_act_replicas(void);
-// the round-4 kernel (pointwise_conv.hip), kept callable while the two are compared (HD_CONV3_V1=1)
-hd_status hd_conv3x3_fwd_v1(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout, void* y,
-                            int64_t y_row_stride, float* stats, hd_stream stream);
 
 extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {
   return B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0 &&
@@ -291,24 +298,15 @@ extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const v
   if (x_row_stride < Cin || y_row_stride < Cout || x_row_stride % 8 || y_row_stride % 8) return HD_ERR_SHAPE;
   if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
-  static const bool v1 = [] { const char* e = getenv("HD_CONV3_V1"); return e && e[0] == '1'; }();
-  if (v1 && Cin % 64 == 0) return hd_conv3x3_fwd_v1(x, x_row_stride, w, B, H, W, Cin, Cout, y, y_row_stride, stats, stream);
   hipStream_t s = (hipStream_t)stream;
-  // ROWS x (W + 2) flat positions per workgroup in 4 MT tiles of 32; two workgroups per CU, the grid one wave of them
-  static const int alt = [] { const char* e = getenv("HD_CONV3_ALT"); return e ? atoi(e) : 0; }();   // experiments
+  // <W, ROWS, MT, workgroups per CU>: ROWS x (W + 2) flat positions per workgroup in 4 MT tiles of 32.  Measured per shape
+  // (tools/conv3_probe.py, profiles/r05_conv3.md): 80 / 104-pixel rows two workgroups per CU with MT = 2 (MT = 4 alone on the CU:
+  // slower), 40-pixel rows one workgroup of MT = 2 per CU (224 workgroups; two of MT = 1: equal to 4 % slower), 20 / 26 / 52 MT = 1.
   switch (W) {
-    case 104:
-      if (alt & 1) return launch_conv3x3<104, 4, 4, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-      return launch_conv3x3<104, 2, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 80:
-      if (alt & 1) return launch_conv3x3<80, 6, 4, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-      return launch_conv3x3<80, 3, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 52:
-      if (alt & 2) return launch_conv3x3<52, 4, 2, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-      return launch_conv3x3<52, 2, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 40:
-      if (alt & 2) return launch_conv3x3<40, 3, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-      return launch_conv3x3<40, 6, 2, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 104: return launch_conv3x3<104, 2, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 80: return launch_conv3x3<80, 3, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 52: return launch_conv3x3<52, 2, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 40: return launch_conv3x3<40, 6, 2, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 26: return launch_conv3x3<26, 4, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 20: return launch_conv3x3<20, 5, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     default: return HD_ERR_SHAPE;

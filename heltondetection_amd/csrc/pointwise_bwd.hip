@@ -361,8 +361,6 @@ struct BwdPlan {
 inline BwdPlan bwd_plan(int64_t R, int Cin, int Cout, int want_grid) {
   BwdPlan p{};
   int tn_max = Cout >= 256 ? 1 : 2;  // 64 x 128 and 32 x 128 tiles spill (256 + 256 registers with the addend in flight)
-  static const int tn128 = [] { const char* e = getenv("HD_BWD_TN128"); return e ? atoi(e) : 0; }();  // experiments: 1 | 2
-  if (Cout == 128 && tn128 >= 1) tn_max = tn128 > 2 ? 2 : tn128;
   int tn = tn_max;
   while (tn > 1 && Cin % (32 * tn)) tn >>= 1;
   p.tn = tn;
@@ -378,11 +376,9 @@ inline BwdPlan bwd_plan(int64_t R, int Cin, int Cout, int want_grid) {
   // YOLOv5s 640^2 bs16 step (profiles/r04_pointwise_bwd.md): the one-per-CU variants at 160-224 workgroups 5.55 ms/step, at 256
   // 5.63 — with every CU taken by a main workgroup the riding slice sum of the previous layer only starts when the first main
   // workgroups retire; at 192 a quarter of the CUs take the riders at once (and the slab is a quarter smaller).  The
-  // two-per-CU variants: 128 / 256 equal, 512 slower (5.67: twice the partials to write and sum).  HD_BWD_CAP1 / _CAP2 override.
+  // two-per-CU variants: 128 / 256 equal, 512 slower (5.67: twice the partials to write and sum).
   const bool two = Cout <= 64 || (Cout == 128 && tn == 1);
-  static const int cap2 = [] { const char* e = getenv("HD_BWD_CAP2"); return e ? atoi(e) : 256; }();
-  static const int cap1 = [] { const char* e = getenv("HD_BWD_CAP1"); return e ? atoi(e) : 192; }();
-  long long cap = want_grid > 0 ? want_grid : (two ? cap2 : cap1);
+  long long cap = want_grid > 0 ? want_grid : (two ? 256 : 192);
   if (cap < L) cap = L;
   if (g > cap) g = cap / L * L;
   p.grid = (int)g;
@@ -398,13 +394,11 @@ inline bool bwd_shape_ok(int64_t R, int Cin, int Cout) {
   return p.nt <= 32;
 }
 
-int g_bwd_grid_override = 0;  // hd_pointwise_bwd_tune: experiments only (0 = the plan's own choice)
+constexpr int g_bwd_grid_override = 0;   // the plan's own grid (round 4 swept it through an exported setter, removed in round 5)
 
 }  // namespace
 
 extern "C" int hd_pointwise_bwd_supported(int64_t R, int Cin, int Cout) { return bwd_shape_ok(R, Cin, Cout) ? 1 : 0; }
-
-extern "C" void hd_pointwise_bwd_tune(int grid) { g_bwd_grid_override = grid; }
 
 extern "C" size_t hd_pointwise_bwd_workspace_bytes(int64_t R, int Cin, int Cout) {
   if (!bwd_shape_ok(R, Cin, Cout)) return 0;

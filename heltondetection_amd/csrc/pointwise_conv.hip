@@ -1241,190 +1241,6 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
     for (int r = 0; r < 16; ++r) out[((size_t)(nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * K + k] = acc[t][r];
 }
 
-// ---- 3x3 / stride 1 / pad 1 forward (and, with flipped + transposed weights, data gradient) -------------------------
-//     Y[b, h, w, n] = sum over (ky, kx, c) of X[b, h + ky - 1, w + kx - 1, c] * Wt[n][ky][kx][c]
-// Implicit GEMM per output row, M = pixels, N = Cout, K = 9 Cin, without an im2col: a workgroup owns 64 output channels
-// and ROWS output rows at a time; LDS holds the ROWS + 2 input rows of one 64-channel chunk (one zero pixel of halo on
-// both sides, zero rows outside the image — borders need no masks) and that chunk's 64 x 9 x 64 weight slab; the nine
-// taps are (row slot, pixel shift) views of the ring, both operands are read K-contiguous (ds_read_b128; pixel rows
-// padded to 144 B and weight rows to 1168 B so 16 consecutive rows fall on distinct bank groups).  A wave owns one
-// 32-channel half and TPW 32-pixel tiles; per (tap, k-step) it issues one weight fragment, TPW pixel fragments and TPW
-// MFMAs.  The accumulators of the pass persist over the Cin chunks.  Epilogue as in the 1x1 kernel: the BatchNorm
-// statistics of the bf16-rounded result per lane column, the tile transposed through a wave-private LDS patch so the
-// global stores are 16 bytes per lane.
-template <int W, int ROWS, bool STATS>
-__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const unsigned short* __restrict__ X, long long ld_x,
-                                                          const unsigned short* __restrict__ Wt,
-                                                          unsigned short* __restrict__ Y, long long ld_y, int B, int H, int Cin,
-                                                          int Cout, int passes_per_wg, float* __restrict__ stats) {
-  constexpr int PT = (W + 31) / 32, WPX = PT * 32, PXS = 144, XROW = (WPX + 2) * PXS, NSLOT = ROWS + 2;
-  constexpr int WROW = 9 * 64 * 2 + 16, SLAB = 64 * WROW;
-  constexpr int PATCH_ROW = 32 * 2 + 16, PATCH = 32 * PATCH_ROW;
-  constexpr int NT = ROWS * PT * 2, TPW = NT / 4;
-  static_assert(NT % 4 == 0, "tiles must divide over the four waves");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [input rows | weight slab | 4 patches]
-  unsigned char* xs = smem;
-  unsigned char* ws = smem + NSLOT * XROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int frow = lane & 31, fh = lane >> 5;
-  unsigned char* patch = ws + SLAB + wave * PATCH;
-  const int n0 = blockIdx.x * 64, ct = wave & 1;
-  const int ppi = (H + ROWS - 1) / ROWS;  // passes per image
-  const int total = B * ppi;
-  const int NC = Cin / 64;
-
-  for (int i = tid; i < NSLOT * XROW / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
-  float s_sum = 0.0f, s_sq = 0.0f;
-  const u32x4 zero = {0u, 0u, 0u, 0u};
-
-  // One step = one (pass, Cin chunk).  The operands of step s + 1 travel in registers while step s is multiplied: all
-  // loads of a step are issued back to back (a load -> LDS store loop would serialise 18 L2 round trips per thread).
-  constexpr int XCH = NSLOT * W * 8, XIT = (XCH + 255) / 256, WIT = 64 * 9 * 8 / 256;
-  u32x4 xr[XIT], wr[WIT];
-  const int my_passes = min(passes_per_wg, total - (int)blockIdx.y * passes_per_wg);
-  const int steps = my_passes > 0 ? my_passes * NC : 0;
-  auto issue = [&](int st) {
-    const int pass = blockIdx.y * passes_per_wg + st / NC, c = st % NC;
-    const int b = pass / ppi, r0 = (pass % ppi) * ROWS;
-#pragma unroll
-    for (int i = 0; i < XIT; ++i) {
-      const int id = i * 256 + tid;
-      if (XCH % 256 == 0 || id < XCH) {
-        const int slot = id / (W * 8), rem = id % (W * 8), px = rem >> 3, ch = rem & 7;
-        const int rc = min(max(r0 - 1 + slot, 0), H - 1);
-        xr[i] = *reinterpret_cast<const u32x4*>(X + ((long long)(b * H + rc) * W + px) * ld_x + c * 64 + ch * 8);
-      }
-    }
-    if (NC > 1 || st == 0) {
-#pragma unroll
-      for (int i = 0; i < WIT; ++i) {
-        const int id = i * 256 + tid, co = id / 72, rem = id % 72, tap = rem >> 3, ch = rem & 7;
-        wr[i] = *reinterpret_cast<const u32x4*>(Wt + ((long long)(n0 + co) * 9 + tap) * Cin + c * 64 + ch * 8);
-      }
-    }
-  };
-  auto stash = [&](int st) {
-    const int pass = blockIdx.y * passes_per_wg + st / NC;
-    const int r0 = (pass % ppi) * ROWS;
-#pragma unroll
-    for (int i = 0; i < XIT; ++i) {
-      const int id = i * 256 + tid;
-      if (XCH % 256 == 0 || id < XCH) {
-        const int slot = id / (W * 8), rem = id % (W * 8), px = rem >> 3, ch = rem & 7;
-        const int r = r0 - 1 + slot;
-        *reinterpret_cast<u32x4*>(xs + slot * XROW + (px + 1) * PXS + ch * 16) = (r >= 0 && r < H) ? xr[i] : zero;
-      }
-    }
-    if (NC > 1 || st == 0) {
-#pragma unroll
-      for (int i = 0; i < WIT; ++i) {
-        const int id = i * 256 + tid, co = id / 72, rem = id % 72, tap = rem >> 3, ch = rem & 7;
-        *reinterpret_cast<u32x4*>(ws + co * WROW + tap * 128 + ch * 16) = wr[i];
-      }
-    }
-  };
-
-  if (steps > 0) issue(0);
-  for (int pi = 0; pi < my_passes; ++pi) {
-    const int pass = blockIdx.y * passes_per_wg + pi;
-    const int b = pass / ppi, r0 = (pass % ppi) * ROWS;
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    for (int c = 0; c < NC; ++c) {
-      const int st = pi * NC + c;
-      __syncthreads();  // the previous step has been read (and, first time, the zero fill is complete)
-      stash(st);
-      if (st + 1 < steps) issue(st + 1);
-      __syncthreads();
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int sk = 0; sk < 4; ++sk) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (ct * 32 + frow) * WROW + (ky * 3 + kx) * 128 + (2 * sk + fh) * 16);
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-              const int t = wave + 4 * i, row = t / (PT * 2), pt = (t / 2) % PT;
-              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (row + ky) * XROW + (pt * 32 + frow + kx) * PXS + (2 * sk + fh) * 16);
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wf, acc[i], 0, 0, 0);
-            }
-          }
-    }
-    // epilogue: C/D map col (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      const int t = wave + 4 * i, row = t / (PT * 2), pt = (t / 2) % PT;
-      const int h = r0 + row;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)acc[i][r]);
-        *reinterpret_cast<unsigned short*>(patch + prow * PATCH_ROW + frow * 2) = v;
-        if (STATS && h < H && pt * 32 + prow < W) {
-          const float f = bf16_bits_to_float(v);
-          s_sum += f;
-          s_sq = fmaf(f, f, s_sq);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {  // 32 pixels x 4 chunks of 16 bytes over 64 lanes
-        const int id = q * 64 + lane, prow = id >> 2, ch = id & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>(patch + prow * PATCH_ROW + ch * 16);
-        const int px = pt * 32 + prow;
-        if (h < H && px < W)
-          *reinterpret_cast<uint4*>(Y + ((long long)(b * H + h) * W + px) * ld_y + n0 + ct * 32 + ch * 8) = v;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
-
-  if (STATS) {
-    __syncthreads();
-    float* s_st = reinterpret_cast<float*>(xs);  // [2][64]
-    for (int i = tid; i < 128; i += 256) s_st[i] = 0.0f;
-    __syncthreads();
-    const float a = s_sum + __shfl_xor(s_sum, 32);
-    const float q = s_sq + __shfl_xor(s_sq, 32);
-    if (fh == 0) {
-      atomicAdd(&s_st[ct * 32 + frow], a);
-      atomicAdd(&s_st[64 + ct * 32 + frow], q);
-    }
-    __syncthreads();
-    float* dst = stats + (size_t)((blockIdx.x + blockIdx.y) % kStatReplicas) * 2 * Cout;
-    for (int i = tid; i < 128; i += 256) atomicAdd(&dst[(i / 64) * Cout + n0 + (i % 64)], s_st[i]);
-  }
-}
-
-template <int W, int ROWS>
-hd_status launch_conv3x3_fwd(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int B, int H, int Cin, int Cout,
-                             float* stats, hipStream_t s) {
-  constexpr int PT = (W + 31) / 32;
-  const size_t lds = (size_t)(ROWS + 2) * (PT * 32 + 2) * 144 + 64 * (9 * 64 * 2 + 16) + 4 * 32 * (32 * 2 + 16);
-  const int total = B * ((H + ROWS - 1) / ROWS);
-  const int tiles = Cout / 64;
-  // one workgroup per CU (142-155 KB of LDS), so more workgroups than CUs run in rounds: keep the grid at <= 256 and
-  // choose ROWS so that (passes x channel tiles) is close to a multiple of 256 (W = 40: 16 x 8 x 2, W = 20: 16 x 4 x 4)
-  int wgs = 256 / tiles;
-  if (wgs < 1) wgs = 1;
-  const int ppw = (total + wgs - 1) / wgs;
-  const dim3 grid((unsigned)tiles, (unsigned)((total + ppw - 1) / ppw));
-  const auto* a = static_cast<const unsigned short*>(x);
-  const auto* b = static_cast<const unsigned short*>(w);
-  auto* c = static_cast<unsigned short*>(y);
-  if (stats)
-    (void)hd_launch(conv3x3_fwd_kernel<W, ROWS, true>, grid, dim3(256), lds, s, a, ld_x, b, c, ld_y, B, H, Cin, Cout, ppw, stats);
-  else
-    (void)hd_launch(conv3x3_fwd_kernel<W, ROWS, false>, grid, dim3(256), lds, s, a, ld_x, b, c, ld_y, B, H, Cin, Cout, ppw,
-                    (float*)nullptr);
-  HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
-}
-
 // Row widths with an instantiation: the 640^2 / 1280^2 pyramids (20, 40, 80) and the 832^2 ones (26, 52, 104).  One image
 // row (+ halo) must fit the LDS ring, which ends at 104 pixels for the stride-2 weight gradient and the forward kernel.
 static inline bool conv3x3_width_ok(int W) { return W == 20 || W == 26 || W == 40 || W == 52 || W == 80 || W == 104; }
@@ -1437,8 +1253,7 @@ struct Wgrad3Plan {
 static bool wgrad3_pair_fits(int W, int stride) {   // two rings (+ the static reduce area) within 160 KB of LDS
   const int WP = (W + 15) / 16 * 16;
   const size_t ring = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
-  static const bool off = [] { const char* e = getenv("HD_WGRAD3_PAIR"); return e && e[0] == '0'; }();
-  return !off && 2 * ring + 4608 <= 160 * 1024;
+  return 2 * ring + 4608 <= 160 * 1024;
 }
 inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout, int W = 0, int stride = 1) {
   // Every workgroup writes a 64 x 9 x 64 float32 partial (147 KB) that the reduce kernel reads back, so the slab traffic
@@ -1615,40 +1430,6 @@ extern "C" size_t hd_pointwise_wgrad_workspace_bytes(int64_t R, int Cin, int Cou
   return (size_t)p.splits * Cin * Cout * sizeof(float);
 }
 
-// hd_bn_bwd (+ the second place of d(out)) -> the kernels' by-value view; checks what the kernels assume
-static hd_status make_bn_view(const hd_bn_bwd* bn, const hd_rows2* tail, int C, int64_t R, hdfuse::BnBwd* out) {
-  *out = hdfuse::BnBwd{};
-  if (!bn) return tail && tail->p2 ? HD_ERR_SHAPE : HD_OK;  // two places only exist for a fused-BN operand
-  if (!bn->y || !bn->save_mean || !bn->save_invstd || !bn->gamma || !bn->beta || !bn->dsums) return HD_ERR_NULL;
-  if ((bn->dgamma == nullptr) != (bn->dbeta == nullptr)) return HD_ERR_NULL;
-  if (bn->act < 0 || bn->act > 2 || bn->rows <= 0) return HD_ERR_SHAPE;
-  const int64_t ld_y = bn->y_row_stride == 0 ? C : bn->y_row_stride;
-  if (ld_y < C || ld_y % 8 || !hd_aligned16(bn->y)) return HD_ERR_SHAPE;
-  if (hd_bn_act_replicas() != hdfuse::kRep) return HD_ERR_SHAPE;
-  out->y = static_cast<const unsigned short*>(bn->y);
-  out->ld_y = ld_y;
-  if (tail && tail->p2) {
-    if (tail->split <= 0 || tail->split >= C || tail->split % 8) return HD_ERR_SHAPE;
-    const int64_t ld2 = tail->ld2 == 0 ? (C - tail->split) : tail->ld2;
-    if (ld2 < C - tail->split || ld2 % 8 || !hd_aligned16(tail->p2)) return HD_ERR_SHAPE;
-    out->dout2 = static_cast<const unsigned short*>(tail->p2);
-    out->ld2 = ld2;
-    out->split = tail->split;
-  }
-  out->mean = bn->save_mean;
-  out->invstd = bn->save_invstd;
-  out->gamma = bn->gamma;
-  out->beta = bn->beta;
-  out->dsums = bn->dsums;
-  out->inv_rows = 1.0f / (float)bn->rows;
-  out->act = bn->act;
-  out->C = C;
-  out->dgamma = bn->dgamma;
-  out->dbeta = bn->dbeta;
-  (void)R;
-  return HD_OK;
-}
-
 static hd_status make_job_view(const hd_wgrad_job* j, hdfuse::ReduceJob* out) {
   *out = hdfuse::ReduceJob{};
   if (!j) return HD_OK;
@@ -1679,24 +1460,23 @@ extern "C" hd_status hd_wgrad_reduce(const hd_wgrad_job* job, hd_stream stream) 
   return HD_OK;
 }
 
-extern "C" hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const hd_rows2* dy_tail,
-                                                const hd_bn_bwd* bn, const void* x, int64_t x_row_stride, int64_t R, int Cin,
-                                                int Cout, void* dw, void* workspace, size_t workspace_bytes,
+extern "C" hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride,
+                                                int64_t R, int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
                                                 const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream) {
+  // (the BNB = true instantiations of the kernels — BatchNorm backward folded into the operand load, round 3: bit-identical and
+  // slower — are no longer built: tools/experiments/r05_removed_paths.patch has the entry points that used them)
   if (!dy || !x || !dw || !workspace || !job_out) return HD_ERR_NULL;
   if (!hd_pointwise_wgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;
-  if (dy_row_stride == 0) dy_row_stride = (dy_tail && dy_tail->p2) ? dy_tail->split : Cout;
+  if (dy_row_stride == 0) dy_row_stride = Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
-  if (dy_row_stride % 8 || x_row_stride < Cin || x_row_stride % 8) return HD_ERR_SHAPE;
-  if (dy_row_stride < ((dy_tail && dy_tail->p2) ? dy_tail->split : Cout)) return HD_ERR_SHAPE;
+  if (dy_row_stride % 8 || x_row_stride < Cin || x_row_stride % 8 || dy_row_stride < Cout) return HD_ERR_SHAPE;
   if (!hd_aligned16(dy) || !hd_aligned16(x) || !hd_aligned16(dw) || !hd_aligned16(workspace)) return HD_ERR_ALIGN;
   const WgradPlan p = wgrad_plan(R, Cin, Cout);
   if (workspace_bytes < (size_t)p.splits * Cin * Cout * sizeof(float)) return HD_ERR_WORKSPACE;
-  hdfuse::BnBwd bv;
+  const hdfuse::BnBwd bv{};
   hdfuse::ReduceJob jv;
-  hd_status st = make_bn_view(bn, dy_tail, Cout, R, &bv);
+  const hd_status st = make_job_view(piggyback, &jv);
   if (st != HD_OK) return st;
-  if ((st = make_job_view(piggyback, &jv)) != HD_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   const auto* a = static_cast<const unsigned short*>(dy);
   const auto* b = static_cast<const unsigned short*>(x);
@@ -1705,18 +1485,12 @@ extern "C" hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_s
   const size_t lds = 64u * ((64u * p.tm * 2u + 64u) + (64u * p.tn * 2u + 64u));
   const int M = (int)R;
 #define HD_WG_LAUNCH(TMM, TNN)                                                                                             \
-  do {                                                                                                                     \
-    if (bn) (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, true>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, \
-                            M, Cout, Cin, p.rows_per_split, slab, p.splits, bv, jv);                                       \
-    else (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, false>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride,  \
-                         M, Cout, Cin, p.rows_per_split, slab, p.splits, bv, jv);                                          \
-  } while (0)
+  (void)hd_launch(pointwise_wgrad_kernel<TMM, TNN, false>, grid, dim3(256), lds, s, a, dy_row_stride, b, x_row_stride, M, Cout, \
+                  Cin, p.rows_per_split, slab, p.splits, bv, jv)
   if (p.tm == 0) {
     const dim3 g32((unsigned)p.tiles, (unsigned)p.splits + piggyback_rows(jv, (unsigned)p.tiles));
-    if (bn) (void)hd_launch(pointwise_wgrad32_kernel<true>, g32, dim3(256), 0, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                            p.rows_per_split, slab, p.splits, bv, jv);
-    else (void)hd_launch(pointwise_wgrad32_kernel<false>, g32, dim3(256), 0, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
-                         p.rows_per_split, slab, p.splits, bv, jv);
+    (void)hd_launch(pointwise_wgrad32_kernel<false>, g32, dim3(256), 0, s, a, dy_row_stride, b, x_row_stride, M, Cout, Cin,
+                    p.rows_per_split, slab, p.splits, bv, jv);
   } else if (p.tm == 2 && p.tn == 2) HD_WG_LAUNCH(2, 2);
   else if (p.tm == 2) HD_WG_LAUNCH(2, 1);
   else if (p.tn == 2) HD_WG_LAUNCH(1, 2);
@@ -1734,8 +1508,8 @@ extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, c
                                         int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
                                         hd_stream stream) {
   hd_wgrad_job job;
-  const hd_status st = hd_pointwise_wgrad_partial(dy, dy_row_stride, nullptr, nullptr, x, x_row_stride, R, Cin, Cout, dw,
-                                                  workspace, workspace_bytes, nullptr, &job, stream);
+  const hd_status st = hd_pointwise_wgrad_partial(dy, dy_row_stride, x, x_row_stride, R, Cin, Cout, dw, workspace, workspace_bytes,
+                                                  nullptr, &job, stream);
   return st != HD_OK ? st : hd_wgrad_reduce(&job, stream);
 }
 
@@ -1794,45 +1568,22 @@ extern "C" hd_status hd_pointwise_conv_dgrad_add(const void* dy, int64_t dy_row_
   return HD_ERR_SHAPE;
 }
 
-extern "C" hd_status hd_pointwise_conv_dgrad_bn(const void* dout, int64_t dout_row_stride, const hd_rows2* dout_tail,
-                                                const hd_bn_bwd* bn, const void* w, int64_t R, int Cin, int Cout, void* dx,
-                                                int64_t dx_row_stride, hd_stream stream) {
-  if (!dout || !w || !dx || !bn) return HD_ERR_NULL;
-  if (!hd_pointwise_conv_dgrad_supported(R, Cin, Cout)) return HD_ERR_SHAPE;  // the reduction runs over Cout
-  const bool two = dout_tail && dout_tail->p2;
-  if (dout_row_stride == 0) dout_row_stride = two ? dout_tail->split : Cout;
-  if (dx_row_stride == 0) dx_row_stride = Cin;
-  if (dout_row_stride < (two ? dout_tail->split : Cout) || dx_row_stride < Cin || dout_row_stride % 8 || dx_row_stride % 8)
-    return HD_ERR_SHAPE;
-  if (!hd_aligned16(dout) || !hd_aligned16(w) || !hd_aligned16(dx)) return HD_ERR_ALIGN;
-  hdfuse::BnBwd bv;
-  hd_status st = make_bn_view(bn, dout_tail, Cout, R, &bv);
-  if (st != HD_OK) return st;
-  hipStream_t s = (hipStream_t)stream;
-  const int M = (int)R;
-  if (Cout == 32 && try_stream<32, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
-  if (Cout == 64 && try_stream<64, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
-  if (Cout == 128 && try_stream<128, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
-  if (Cout == 256 && try_stream<256, true>(dout, dout_row_stride, w, dx, dx_row_stride, M, Cin, nullptr, s, &st, &bv)) return st;
-  return HD_ERR_SHAPE;
-}
-
-extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride) {
+int hd_conv3x3_wgrad_supported_v1(int B, int H, int W, int Cin, int Cout, int stride) {
   return (stride == 1 || stride == 2) && B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 64 && Cin % 64 == 0 &&
          Cout >= 64 && Cout % 64 == 0 && Cin <= 1024 && Cout <= 1024 && (long long)B * H * W * stride * stride <= 0x7fffffff;
 }
 
-extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride) {
-  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return 0;
+size_t hd_conv3x3_wgrad_workspace_bytes_v1(int B, int H, int W, int Cin, int Cout, int stride) {
+  if (!hd_conv3x3_wgrad_supported_v1(B, H, W, Cin, Cout, stride)) return 0;
   return (size_t)wgrad3_plan(B, H, Cin, Cout, W, stride).partials * Cout * 9 * Cin * sizeof(float);
 }
 
-extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B,
-                                              int H, int W, int Cin, int Cout, int stride, void* dw, void* workspace,
-                                              size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
-                                              hd_stream stream) {
+hd_status hd_conv3x3_wgrad_partial_v1(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B,
+                                      int H, int W, int Cin, int Cout, int stride, void* dw, void* workspace,
+                                      size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
+                                      hd_stream stream) {
   if (!dy || !x || !dw || !workspace || !job_out) return HD_ERR_NULL;
-  if (!hd_conv3x3_wgrad_supported(B, H, W, Cin, Cout, stride)) return HD_ERR_SHAPE;
+  if (!hd_conv3x3_wgrad_supported_v1(B, H, W, Cin, Cout, stride)) return HD_ERR_SHAPE;
   if (dy_row_stride == 0) dy_row_stride = Cout;
   if (x_row_stride == 0) x_row_stride = Cin;
   if (dy_row_stride < Cout || x_row_stride < Cin || dy_row_stride % 8 || x_row_stride % 8) return HD_ERR_SHAPE;
@@ -1880,37 +1631,4 @@ extern "C" hd_status hd_conv3x3_wgrad_partial(const void* dy, int64_t dy_row_str
   job_out->count = (int64_t)Cout * 9 * Cin;
   job_out->dw = dw;
   return HD_OK;
-}
-
-extern "C" hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H,
-                                      int W, int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes,
-                                      hd_stream stream) {
-  hd_wgrad_job job;
-  const hd_status st = hd_conv3x3_wgrad_partial(dy, dy_row_stride, x, x_row_stride, B, H, W, Cin, Cout, stride, dw, workspace,
-                                                workspace_bytes, nullptr, &job, stream);
-  return st != HD_OK ? st : hd_wgrad_reduce(&job, stream);
-}
-
-// the round-4 forward kernel, reachable through hd_conv3x3_fwd with HD_CONV3_V1=1 (csrc/conv3x3.hip holds the current one)
-hd_status hd_conv3x3_fwd_v1(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout,
-                            void* y, int64_t y_row_stride, float* stats, hd_stream stream) {
-  if (!x || !w || !y) return HD_ERR_NULL;
-  if (!(conv3x3_width_ok(W) && Cin % 64 == 0 && Cout % 64 == 0)) return HD_ERR_SHAPE;
-  if (x_row_stride == 0) x_row_stride = Cin;
-  if (y_row_stride == 0) y_row_stride = Cout;
-  if (x_row_stride < Cin || y_row_stride < Cout || x_row_stride % 8 || y_row_stride % 8) return HD_ERR_SHAPE;
-  if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
-  if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  // ROWS per width: the LDS ring must fit beside the weight slab, tiles must divide over four waves, and passes x channel
-  // tiles should be close to a multiple of the 256 CUs (one workgroup per CU)
-  switch (W) {
-    case 104: return launch_conv3x3_fwd<104, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 80: return launch_conv3x3_fwd<80, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 52: return launch_conv3x3_fwd<52, 4>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 40: return launch_conv3x3_fwd<40, 5>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 26: return launch_conv3x3_fwd<26, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 20: return launch_conv3x3_fwd<20, 6>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    default: return HD_ERR_SHAPE;
-  }
 }

@@ -175,178 +175,6 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__
   }
 }
 
-// ---- SPPF: the chain of three 5x5 pools in ONE launch ---------------------------------------------------------------------
-// y1 = pool(x), y2 = pool(y1), y3 = pool(y2) — the three maps SPPF concatenates with x.  The separate kernels above are bound
-// by their 25-fold re-read through L1 / L2 (13 us per forward launch for a 3.3 MB map, 17 us per backward launch) and autograd
-// adds the branch gradients between the three backward launches (three more kernels).  Here a workgroup owns one image and CG
-// channels (two 16-byte vectors per pixel): the whole H x W plane sits in LDS, every pool reads its 25 taps from there, and
-// the next pool starts from the plane the previous one left.  Same comparisons in the same order as maxpool5_fwd_kernel, so
-// values and tap indices are identical.  Backward: t2 = g2 + gather(g3, idx3), t1 = g1 + gather(t2, idx2), dx = gather(t1,
-// idx1) on float32 planes in LDS (the chain of separate kernels rounds t2 and t1 to the tensor's dtype; this does not).
-template <typename T>
-struct PoolPlane {
-  static constexpr int V = Vec<T>::N, G = 2, CG = V * G;   // vectors per pixel and channels per workgroup
-};
-
-template <typename T>
-__device__ __forceinline__ void sppf_pool_once(const uint4* __restrict__ src, uint4* __restrict__ dst, int H, int W, int b, int c0,
-                                               int C, T* __restrict__ y, long long ld_y, uint8_t* __restrict__ idx) {
-  constexpr int V = Vec<T>::N, G = PoolPlane<T>::G;
-  const int items = H * W * G;
-  for (int id = threadIdx.x; id < items; id += blockDim.x) {
-    const int g = id % G, p = id / G, x = p % W, yy0 = p / W;
-    float best[V];
-    uint32_t bi[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      best[k] = -INFINITY;
-      bi[k] = 12;
-    }
-#pragma unroll
-    for (int ty = 0; ty < 5; ++ty) {
-      const int yy = yy0 + ty - 2;
-      if (yy < 0 || yy >= H) continue;
-#pragma unroll
-      for (int tx = 0; tx < 5; ++tx) {
-        const int xx = x + tx - 2;
-        if (xx < 0 || xx >= W) continue;
-        float v[V];
-        Vec<T>::unpack(src[(yy * W + xx) * G + g], v);
-#pragma unroll
-        for (int k = 0; k < V; ++k)
-          if (v[k] > best[k] || v[k] != v[k]) {
-            best[k] = v[k];
-            bi[k] = ty * 5 + tx;
-          }
-      }
-    }
-    uint4 packed;
-    Vec<T>::store(reinterpret_cast<T*>(&packed), best);
-    if (dst) dst[id] = packed;
-    const size_t pix = ((size_t)b * H + yy0) * W + x;
-    *reinterpret_cast<uint4*>(y + pix * ld_y + c0 + g * V) = packed;
-    const size_t o = pix * C + c0 + g * V;
-    if (V == 8) {
-      *reinterpret_cast<uint2*>(idx + o) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
-                                                      bi[4 % V] | (bi[5 % V] << 8) | (bi[6 % V] << 16) | (bi[7 % V] << 24));
-    } else {
-      *reinterpret_cast<uint32_t*>(idx + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_pools_fwd_kernel(const T* __restrict__ x, long long ld_x, int B, int H, int W, int C,
-                                                             T* __restrict__ y1, long long ld1, T* __restrict__ y2, long long ld2,
-                                                             T* __restrict__ y3, long long ld3, uint8_t* __restrict__ i1,
-                                                             uint8_t* __restrict__ i2, uint8_t* __restrict__ i3) {
-  constexpr int V = Vec<T>::N, G = PoolPlane<T>::G, CG = PoolPlane<T>::CG;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int items = H * W * G;
-  uint4* pa = reinterpret_cast<uint4*>(smem);
-  uint4* pb = pa + items;
-  const int b = blockIdx.y, c0 = blockIdx.x * CG;
-  for (int id = threadIdx.x; id < items; id += blockDim.x) {
-    const int g = id % G, p = id / G;
-    pa[id] = *reinterpret_cast<const uint4*>(x + ((size_t)b * H * W + p) * ld_x + c0 + g * V);
-  }
-  __syncthreads();
-  sppf_pool_once<T>(pa, pb, H, W, b, c0, C, y1, ld1, i1);
-  __syncthreads();
-  sppf_pool_once<T>(pb, pa, H, W, b, c0, C, y2, ld2, i2);
-  __syncthreads();
-  sppf_pool_once<T>(pa, nullptr, H, W, b, c0, C, y3, ld3, i3);
-}
-
-// one gather stage on LDS planes: out[p] = add[p] + sum of src[q] over the windows q whose recorded tap points at p
-template <typename T, bool LAST>
-__device__ __forceinline__ void sppf_gather_once(const float* __restrict__ src, float* __restrict__ dst,
-                                                 const uint8_t* __restrict__ taps /* LDS [P][CG] */, int H, int W, int b, int c0, int C,
-                                                 const T* __restrict__ add, long long ld_add, T* __restrict__ out_global) {
-  constexpr int V = Vec<T>::N, G = PoolPlane<T>::G, CG = PoolPlane<T>::CG;
-  const int items = H * W * G;
-  for (int id = threadIdx.x; id < items; id += blockDim.x) {
-    const int g = id % G, p = id / G, x = p % W, y = p / W;
-    float acc[V];
-    const size_t pix = ((size_t)b * H + y) * W + x;
-    if (add) Vec<T>::load(add + pix * ld_add + c0 + g * V, acc);
-    else {
-#pragma unroll
-      for (int k = 0; k < V; ++k) acc[k] = 0.0f;
-    }
-#pragma unroll
-    for (int ty = 0; ty < 5; ++ty) {
-      const int qy = y - ty + 2;
-      if (qy < 0 || qy >= H) continue;
-#pragma unroll
-      for (int tx = 0; tx < 5; ++tx) {
-        const int qx = x - tx + 2;
-        if (qx < 0 || qx >= W) continue;
-        const int q = qy * W + qx;
-        const uint32_t want = ty * 5 + tx;
-        uint32_t w0, w1 = 0u;
-        if (V == 8) {
-          const uint2 t = *reinterpret_cast<const uint2*>(taps + q * CG + g * V);
-          w0 = t.x;
-          w1 = t.y;
-        } else {
-          w0 = *reinterpret_cast<const uint32_t*>(taps + q * CG + g * V);
-        }
-#pragma unroll
-        for (int k = 0; k < V; ++k)
-          if ((((k < 4 ? w0 : w1) >> (8 * (k & 3))) & 255u) == want) acc[k] += src[q * CG + g * V + k];
-      }
-    }
-    if (LAST) {
-      Vec<T>::store(out_global + pix * C + c0 + g * V, acc);
-    } else {
-#pragma unroll
-      for (int k = 0; k < V; ++k) dst[p * CG + g * V + k] = acc[k];
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_pools_bwd_kernel(const T* __restrict__ g1, long long ld1, const T* __restrict__ g2,
-                                                             long long ld2, const T* __restrict__ g3, long long ld3,
-                                                             const uint8_t* __restrict__ i1, const uint8_t* __restrict__ i2,
-                                                             const uint8_t* __restrict__ i3, int B, int H, int W, int C,
-                                                             T* __restrict__ dx) {
-  constexpr int V = Vec<T>::N, G = PoolPlane<T>::G, CG = PoolPlane<T>::CG;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int P = H * W, items = P * G;
-  float* fa = reinterpret_cast<float*>(smem);          // [P][CG]
-  float* fb = fa + (size_t)P * CG;                     // [P][CG]
-  uint8_t* tp = reinterpret_cast<uint8_t*>(fb + (size_t)P * CG);   // [P][CG] tap bytes of the current stage
-  const int b = blockIdx.y, c0 = blockIdx.x * CG;
-  auto load_taps = [&](const uint8_t* idx) {
-    for (int id = threadIdx.x; id < items; id += blockDim.x) {
-      const int g = id % G, p = id / G;
-      const size_t o = ((size_t)b * P + p) * C + c0 + g * V;
-      if (V == 8) *reinterpret_cast<uint2*>(tp + p * CG + g * V) = *reinterpret_cast<const uint2*>(idx + o);
-      else *reinterpret_cast<uint32_t*>(tp + p * CG + g * V) = *reinterpret_cast<const uint32_t*>(idx + o);
-    }
-  };
-  for (int id = threadIdx.x; id < items; id += blockDim.x) {
-    const int g = id % G, p = id / G;
-    float v[V];
-    Vec<T>::load(g3 + ((size_t)b * P + p) * ld3 + c0 + g * V, v);
-#pragma unroll
-    for (int k = 0; k < V; ++k) fa[p * CG + g * V + k] = v[k];
-  }
-  load_taps(i3);
-  __syncthreads();
-  sppf_gather_once<T, false>(fa, fb, tp, H, W, b, c0, C, g2, ld2, nullptr);   // t2 = g2 + gather(g3)
-  __syncthreads();
-  load_taps(i2);
-  __syncthreads();
-  sppf_gather_once<T, false>(fb, fa, tp, H, W, b, c0, C, g1, ld1, nullptr);   // t1 = g1 + gather(t2)
-  __syncthreads();
-  load_taps(i1);
-  __syncthreads();
-  sppf_gather_once<T, true>(fa, nullptr, tp, H, W, b, c0, C, nullptr, 0, dx);  // dx = gather(t1)
-}
-
 // ---- 3x3 / stride 2 / pad 1 (the ResNet stem's pooling, reference README.md:8 FasterRCNN-R50) ---------------------------
 // Same scheme: the forward records the winning tap (0..8, one byte per OUTPUT element), the backward is the gather form —
 // an input pixel is covered by at most 2 x 2 output windows — so there is no int64 index tensor (PyTorch writes and reads
@@ -551,72 +379,3 @@ extern "C" hd_status hd_maxpool3s2_bwd(const void* grad_out, const uint8_t* idx,
   return HD_OK;
 }
 
-// ---- SPPF pool chain ------------------------------------------------------------------------------------------------------
-static size_t sppf_fwd_lds(int dtype, int H, int W) { return (size_t)2 * H * W * 2 * 16; }
-static size_t sppf_bwd_lds(int dtype, int H, int W) {
-  const size_t cg = dtype == 0 ? 8 : 16;
-  return (size_t)H * W * cg * (2 * sizeof(float) + 1);
-}
-
-extern "C" int hd_sppf_pools_supported(int dtype, int B, int H, int W, int C) {
-  if ((dtype != 0 && dtype != 1) || B < 1 || H < 1 || W < 1 || C < 1 || B > 65535) return 0;
-  const int cg = dtype == 0 ? 8 : 16;
-  if (C % cg) return 0;
-  return sppf_fwd_lds(dtype, H, W) <= 160 * 1024 && sppf_bwd_lds(dtype, H, W) <= 160 * 1024 ? 1 : 0;
-}
-
-extern "C" hd_status hd_sppf_pools_fwd(const void* x, int64_t x_row_stride, int dtype, int B, int H, int W, int C, void* y1,
-                                       int64_t y1_row_stride, void* y2, int64_t y2_row_stride, void* y3, int64_t y3_row_stride,
-                                       uint8_t* idx1, uint8_t* idx2, uint8_t* idx3, hd_stream stream) {
-  if (!x || !y1 || !y2 || !y3 || !idx1 || !idx2 || !idx3) return HD_ERR_NULL;
-  if (!hd_sppf_pools_supported(dtype, B, H, W, C)) return HD_ERR_SHAPE;
-  const int V = dtype == 0 ? 4 : 8;
-  int64_t lx = 0, l1 = 0, l2 = 0, l3 = 0;
-  if (pool_stride(x_row_stride, C, V, &lx) != HD_OK || pool_stride(y1_row_stride, C, V, &l1) != HD_OK ||
-      pool_stride(y2_row_stride, C, V, &l2) != HD_OK || pool_stride(y3_row_stride, C, V, &l3) != HD_OK)
-    return HD_ERR_SHAPE;
-  if (!hd_aligned16(x) || !hd_aligned16(y1) || !hd_aligned16(y2) || !hd_aligned16(y3) || (reinterpret_cast<uintptr_t>(idx1) & 7u) ||
-      (reinterpret_cast<uintptr_t>(idx2) & 7u) || (reinterpret_cast<uintptr_t>(idx3) & 7u))
-    return HD_ERR_ALIGN;
-  const dim3 grid((unsigned)(C / (2 * V)), (unsigned)B);
-  const size_t lds = sppf_fwd_lds(dtype, H, W);
-  if (dtype == 0)
-    (void)hd_launch(sppf_pools_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, static_cast<const float*>(x),
-                    (long long)lx, B, H, W, C, static_cast<float*>(y1), (long long)l1, static_cast<float*>(y2), (long long)l2,
-                    static_cast<float*>(y3), (long long)l3, idx1, idx2, idx3);
-  else
-    (void)hd_launch(sppf_pools_fwd_kernel<__hip_bfloat16>, grid, dim3(256), lds, (hipStream_t)stream,
-                    static_cast<const __hip_bfloat16*>(x), (long long)lx, B, H, W, C, static_cast<__hip_bfloat16*>(y1), (long long)l1,
-                    static_cast<__hip_bfloat16*>(y2), (long long)l2, static_cast<__hip_bfloat16*>(y3), (long long)l3, idx1, idx2,
-                    idx3);
-  HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
-}
-
-extern "C" hd_status hd_sppf_pools_bwd(const void* g1, int64_t g1_row_stride, const void* g2, int64_t g2_row_stride, const void* g3,
-                                       int64_t g3_row_stride, const uint8_t* idx1, const uint8_t* idx2, const uint8_t* idx3,
-                                       int dtype, int B, int H, int W, int C, void* dx, hd_stream stream) {
-  if (!g1 || !g2 || !g3 || !idx1 || !idx2 || !idx3 || !dx) return HD_ERR_NULL;
-  if (!hd_sppf_pools_supported(dtype, B, H, W, C)) return HD_ERR_SHAPE;
-  const int V = dtype == 0 ? 4 : 8;
-  int64_t l1 = 0, l2 = 0, l3 = 0;
-  if (pool_stride(g1_row_stride, C, V, &l1) != HD_OK || pool_stride(g2_row_stride, C, V, &l2) != HD_OK ||
-      pool_stride(g3_row_stride, C, V, &l3) != HD_OK)
-    return HD_ERR_SHAPE;
-  if (!hd_aligned16(g1) || !hd_aligned16(g2) || !hd_aligned16(g3) || !hd_aligned16(dx) || (reinterpret_cast<uintptr_t>(idx1) & 7u) ||
-      (reinterpret_cast<uintptr_t>(idx2) & 7u) || (reinterpret_cast<uintptr_t>(idx3) & 7u))
-    return HD_ERR_ALIGN;
-  const dim3 grid((unsigned)(C / (2 * V)), (unsigned)B);
-  const size_t lds = sppf_bwd_lds(dtype, H, W);
-  if (dtype == 0)
-    (void)hd_launch(sppf_pools_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, static_cast<const float*>(g1),
-                    (long long)l1, static_cast<const float*>(g2), (long long)l2, static_cast<const float*>(g3), (long long)l3, idx1,
-                    idx2, idx3, B, H, W, C, static_cast<float*>(dx));
-  else
-    (void)hd_launch(sppf_pools_bwd_kernel<__hip_bfloat16>, grid, dim3(256), lds, (hipStream_t)stream,
-                    static_cast<const __hip_bfloat16*>(g1), (long long)l1, static_cast<const __hip_bfloat16*>(g2), (long long)l2,
-                    static_cast<const __hip_bfloat16*>(g3), (long long)l3, idx1, idx2, idx3, B, H, W, C,
-                    static_cast<__hip_bfloat16*>(dx));
-  HD_RETURN_IF_LAUNCH_FAILED();
-  return HD_OK;
-}

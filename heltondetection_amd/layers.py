@@ -442,9 +442,6 @@ class SPPF(nn.Module):
             from . import ops  # HIP SPPF pool (arg-max tap forward, gather backward); see csrc/pool.hip
             # cv1's activation and the three pools are written straight into their quarter of the concatenation
             x = self.cv1(x, None, cb.slot(0))
-            if ops.sppf_pools_supported(x):   # the three pools (and, backward, the branch sums) in one launch
-                y1, y2, y3 = ops.sppf_pools(x, (cb.slot(1), cb.slot(2), cb.slot(3)))
-                return self.cv2(cb.join((x, y1, y2, y3)))
             if ops.maxpool5_supported(x):
                 y1 = ops.maxpool5(x, cb.slot(1))
                 y2 = ops.maxpool5(y1, cb.slot(2))

@@ -903,79 +903,6 @@ def maxpool5(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return _MaxPool5Fn.apply(x, _OutSlot(out) if out is not None else None)
 
 
-class SppfPoolsSwitch:
-    """SPPF's three chained 5x5 pools as one launch each way (csrc/pool.hip: sppf_pools_*), the image plane in LDS.
-    OFF by default (HD_SPPF_FUSED=1 switches it on): exact (tests/test_gpu_sppf_pools.py) but slower on the 20 x 20 level of
-    YOLOv5s 640^2 bs16 — forward 57 us against 3 x 13 us, backward 105 us against 3 x 17 us + three 6 us adds, step 5.28 ->
-    5.32 ms.  One workgroup per (image, 16 channels) is 256 workgroups of 4 waves: one wave per SIMD runs the 25-tap compare
-    chains (1000 VALU operations per output vector) with nothing to overlap its LDS and dependency latency, while the separate
-    kernels put 12 waves on every CU; the HBM bytes saved (every map read once) were never the bound — the unfused kernels
-    are bound by L1 / L2 re-reads and VALU in equal parts."""
-    enabled = os.environ.get("HD_SPPF_FUSED", "0") == "1"
-
-
-class _SppfPoolsFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, s1, s2, s3):
-        lib = _lib.load()
-        B, Cc, H, W = x.shape
-        dt = {torch.float32: 0, torch.bfloat16: 1}[x.dtype]
-        vec = 4 if dt == 0 else 8
-        outs = []
-        for s_ in (s1, s2, s3):
-            outs.append(s_.t if s_ is not None else torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device,
-                                                                  memory_format=torch.channels_last))
-        lds = [_cl_row_stride(t, vec) for t in (x, *outs)]
-        if any(l is None for l in lds):
-            raise _lib.HdError("sppf_pools: input / outputs must be (channel slices of) channels-last tensors")
-        idx = [torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device) for _ in range(3)]
-        check(lib.hd_sppf_pools_fwd(_ptr(x), int(lds[0]), dt, B, H, W, Cc, _ptr(outs[0]), int(lds[1]), _ptr(outs[1]), int(lds[2]),
-                                    _ptr(outs[2]), int(lds[3]), _ptr(idx[0]), _ptr(idx[1]), _ptr(idx[2]), _stream(x)),
-              "hd_sppf_pools_fwd")
-        ctx.save_for_backward(*idx)
-        ctx.meta = (dt, B, H, W, Cc)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, g1, g2, g3):
-        lib = _lib.load()
-        idx = ctx.saved_tensors
-        dt, B, H, W, Cc = ctx.meta
-        want = torch.float32 if dt == 0 else torch.bfloat16
-        vec = 4 if dt == 0 else 8
-        gs, lds = [], []
-        for g in (g1, g2, g3):
-            if g is None:
-                g = torch.zeros((B, Cc, H, W), dtype=want, device=idx[0].device, memory_format=torch.channels_last)
-            ld = _cl_row_stride(g, vec)
-            if ld is None or g.dtype != want:
-                g = g.to(want).contiguous(memory_format=torch.channels_last)
-                ld = Cc
-            gs.append(g)
-            lds.append(ld)
-        dx = torch.empty((B, Cc, H, W), dtype=want, device=gs[0].device, memory_format=torch.channels_last)
-        check(lib.hd_sppf_pools_bwd(_ptr(gs[0]), int(lds[0]), _ptr(gs[1]), int(lds[1]), _ptr(gs[2]), int(lds[2]), _ptr(idx[0]),
-                                    _ptr(idx[1]), _ptr(idx[2]), dt, B, H, W, Cc, _ptr(dx), _stream(dx)), "hd_sppf_pools_bwd")
-        return dx, None, None, None
-
-
-def sppf_pools_supported(x: torch.Tensor) -> bool:
-    if not (SppfPoolsSwitch.enabled and maxpool5_supported(x)):
-        return False
-    B, Cc, H, W = x.shape
-    return bool(_lib.load().hd_sppf_pools_supported(0 if x.dtype == torch.float32 else 1, B, H, W, Cc))
-
-
-def sppf_pools(x: torch.Tensor, outs: Optional[Sequence[Optional[torch.Tensor]]] = None):
-    """(y1, y2, y3) = the three chained 5x5 / stride 1 / pad 2 max-pools of SPPF in one launch (one more for the backward of all
-    three, branch gradients included); outs: three CatBuffer slots (or None) to write them into.  Values, tap indices and —
-    up to the float32 intermediate sums — gradients equal maxpool5(maxpool5(maxpool5(x)))'s."""
-    if not sppf_pools_supported(x):
-        raise _lib.HdError("sppf_pools: needs a channels-last float32 / bfloat16 HIP tensor whose plane fits LDS")
-    outs = tuple(outs) if outs is not None else (None, None, None)
-    return _SppfPoolsFn.apply(x, *[_OutSlot(o) if o is not None else None for o in outs])
-
-
 class _MaxPool3s2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1190,57 +1117,6 @@ def _fwd_sums(slot: "_StatSlot", channels: int) -> torch.Tensor:
     return sums
 
 
-class WgradOverlap:
-    """The 3x3 weight gradients on a SECOND stream.  In backward the data gradient is the critical path (the next layer's
-    BatchNorm backward waits for it); a 3x3 layer's weight gradient (MFMA-bound, 20-60 us) is needed only when its bucket is
-    reduced or the optimizer runs.  With `active` (set by train.Trainer around backward) ops.conv3x3_wgrad_rows forks a side
-    stream at the point of the call — the side stream waits for everything enqueued so far, i.e. for dy and x — launches there
-    and returns; the main stream goes on with the data gradient and the HBM-bound BatchNorm kernels of the following layers,
-    which leave the matrix pipes idle.  `join()` (from flush_wgrad(): before a bucket is packed, at the end of backward) makes
-    the current stream wait for the side stream.  Under hipGraph capture the fork / join become graph edges: the captured
-    step holds two branches.  The side lane has its own slice-sum chain and slabs (_WgradChain lane 1): a job never rides in a
-    launch of the other stream.  Tensors handed to the side stream stay referenced until the join (the caching allocator may
-    hand a freed block to the main stream at once).
-    OFF by default (HD_WGRAD_OVERLAP=1 switches it on): measured on the YOLOv5s 640^2 bs16 step, hipGraph replay, the 15 forks
-    and joins made the step SLOWER, 5.28 -> 5.62 ms — every cross-branch edge of a replayed hipGraph is a barrier packet between
-    hardware queues, and the concurrent MFMA-bound weight gradient takes CUs from the data gradient it was meant to hide
-    behind."""
-    enabled = os.environ.get("HD_WGRAD_OVERLAP", "0") == "1"
-    active = False
-    _side: dict = {}
-    _forked: set = set()
-    _keep: list = []
-
-    @classmethod
-    def lane(cls, device) -> int:
-        return 1 if (cls.enabled and cls.active and device.type == "cuda") else 0
-
-    @classmethod
-    def side_stream(cls, device):
-        key = _WgradChain._key(device)
-        st = cls._side.get(key)
-        if st is None:
-            st = cls._side[key] = torch.cuda.Stream(torch.device(key[0], key[1]))
-        return st
-
-    @classmethod
-    def fork(cls, device, *keep):
-        """-> the side stream, ordered behind everything enqueued on the current stream so far."""
-        st = cls.side_stream(device)
-        st.wait_stream(torch.cuda.current_stream(device))
-        cls._forked.add(_WgradChain._key(device))
-        cls._keep.extend(keep)
-        return st
-
-    @classmethod
-    def join(cls) -> None:
-        for key in list(cls._forked):
-            dev = torch.device(key[0], key[1])
-            torch.cuda.current_stream(dev).wait_stream(cls._side[key])
-        cls._forked.clear()
-        cls._keep.clear()
-
-
 class _WgradChain:
     """Weight gradients are computed as row-sliced float32 partial products (a slab) plus their sum over the slices.  Inside
     a training step (`enabled`, set by train.Trainer around backward) the sum of layer L does not get a launch of its own:
@@ -1263,10 +1139,9 @@ class _WgradChain:
         return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
     @classmethod
-    def slab(cls, device, nbytes: int, lane: int = 0) -> torch.Tensor:
-        """A slab of >= nbytes that is NOT the one the pending job's partial products live in.  lane 1: the side stream's own
-        pair and chain (WgradOverlap)."""
-        key = cls._key(device) + ((lane,) if lane else ())
+    def slab(cls, device, nbytes: int) -> torch.Tensor:
+        """A slab of >= nbytes that is NOT the one the pending job's partial products live in."""
+        key = cls._key(device)
         pair = cls._slabs.setdefault(key, [None, None])
         pend = cls._pending.get(key)
         busy = pend[1][0] if pend is not None else None
@@ -1288,19 +1163,19 @@ class _WgradChain:
                   "hd_wgrad_reduce")
 
     @classmethod
-    def piggyback(cls, device, lane: int = 0):
+    def piggyback(cls, device):
         """The pending job of `device` (to ride in the launch being prepared), or None."""
-        pend = cls._pending.pop(cls._key(device) + ((lane,) if lane else ()), None)
+        pend = cls._pending.pop(cls._key(device), None)
         return pend
 
     @classmethod
-    def submit(cls, device, job, keep, leaf=None, lane: int = 0) -> None:
+    def submit(cls, device, job, keep, leaf=None) -> None:
         """`job` (a filled WgradJob) has been launched: chain it, or sum it right away.  Chained only inside a training step
         AND when the gradient goes to an autograd LEAF (the bf16 weight shadow): AccumulateGrad takes a leaf's first gradient
         as it is and nothing reads it before the bucket is packed; a non-leaf weight (autocast's cast of a float32 master)
         has its gradient cast back by the very next autograd node, which must see the finished sum."""
         if cls.enabled and leaf is not None and leaf.is_leaf:
-            cls._pending[cls._key(device) + ((lane,) if lane else ())] = (job, keep)
+            cls._pending[cls._key(device)] = (job, keep)
             if leaf is not None:
                 import weakref
                 cls._handed.append((weakref.ref(leaf), int(job.dw)))
@@ -1322,20 +1197,12 @@ class _WgradChain:
         aborted step are lost, which is what an aborted step means."""
         cls._pending.clear()
         cls._handed.clear()
-        WgradOverlap._forked.clear()
-        WgradOverlap._keep.clear()
 
     @classmethod
     def flush(cls) -> None:
         for key, (job, keep) in list(cls._pending.items()):
-            dev = torch.device(key[0], key[1])
-            if len(key) > 2:   # the side lane's last job: summed on the side stream, behind the launch that produced it
-                with torch.cuda.stream(WgradOverlap.side_stream(dev)):
-                    cls._reduce_now(job, dev)
-            else:
-                cls._reduce_now(job, dev)
+            cls._reduce_now(job, torch.device(key[0], key[1]))
         cls._pending.clear()
-        WgradOverlap.join()
         # a chained gradient is complete only after the launch that carried its sum: autograd must have taken the returned
         # tensor as it is (AccumulateGrad steals a fresh dense gradient); a copy taken earlier would hold unsummed bytes
         for ref, ptr in cls._handed:
@@ -1353,30 +1220,14 @@ def flush_wgrad() -> None:
     _WgradChain.flush()
 
 
-def _wgrad_workspace(device, nbytes: int, lane: int = 0) -> torch.Tensor:
+def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
     """One of the device's two float32 slabs (see _WgradChain), at least `nbytes` long."""
-    return _WgradChain.slab(device, nbytes, lane)
+    return _WgradChain.slab(device, nbytes)
 
 
-def _bn_bwd_struct(st: "_BNState", y_raw: torch.Tensor, g_: "_BNGrad", dg: Optional[torch.Tensor]):
-    """hd_bn_bwd for the gradient entry points that fold the BatchNorm backward into their operand load."""
-    bn = _lib.BnBwd()
-    bn.y = y_raw.data_ptr()
-    bn.y_row_stride = int(_cl_row_stride(y_raw, 8))
-    bn.save_mean, bn.save_invstd = st.save[0].data_ptr(), st.save[1].data_ptr()
-    bn.gamma, bn.beta = st.w.data_ptr(), st.b.data_ptr()
-    bn.dsums = g_.dsums.data_ptr()
-    bn.rows = int(st.stat_rows) if st.stat_rows else int(st.R)
-    bn.act = int(st.act)
-    bn.dgamma = dg[1].data_ptr() if dg is not None else None
-    bn.dbeta = dg[0].data_ptr() if dg is not None else None
-    return bn
-
-
-def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None, bn=None, dy_tail=None,
+def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch.Tensor] = None,
                          add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx[B, Cin, H, W] = dy[B, Cout, H, W] . w2[Cout, Cin] on channels-last rows, no autograd; Cout in {32, 64, 128, 256}.
-    bn / dy_tail: as for pointwise_wgrad_rows (dy is d(out) of a fused BatchNorm + activation, possibly in two places).
     add: bf16 channels-last rows [B, Cin, H, W] summed into the result in the kernel's epilogue (the gradient that reaches
     the same input through a shortcut) — float32 add of the two bf16 values, one rounding, like a separate bf16 add."""
     lib = _lib.load()
@@ -1385,31 +1236,26 @@ def pointwise_dgrad_rows(dy: torch.Tensor, w2: torch.Tensor, out: Optional[torch
     K = w2.shape[1]
     ld_dy = _cl_row_stride(dy, 8)
     if ld_dy is None or dy.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or not w2.is_contiguous() \
-            or (dy_tail is None and dy.shape[1] != N):
+            or dy.shape[1] != N:
         raise _lib.HdError("pointwise_dgrad: needs bf16 channels-last rows and the dense bf16 [Cout, Cin] forward weight")
     if out is None:
         out = torch.empty((B, K, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     ld_dx = _cl_row_stride(out, 8)
     if ld_dx is None or out.shape != (B, K, H, W) or out.dtype != torch.bfloat16:
         raise _lib.HdError("pointwise_dgrad: `out` must be a bf16 channels-last tensor (or channel slice) [B, Cin, H, W]")
-    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K) + (2 * B * H * W * N if bn is not None else 0),
+    _note_bytes("pointwise_dgrad", 2 * (B * H * W * (K + N) + N * K),
                 {"flops": 2 * B * H * W * K * N, "shape": (B * H * W, N, K)})
     if add is not None:
         ld_add = _cl_row_stride(add, 8)
-        if bn is not None or ld_add is None or add.dtype != torch.bfloat16 or tuple(add.shape) != (B, K, H, W):
-            raise _lib.HdError("pointwise_dgrad: `add` must be bf16 channels-last rows of the result's shape (not with bn)")
+        if ld_add is None or add.dtype != torch.bfloat16 or tuple(add.shape) != (B, K, H, W):
+            raise _lib.HdError("pointwise_dgrad: `add` must be bf16 channels-last rows of the result's shape")
         with _ktimed("pointwise_dgrad"):
             check(lib.hd_pointwise_conv_dgrad_add(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(add), int(ld_add), _ptr(out),
                                                   int(ld_dx), _stream(dy)), "hd_pointwise_conv_dgrad_add")
         return out
     with _ktimed("pointwise_dgrad"):
-        if bn is not None:
-            check(lib.hd_pointwise_conv_dgrad_bn(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
-                                                 C.byref(bn), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
-                  "hd_pointwise_conv_dgrad_bn")
-        else:
-            check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
-                  "hd_pointwise_conv_dgrad")
+        check(lib.hd_pointwise_conv_dgrad(_ptr(dy), int(ld_dy), _ptr(w2), B * H * W, K, N, _ptr(out), int(ld_dx), _stream(dy)),
+              "hd_pointwise_conv_dgrad")
     return out
 
 
@@ -1417,16 +1263,14 @@ def pointwise_wgrad_supported(R: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().hd_pointwise_wgrad_supported(int(R), int(cin), int(cout)))
 
 
-def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=None, cout: Optional[int] = None,
-                         leaf: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, leaf: Optional[torch.Tensor] = None,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dw[Cout, Cin] (bf16) = sum over rows of dy[B, Cout, H, W]^T x[B, Cin, H, W], channels-last rows, no autograd.
-    bn (hd_bn_bwd; dy_tail = the second place of dy, cout = the channels of both places together): dy is d(out) of a fused
-    BatchNorm + activation and the kernel forms the convolution's dy itself (csrc/hd_bn_fuse.h).
     leaf: the tensor autograd will hand the result to (checked by the chain, see _WgradChain).  Inside a training step the
     returned tensor is complete only after the next weight-gradient launch or flush_wgrad()."""
     lib = _lib.load()
     B, K, H, W = x.shape
-    N = int(cout) if cout is not None else int(dy.shape[1])
+    N = int(dy.shape[1])
     ld_dy, ld_x = _cl_row_stride(dy, 8), _cl_row_stride(x, 8)
     if (ld_dy is None or ld_x is None or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
             or x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:]):
@@ -1441,11 +1285,9 @@ def pointwise_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, bn=None, dy_tail=Non
         raise _lib.HdError("pointwise_wgrad: `out` must be a dense bf16 tensor of Cout x Cin elements")
     pend = _WgradChain.piggyback(dy.device)
     job = _lib.WgradJob()
-    # fused: d(out) and y are read where dy was
-    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K) + (2 * R * N if bn is not None else 0), {"flops": 2 * R * K * N, "shape": (R, K, N)})
+    _note_bytes("pointwise_wgrad", 2 * (R * (K + N) + N * K), {"flops": 2 * R * K * N, "shape": (R, K, N)})
     with _ktimed("pointwise_wgrad"):
-        check(lib.hd_pointwise_wgrad_partial(_ptr(dy), int(ld_dy), C.byref(dy_tail) if dy_tail is not None else None,
-                                             C.byref(bn) if bn is not None else None, _ptr(x), int(ld_x), R, K, N, _ptr(dw),
+        check(lib.hd_pointwise_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), R, K, N, _ptr(dw),
                                              _ptr(ws), ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job),
                                              _stream(dy)), "hd_pointwise_wgrad_partial")
     _WgradChain.submit(dy.device, job, (ws,), leaf)  # not dw: a second reference would make autograd copy it
@@ -1648,24 +1490,20 @@ def conv3x3_wgrad_rows(dy: torch.Tensor, x: torch.Tensor, stride: int = 1, out: 
         raise _lib.HdError("conv3x3_wgrad: needs bf16 channels-last rows, x spatially `stride` times dy")
     nbytes = lib.hd_conv3x3_wgrad_workspace_bytes(B, H, W, K, N, int(stride))
     if nbytes == 0:
-        raise _lib.HdError("conv3x3_wgrad: output W must be 20, 40 or 80, channel counts multiples of 64, stride 1 or 2")
-    # inside a training step with a leaf to hand the gradient to: the side stream (WgradOverlap), with its own chain
-    lane = WgradOverlap.lane(dy.device) if (_WgradChain.enabled and leaf is not None and leaf.is_leaf) else 0
-    ws = _wgrad_workspace(dy.device, nbytes, lane)   # the other slab of the pair: a pending chained job stays intact
+        raise _lib.HdError("conv3x3_wgrad: channel counts must be multiples of 32 (<= 1024), stride 1 or 2, and one row block must fit LDS")
+    ws = _wgrad_workspace(dy.device, nbytes)   # the other slab of the pair: a pending chained job stays intact
     dw = out if out is not None else torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     if dw.dtype != torch.bfloat16 or tuple(dw.shape) != (N, K, 3, 3) or not dw.is_contiguous(memory_format=torch.channels_last):
         raise _lib.HdError("conv3x3_wgrad: `out` must be a channels-last bf16 [Cout, Cin, 3, 3] tensor")
-    pend = _WgradChain.piggyback(dy.device, lane)
+    pend = _WgradChain.piggyback(dy.device)
     job = _lib.WgradJob()
     _note_bytes("conv3x3_wgrad", 2 * (B * H * W * (stride * stride * K + N) + 9 * N * K),
                 {"flops": 18 * B * H * W * K * N, "shape": (B, H, W, K, N, stride)})
-    # (dw is NOT among the tensors kept until the join: a second reference would make autograd copy it; the leaf holds it)
-    where = torch.cuda.stream(WgradOverlap.fork(dy.device, dy, x, ws)) if lane else contextlib.nullcontext()
-    with where, _ktimed("conv3x3_wgrad"):
+    with _ktimed("conv3x3_wgrad"):
         check(lib.hd_conv3x3_wgrad_partial(_ptr(dy), int(ld_dy), _ptr(x), int(ld_x), B, H, W, K, N, int(stride), _ptr(dw), _ptr(ws),
                                            ws.numel(), C.byref(pend[0]) if pend is not None else None, C.byref(job), _stream(dy)),
               "hd_conv3x3_wgrad_partial")
-    _WgradChain.submit(dy.device, job, (ws,), leaf, lane)
+    _WgradChain.submit(dy.device, job, (ws,), leaf)
     return dw
 
 
@@ -2121,22 +1959,11 @@ class _BNActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, gres, None, None, None
 
 
-class FuseSwitch:
-    """Class-wide switches of the layer-level fusions (tests flip them to compare against the unfused chain)."""
-    # fold bn_bwd_dx into the convolution's data / weight gradient kernels (csrc/hd_bn_fuse.h).  OFF by default: bit-exact,
-    # but slower — the SiLU' transform (~14 VALU slots per element, two transcendentals) runs inside kernels that hold one or
-    # two waves per SIMD for their LDS slabs and is repeated by every column tile: YOLOv5s 640^2 bs16 dgrad family 0.39 ->
-    # 0.89 ms per step for 0.27 ms of bn_bwd_dx launches saved (profiles/r03_fused_bn_backward.md).  HD_FUSE_BN_BACKWARD=1.
-    bn_backward = os.environ.get("HD_FUSE_BN_BACKWARD", "0") == "1"
-
-
 class _PwConvBNActFn(torch.autograd.Function):
-    """1x1 convolution -> BatchNorm (batch statistics) -> activation [-> + residual] as ONE autograd node, so that the
-    backward can fold the elementwise half of the BatchNorm backward into the convolution's gradient kernels:
-        bn_bwd_reduce (per-channel sums)  ->  hd_pointwise_conv_dgrad_bn + hd_pointwise_wgrad_partial(bn)
-    instead of bn_bwd_reduce, bn_bwd_dx (writes dy), dgrad (reads dy), wgrad (reads dy), wgrad reduce.  Same bits as that
-    chain (the kernels apply bn_bwd_dx's arithmetic to every chunk they stage).  Shapes / modes the fused kernels do not
-    take (pre-activation residual, SyncBN, channel counts outside the kernels' range) run the unfused chain in here."""
+    """1x1 convolution -> BatchNorm (batch statistics) -> activation [-> + residual] as ONE autograd node: its backward runs
+    bn_bwd_reduce, bn_bwd_dx and then the convolution's data + weight gradient in one launch (hd_pointwise_bwd), with a
+    shortcut's gradient added in that kernel's epilogue (`fork`).  (Folding bn_bwd_dx into the gradient kernels' operand load
+    was built in round 3 — bit-identical, slower — and removed in round 5: tools/experiments/r05_removed_paths.patch.)"""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, slot, res, res_mode, out_slot, ours_fwd,
@@ -2177,17 +2004,6 @@ class _PwConvBNActFn(torch.autograd.Function):
         g_ = _bn_backward_reduce(st, y_raw, dout, dout2)
         ours_dx = bool(lib.hd_pointwise_conv_dgrad_supported(R, K, N))
         ours_dw = pointwise_wgrad_supported(R, K, N) and _cl_row_stride(x, 8) is not None
-        fused = (FuseSwitch.bn_backward and st.dt == 1 and st.res is None and st.sync_group is None and need_dw and ours_dw
-                 and (ours_dx or not need_dx) and _cl_row_stride(y_raw, 8) is not None)
-        if fused:
-            dg = torch.empty((2, N), dtype=_F32, device=x.device)
-            bn = _bn_bwd_struct(st, y_raw, g_, dg)
-            dw = pointwise_wgrad_rows(g_.dy, x, bn, g_.tail, N, weight).view(N, K, 1, 1)
-            dx = pointwise_dgrad_rows(g_.dy, weight.view(N, K), None, bn, g_.tail) if need_dx else None
-            if dx is not None and d_skip is not None:
-                dx = dx + d_skip
-            gres = g_.dy if st.res_mode == 2 else None
-            return dx, dw, dg[1], dg[0], None, None, None, None, None, None, gres, None, None, None, None
         dy, dgamma, dbeta, gres = _bn_backward_dx(st, y_raw, g_)
         dx = dw = None
         if need_dw and ours_dw and need_dx and ours_dx and pointwise_bwd_supported(R, K, N):

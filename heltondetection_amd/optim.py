@@ -18,7 +18,7 @@ from . import _lib
 
 # elements per workgroup of hd_adamw_multi.  4096: 1760 workgroups for YOLOv5s' 7.2 M parameters — at 16384 the 440 workgroups kept
 # ~7 waves per CU in flight and the pass ran at 4 TB/s (50 us); 4096 / 2048: 5.293 -> 5.276 ms per step, 8192: 5.288
-_CHUNK = int(os.environ.get("HD_ADAMW_CHUNK", "4096"))
+_CHUNK = 4096   # elements per workgroup of the AdamW pass (round 4 sweep: 5.293 -> 5.276 ms per step against 1024)
 
 
 class _Desc(C.Structure):

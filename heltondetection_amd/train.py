@@ -199,7 +199,6 @@ class Trainer:
             from . import ops
             chain = ops._WgradChain   # weight-gradient slice sums ride in the next weight-gradient launch (ops._WgradChain)
             chain.enabled = True
-            ops.WgradOverlap.active = True   # 3x3 weight gradients on a second stream, joined by flush_wgrad()
             if self._flipped is not None:
                 self._flipped.refresh()
                 self._flipped.__enter__()
@@ -220,7 +219,6 @@ class Trainer:
             LowpWeights.on = False
             if chain is not None:
                 chain.enabled = False
-                ops.WgradOverlap.active = False
                 if self._flipped is not None:
                     self._flipped.__exit__()
         return loss.detach(), parts

@@ -383,20 +383,6 @@ hd_status hd_maxpool5_fwd(const void* in, int64_t in_row_stride, int dtype, int 
                           void* out, int64_t out_row_stride, uint8_t* idx, hd_stream stream);
 hd_status hd_maxpool5_bwd(const void* grad_out, int64_t grad_out_row_stride, const uint8_t* idx, int dtype,
                           int B, int H, int W, int C, void* grad_in, hd_stream stream);
-/* SPPF's chain of three 5x5 pools (reference README.md:9, CSPDarknet's SPPF block) in ONE launch each way: y1 = pool(x),
- * y2 = pool(y1), y3 = pool(y2), with the tap indices of all three (idx1..3, dense [B,H,W,C] uint8 as for hd_maxpool5_fwd).
- * A workgroup keeps one image's H x W plane of 16 (bfloat16) / 8 (float32) channels in LDS, so every value is read from HBM
- * once; values and indices equal three hd_maxpool5_fwd calls bit for bit.  Backward: dx = gather(g1 + gather(g2 +
- * gather(g3, idx3), idx2), idx1) with the two intermediate sums kept in float32 (the separate calls round them to the tensor's
- * dtype and leave the two additions to the caller).  Row strides as for hd_maxpool5_*; dx is dense.
- * hd_sppf_pools_supported: C % 16 (bfloat16) / C % 8 (float32) == 0 and the planes fit the 160 KB of LDS (H x W <= 1241). */
-int hd_sppf_pools_supported(int dtype, int B, int H, int W, int C);
-hd_status hd_sppf_pools_fwd(const void* x, int64_t x_row_stride, int dtype, int B, int H, int W, int C, void* y1,
-                            int64_t y1_row_stride, void* y2, int64_t y2_row_stride, void* y3, int64_t y3_row_stride,
-                            uint8_t* idx1, uint8_t* idx2, uint8_t* idx3, hd_stream stream);
-hd_status hd_sppf_pools_bwd(const void* g1, int64_t g1_row_stride, const void* g2, int64_t g2_row_stride, const void* g3,
-                            int64_t g3_row_stride, const uint8_t* idx1, const uint8_t* idx2, const uint8_t* idx3, int dtype, int B,
-                            int H, int W, int C, void* dx, hd_stream stream);
 /* 3x3 / stride 2 / pad 1 max-pool (the ResNet50 stem, reference README.md:8) on DENSE channels-last tensors: in [B, H, W, C]
  * -> out [B, Ho, Wo, C] with Ho = (H - 1) / 2 + 1; idx: one byte per OUTPUT element (winning tap 0..8), dense.  Backward is
  * the gather form (an input pixel sits under at most 2 x 2 windows): grad_in [B, H, W, C] from grad_out / idx, no atomics. */
@@ -487,29 +473,6 @@ hd_status hd_pointwise_conv_dgrad(const void* dy, int64_t dy_row_stride, const v
 hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, const void* w, int64_t R, int Cin, int Cout, void* y,
                             int64_t y_row_stride, float* stats, hd_stream stream);
 
-/* BatchNorm + activation backward folded into a convolution gradient (csrc/hd_bn_fuse.h).  A layer is
- * y = conv(x, w), out = act(bn(y)) [+ r]; after hd_bn_act_bwd_reduce(y, d(out), ...) has left the per-channel sums in
- * `dsums`, the gradient entry points with the `_bn` / `bn` argument take d(out) where they otherwise take dy and form
- *     dy = A dz + (P y + Q),   dz = d(out) act'(z),   z = bn(y)
- * while they stage the operand — the arithmetic, operation order and bf16 rounding of hd_bn_act_bwd_dx, whose launch (and
- * the dy tensor) they replace.  y: bfloat16 rows [R, C] (y_row_stride elements, 0 = dense); save_mean / save_invstd /
- * gamma / beta: float32 [C] as for hd_bn_act_bwd_dx; rows: the row count the batch statistics were taken over (R, or
- * R x replicas under SyncBN); act: 0 none, 1 SiLU, 2 ReLU (no pre-activation residual); dgamma / dbeta (both or
- * neither): written by the weight-gradient call.  d(out) may live in two places (hd_rows2, as for hd_bn_act_bwd_*). */
-typedef struct hd_bn_bwd {
-  const void* y;
-  int64_t y_row_stride;
-  const float* save_mean;
-  const float* save_invstd;
-  const float* gamma;
-  const float* beta;
-  const float* dsums;
-  int64_t rows;
-  int act;
-  float* dgamma;
-  float* dbeta;
-} hd_bn_bwd;
-
 /* The row-sliced float32 partial products of a weight gradient that still have to be summed into dw (bfloat16, `count`
  * elements, a multiple of 4): hd_*_wgrad_partial fills one; it is consumed either by hd_wgrad_reduce (a launch of its
  * own) or as the `piggyback` argument of the NEXT hd_*_wgrad_partial call on the same stream, whose launch then carries
@@ -528,16 +491,11 @@ hd_status hd_wgrad_reduce(const hd_wgrad_job* job, hd_stream stream);
 hd_status hd_pointwise_conv_dgrad_add(const void* dy, int64_t dy_row_stride, const void* w, int64_t R, int Cin, int Cout,
                                       const void* add, int64_t add_row_stride, void* dx, int64_t dx_row_stride,
                                       hd_stream stream);
-/* hd_pointwise_conv_dgrad with the fused BatchNorm backward: dx[R, Cin] = dy[R, Cout] . w, dy formed from dout / bn. */
-hd_status hd_pointwise_conv_dgrad_bn(const void* dout, int64_t dout_row_stride, const hd_rows2* dout_tail, const hd_bn_bwd* bn,
-                                     const void* w, int64_t R, int Cin, int Cout, void* dx, int64_t dx_row_stride,
-                                     hd_stream stream);
-/* hd_pointwise_wgrad split in its two halves: this call launches the partial products (bn nullable: dy is then taken as
- * it is; piggyback nullable) and describes the pending summation in *job_out (dw is written by whoever runs the job). */
-hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const hd_rows2* dy_tail, const hd_bn_bwd* bn,
-                                     const void* x, int64_t x_row_stride, int64_t R, int Cin, int Cout, void* dw,
-                                     void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback,
-                                     hd_wgrad_job* job_out, hd_stream stream);
+/* hd_pointwise_wgrad split in its two halves: this call launches the partial products (piggyback nullable) and describes the
+ * pending summation in *job_out (dw is written by whoever runs the job). */
+hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int64_t R,
+                                     int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes,
+                                     const hd_wgrad_job* piggyback, hd_wgrad_job* job_out, hd_stream stream);
 
 /* The WHOLE backward of a 1x1 convolution in one launch (csrc/pointwise_bwd.hip; README.md:9 — every C3 / Bottleneck block
  * of the reference's CSPDarknet / PAFPN is 1x1-heavy): dx[R, Cin] = dy[R, Cout] . w (+ add, as hd_pointwise_conv_dgrad_add;
@@ -545,11 +503,9 @@ hd_status hd_pointwise_wgrad_partial(const void* dy, int64_t dy_row_stride, cons
  * the pair hd_pointwise_conv_dgrad[_add] + hd_pointwise_wgrad_partial where Cout is 32 / 64 / 128 / 256 (the reduction of
  * the data gradient) and Cin a multiple of 32 with at most 32 column tiles.  w: the forward weight [Cout][Cin] as it lies.
  * The slab holds ONE partial per workgroup of a column tile (hd_pointwise_bwd_workspace_bytes: 4-8 MB whatever the layer);
- * piggyback / job_out as for hd_pointwise_wgrad_partial.  dx may alias add.  hd_pointwise_bwd_tune(grid) overrides the
- * planned main grid for experiments (0 = planned; call hd_pointwise_bwd_workspace_bytes again afterwards). */
+ * piggyback / job_out as for hd_pointwise_wgrad_partial.  dx may alias add. */
 int hd_pointwise_bwd_supported(int64_t R, int Cin, int Cout);
 size_t hd_pointwise_bwd_workspace_bytes(int64_t R, int Cin, int Cout);
-void hd_pointwise_bwd_tune(int grid);
 hd_status hd_pointwise_bwd(const void* dy, int64_t dy_row_stride, const void* w, const void* x, int64_t x_row_stride, int64_t R,
                            int Cin, int Cout, const void* add, int64_t add_row_stride, void* dx, int64_t dx_row_stride, void* dw,
                            void* workspace, size_t workspace_bytes, const hd_wgrad_job* piggyback, hd_wgrad_job* job_out,
@@ -603,8 +559,9 @@ hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* 
 /* 3x3 / stride 1 / pad 1 convolution forward on channels-last rows, BatchNorm statistics in the epilogue like
  * hd_pointwise_conv (the bottleneck 3x3 of the YOLOv5 C3 blocks):
  *     y[b, h, w, n] (bfloat16) = sum over (ky, kx, c) of x[b, h + ky - 1, w + kx - 1, c] * w[n][ky][kx][c]
- * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 26, 40, 52, 80, 104}; Cin, Cout
- * multiples of 64; row strides in elements (0 = dense, multiples of 8).  stats: nullable, as for hd_pointwise_conv.
+ * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 26, 40, 52, 80, 104}; Cin a
+ * multiple of 32, Cout of 64 (csrc/conv3x3.hip); row strides in elements (0 = dense, multiples of 8).  stats: nullable, as for
+ * hd_pointwise_conv.
  * The data gradient is the same entry point applied to dy with the weights flipped and transposed:
  *     wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]   ->   dx = hd_conv3x3_fwd(dy, wt, ..., Cin = Cout, Cout = Cin). */
 int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);
@@ -616,7 +573,11 @@ hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int
  *     dw[n][ky][kx][k] (bfloat16, i.e. a channels-last [Cout, Cin, 3, 3] weight) = sum over (b, h, w) of
  *         dy[b, h, w, n] * x[b, stride h + ky - 1, stride w + kx - 1, k]   (zero outside the image; float32 accumulate)
  * H, W: the OUTPUT size; dy [B, H, W, Cout], x [B, stride H, stride W, Cin] bfloat16 rows (strides in elements, 0 = dense).
- * W in {20, 26, 40, 52, 80, 104}; Cin, Cout multiples of 64.  Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
+ * Two kernels behind one entry point: the row kernels (csrc/pointwise_conv.hip: W in {20, 26, 40, 52, 80, 104}, Cin, Cout
+ * multiples of 64) and the flat-position kernel (csrc/conv3x3_wgrad.hip: any W whose row block fits LDS, Cin, Cout multiples
+ * of 32); hd_conv3x3_wgrad_supported says which shapes are taken, hd_conv3x3_wgrad_select(mode) overrides the choice between
+ * the two (0 automatic, 1 row kernels only, 2 the flat kernel on every shape it can run: tests and probes).
+ * Two launches (row-sliced partial products for all nine taps, then the slab sum), no zero-fill.
  * workspace: hd_conv3x3_wgrad_workspace_bytes(...), 16-byte aligned, contents undefined on entry and exit. */
 /* The flipped, transposed weights hd_conv3x3_fwd takes as a data gradient, wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c], for up
  * to HD_MAX_FLIP layers in ONE launch (w[l]: bfloat16 [Cout][3][3][Cin], wt[l]: bfloat16 [Cin][3][3][Cout]; the pointer and
@@ -625,6 +586,7 @@ hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int
 hd_status hd_conv3x3_flip_weights(int n_layers, const void* const* w, void* const* wt, const int* cout, const int* cin,
                                   hd_stream stream);
 int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride);
+void hd_conv3x3_wgrad_select(int mode);
 size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 hd_status hd_conv3x3_wgrad(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int H, int W,
                            int Cin, int Cout, int stride, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);

@@ -99,6 +99,3 @@ def test_detect_convolution_host_arithmetic_and_validation():
     assert lib.hd_head_conv_bwd_supported(6400, 128, 300) == 0
     assert lib.hd_head_conv_bwd_workspace_bytes(102400, 128, 255) == lib.hd_pointwise_bwd_workspace_bytes(102400, 128, 256) > 0
     assert lib.hd_head_conv_fwd(None, 0, None, None, 64, 128, 255, None, 0, None) == -1          # HD_ERR_NULL
-    assert lib.hd_sppf_pools_supported(1, 16, 20, 20, 256) == 1
-    assert lib.hd_sppf_pools_supported(1, 16, 80, 80, 256) == 0         # the planes do not fit LDS
-    assert lib.hd_sppf_pools_supported(1, 16, 20, 20, 24) == 0          # 16 channels per workgroup

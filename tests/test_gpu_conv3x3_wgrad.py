@@ -6,6 +6,19 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "flat"])
+def wgrad_kernel(request):
+    """The weight gradient has two kernels behind one entry point (row kernels / flat-position kernel, csrc/conv3x3_wgrad.hip);
+    `flat` forces the second on every shape it can run, `auto` is the shipped choice."""
+    from heltondetection_amd import _lib
+    lib = _lib.load()
+    lib.hd_conv3x3_wgrad_select(2 if request.param == "flat" else 0)
+    try:
+        yield request.param
+    finally:
+        lib.hd_conv3x3_wgrad_select(0)
+
+
 def _ref(dy, x, stride=1):
     w = torch.zeros((dy.shape[1], x.shape[1], 3, 3), dtype=torch.float32, device=x.device)
     return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (stride, stride), (1, 1), (1, 1), False, (0, 0), 1,
@@ -14,8 +27,11 @@ def _ref(dy, x, stride=1):
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (3, 64, 40, 40, 128), (2, 128, 13, 40, 128),
                                    (1, 64, 80, 80, 64), (2, 64, 5, 80, 64), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64),
-                                   (2, 64, 26, 26, 128), (1, 128, 11, 52, 64), (1, 64, 9, 104, 64)])
-def test_conv3x3_wgrad_is_exact_on_integer_data(shape):
+                                   (2, 64, 26, 26, 128), (1, 128, 11, 52, 64), (1, 64, 9, 104, 64),
+                                   # round 5 (flat position blocks): channel counts in multiples of 32, any width, many slices
+                                   (2, 32, 9, 40, 32), (1, 96, 6, 12, 64), (2, 32, 5, 160, 32), (1, 32, 3, 208, 64), (3, 160, 17, 33, 96),
+                                   (16, 128, 40, 40, 128), (4, 32, 160, 160, 32)])
+def test_conv3x3_wgrad_is_exact_on_integer_data(shape, wgrad_kernel):
     """Small integers: all products and sums are exact in float32, so borders (zero halo), row slices with their halo
     rows, the pixel padding to 16 and the tap -> (row slot, shift) mapping must reproduce the exact gradient."""
     from heltondetection_amd import ops
@@ -24,6 +40,9 @@ def test_conv3x3_wgrad_is_exact_on_integer_data(shape):
     g = torch.Generator().manual_seed(K + N + H + W)
     x = torch.randint(-2, 3, (B, K, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dy = torch.randint(-2, 3, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if not ops.conv3x3_wgrad_supported(x, N, 1):
+        assert wgrad_kernel == "auto"      # a shape the shipped choice leaves to the library
+        pytest.skip("left to the library by the automatic choice")
     dw = ops.conv3x3_wgrad_rows(dy, x)
     ref = _ref(dy, x)
     assert dw.shape == (N, K, 3, 3) and dw.dtype == torch.bfloat16
@@ -64,8 +83,9 @@ def test_conv3x3_layer_matches_library_path():
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 64, 9, 40, 64),
                                    (1, 64, 80, 80, 128), (16, 256, 20, 20, 512), (1, 64, 1, 20, 64),
-                                   (2, 64, 13, 26, 64), (1, 64, 7, 52, 128), (1, 64, 5, 104, 64)])
-def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
+                                   (2, 64, 13, 26, 64), (1, 64, 7, 52, 128), (1, 64, 5, 104, 64),
+                                   (2, 32, 9, 40, 64), (1, 96, 5, 11, 32), (2, 32, 6, 160, 64), (16, 128, 40, 40, 256), (3, 64, 7, 30, 96)])
+def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape, wgrad_kernel):
     """Stride 2: (B, Cin, Ho, Wo, Cout) with the input 2 Ho x 2 Wo; even / odd pixel planes, two new input rows per output row."""
     from heltondetection_amd import ops
     dev = torch.device("cuda:0")
@@ -73,7 +93,9 @@ def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape):
     g = torch.Generator().manual_seed(K + N + H + W + 1)
     x = torch.randint(-2, 3, (B, K, 2 * H, 2 * W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dy = torch.randint(-2, 3, (B, N, H, W), generator=g).float().to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    assert ops.conv3x3_wgrad_supported(x, N, 2)
+    if not ops.conv3x3_wgrad_supported(x, N, 2):
+        assert wgrad_kernel == "auto"
+        pytest.skip("left to the library by the automatic choice")
     dw = ops.conv3x3_wgrad_rows(dy, x, 2)
     ref = _ref(dy, x, 2)
     assert torch.equal(dw.float(), ref.to(torch.bfloat16).float())
@@ -155,41 +177,3 @@ def test_flipped_weights_of_all_layers_in_one_launch_equal_flip_permute():
             assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
             assert torch.equal(got, want)
     assert ops.FlippedWeights.get(ws[0]) is None
-
-
-def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones():
-    """ops.WgradOverlap (off by default, HD_WGRAD_OVERLAP=1): three chained 3x3 weight gradients launched on the side stream,
-    interleaved with main-stream work that overwrites nothing they read, joined by flush_wgrad() — bit-identical to the same
-    three launched in line (same kernels, same slices; the side lane has its own slabs and slice-sum chain)."""
-    from heltondetection_amd import ops
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(5)
-    shapes = [(4, 64, 40, 40, 64), (4, 128, 20, 20, 128), (4, 64, 80, 80, 64)]
-    data = []
-    for B, K, H, W, N in shapes:
-        x = torch.randn((B, K, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dy = torch.randn((B, N, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        data.append((dy, x))
-    out = {}
-    was = (ops.WgradOverlap.enabled, ops.WgradOverlap.active, ops._WgradChain.enabled)
-    try:
-        for side in (False, True):
-            ops.WgradOverlap.enabled = ops.WgradOverlap.active = side
-            ops._WgradChain.enabled = True
-            leaves = [torch.empty((s[4], s[1], 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
-                      .requires_grad_(True) for s in shapes]
-            dws = []
-            for (dy, x), leaf in zip(data, leaves):
-                dws.append(ops.conv3x3_wgrad_rows(dy, x, leaf=leaf))
-                (x.float() * 2).sum()                      # unrelated main-stream work between the launches
-            assert (len(ops.WgradOverlap._forked) > 0) == side
-            ops._WgradChain._handed.clear()                # no autograd here: nobody takes the tensors as .grad
-            ops.flush_wgrad()
-            assert len(ops.WgradOverlap._forked) == 0 and not ops.WgradOverlap._keep
-            torch.cuda.synchronize()
-            out[side] = [d.clone() for d in dws]
-    finally:
-        ops.WgradOverlap.enabled, ops.WgradOverlap.active, ops._WgradChain.enabled = was
-        ops._WgradChain.reset()
-    for a, b in zip(out[True], out[False]):
-        assert torch.equal(a, b)

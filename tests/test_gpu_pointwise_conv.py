@@ -255,59 +255,13 @@ FUSED_CASES = [(64, 64, 24, "silu", False, False), (128, 128, 13, "silu", True, 
 
 
 @pytest.mark.parametrize("cin,cout,hw,act,residual,two_place", FUSED_CASES)
-def test_fused_bn_backward_kernels_are_bit_identical_to_bn_bwd_dx_then_gradients(cin, cout, hw, act, residual, two_place):
-    """hd_pointwise_conv_dgrad_bn / hd_pointwise_wgrad_partial(bn) against hd_bn_act_bwd_dx -> hd_pointwise_conv_dgrad /
-    hd_pointwise_wgrad on the SAME per-channel sums (one bn_bwd_reduce launch feeds both; its float atomics are the only
-    run-to-run freedom): the fused kernels apply bn_bwd_dx's arithmetic to every chunk they stage, so dx, dw, dgamma and
-    dbeta must come out with the same bits — ragged rows, post-activation residual, d(out) in two places (the merged C3
-    branch convolutions), a Cin > 256 layer."""
-    from heltondetection_amd import _lib, ops
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(cin + cout + hw)
-    B = 3
-    x = torch.randn((B, cin, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn((cout, cin, 1, 1), generator=g) * cin ** -0.5).to(dev).to(torch.bfloat16)
-    gamma = (torch.rand((cout,), generator=g) + 0.5).to(dev)
-    beta = (torch.rand((cout,), generator=g) - 0.5).to(dev)
-    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
-    res = torch.randn((B, cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
-    ops.bn_arena_reset(dev)
-    slot = ops.bn_act_slot(dev, cout)
-    y_raw = torch.nn.functional.conv2d(x.float(), w.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    _, _, st = ops._bn_forward(y_raw, gamma, beta, rm, rv, 1e-3, 0.03, ops._ACT_CODE[act], slot, None, res, 2 if residual else 0,
-                               None, False)
-    if two_place:
-        c1 = cout // 2
-        d1 = torch.randn((B, c1, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        wide = torch.randn((B, 2 * cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dout, dout2 = d1, wide[:, cout:cout + (cout - c1)]
-        st.split = c1
-    else:
-        dout = torch.randn((B, cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dout2 = None
-    g_ = ops._bn_backward_reduce(st, y_raw, dout, dout2)
-    dy, dgamma, dbeta, _ = ops._bn_backward_dx(st, y_raw, g_)
-    R = B * hw * hw
-    lib = _lib.load()
-    dg = torch.zeros((2, cout), dtype=torch.float32, device=dev)
-    bn = ops._bn_bwd_struct(st, y_raw, g_, dg)
-    dw = ops.pointwise_wgrad_rows(g_.dy, x, bn, g_.tail, cout)
-    dw_ref = ops.pointwise_wgrad_rows(dy, x)
-    assert torch.equal(dw, dw_ref), float((dw.float() - dw_ref.float()).abs().max())
-    assert torch.equal(dg[1], dgamma) and torch.equal(dg[0], dbeta)
-    if lib.hd_pointwise_conv_dgrad_supported(R, cin, cout):
-        dx = ops.pointwise_dgrad_rows(g_.dy, w.view(cout, cin), None, bn, g_.tail)
-        dx_ref = ops.pointwise_dgrad_rows(dy, w.view(cout, cin))
-        assert torch.equal(dx, dx_ref), float((dx.float() - dx_ref.float()).abs().max())
-    else:
-        assert cout not in (32, 64, 128, 256)   # the data gradient's reduction (Cout) must fit the resident-weight kernel
-
-
-@pytest.mark.parametrize("cin,cout,hw,act,residual,two_place", FUSED_CASES)
-def test_fused_conv_bn_act_node_matches_the_unfused_chain(cin, cout, hw, act, residual, two_place):
-    """ops._PwConvBNActFn with ops.FuseSwitch.bn_backward on and off, through layers.ConvBNAct under autocast: two runs, so
-    the float atomics of the statistics / reduce kernels differ in their last bits — equal up to one bf16 rounding."""
-    from heltondetection_amd import layers, ops
+def test_conv_bn_act_node_matches_the_separate_modules(cin, cout, hw, act, residual, two_place):
+    """ops._PwConvBNActFn (one autograd node: convolution + BatchNorm + activation, its backward on hd_bn_act_bwd_* and
+    hd_pointwise_bwd) through layers.ConvBNAct under autocast against the same layer with the 1x1 kernels switched off
+    (library convolution + fused BatchNorm): ragged rows, post-activation residual, output in two places (the merged C3
+    branch convolutions), a Cin > 256 layer, 32-channel tiles.  Two runs of float atomics and two convolution
+    implementations: equal up to a couple of bf16 roundings of the element or of a typical one."""
+    from heltondetection_amd import layers
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     m = layers.ConvBNAct(cin, cout, 1, 1, act=act).to(dev).to(memory_format=torch.channels_last).train()
@@ -322,25 +276,23 @@ def test_fused_conv_bn_act_node_matches_the_unfused_chain(cin, cout, hw, act, re
     else:
         gy = torch.randn((B, cout, hw, hw), device=dev).contiguous(memory_format=torch.channels_last)
     runs = {}
-    was = ops.FuseSwitch.bn_backward
-    for fused in (True, False):
-        ops.FuseSwitch.bn_backward = fused
+    was = layers.ConvBNAct.pointwise
+    for ours in (True, False):
+        layers.ConvBNAct.pointwise = ours
         try:
             out_pair = None
             if two_place:   # first half dense, second half a slice of a wider concatenation buffer
                 y1 = torch.empty((B, c1, hw, hw), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
                 cat = torch.zeros((B, 2 * cout, hw, hw), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
                 out_pair = (y1, cat[:, cout:cout + (cout - c1)])
-            runs[fused] = _layer_run(m, x0, gy, res_in, out_pair, dev)
+            runs[ours] = _layer_run(m, x0, gy, res_in, out_pair, dev)
         finally:
-            ops.FuseSwitch.bn_backward = was
+            layers.ConvBNAct.pointwise = was
     for k in runs[True]:
         a, b = runs[True][k], runs[False][k]
         if a is None:
             continue
-        # two runs: the statistics / reduce kernels' float atomics differ in their last bits, which moves single bf16 roundings
-        # (dx and dw are sums over many such terms): a couple of bf16 roundings of the element or of a typical one
-        tol = 2.0 ** -6 * b.abs() + 2.0 ** -6 * b.abs().mean() + 1e-7
+        tol = 2.0 ** -5 * b.abs() + 2.0 ** -5 * b.abs().mean() + 1e-7
         assert bool(((a - b).abs() <= tol).all()), (k, float(((a - b).abs() / tol).max()))
 
 
