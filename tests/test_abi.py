@@ -15,6 +15,34 @@ def _header_functions():
     return set(re.findall(r"\b(hd_[a-z0-9_]+)\s*\(", src))
 
 
+def _header_abi_digest():
+    """sha256 over everything a caller compiles against: the header without comments and blank runs (prototypes, structs,
+    constants).  Any change of it is an ABI change."""
+    import hashlib
+    src = open(os.path.join(ROOT, "include", "hd_ops.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"\s+", " ", src).strip()
+    return hashlib.sha256(src.encode()).hexdigest()[:16]
+
+
+# version -> digest of the header it was cut from.  A header edit without a new version (hd_abi_version in csrc/lib.hip,
+# ABI_VERSION in _lib.py, a line here) fails this test: a stale libhd_ops.so must fail with "rebuild", not AttributeError
+# (round 4 added 17 entry points at version 29).
+ABI_HEADER_DIGESTS = {30: "1f8ec122881dfc5b"}
+
+
+def test_abi_version_is_bumped_with_the_header():
+    from heltondetection_amd import _lib
+    digest = _header_abi_digest()
+    assert _lib.ABI_VERSION in ABI_HEADER_DIGESTS, f"ABI_VERSION {_lib.ABI_VERSION} has no digest line in tests/test_abi.py"
+    assert ABI_HEADER_DIGESTS[_lib.ABI_VERSION] == digest, (
+        f"include/hd_ops.h changed (digest {digest}) but the ABI version is still {_lib.ABI_VERSION}: bump hd_abi_version / "
+        "ABI_VERSION and add the new (version, digest) line")
+    src = open(os.path.join(ROOT, "heltondetection_amd", "csrc", "lib.hip")).read()
+    assert re.search(r"hd_abi_version\(void\)\s*\{\s*return\s+%d\s*;" % _lib.ABI_VERSION, src)
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     import __graft_entry__ as g
     g.build()

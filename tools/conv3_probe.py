@@ -1,6 +1,6 @@
 """3x3 / stride 1 forward (+ statistics) and data gradient per YOLOv5s / 832^2 layer shape: kernel-only HIP-event times
 (hd_profile_time_next_launch), median of 30 back-to-back launches, TFLOP/s and fraction of the 2.5 PF dense bf16 peak.
-HD_CONV3_V1=1 python tools/conv3_probe.py  runs the round-4 kernel on the same shapes."""
+(The round-4 kernel it replaced is gone; its times on the same shapes: profiles/r05_conv3.md.)"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 SHAPES = [(16, 64, 80, 80, 64), (16, 128, 40, 40, 128), (16, 256, 20, 20, 256), (16, 64, 104, 104, 64), (16, 128, 52, 52, 128),
           (16, 256, 26, 26, 256)]
 rep = _lib.load().hd_bn_act_replicas()
-print("kernel", "v1 (round 4)" if os.environ.get("HD_CONV3_V1") == "1" else "v2 (round 5)")
+print("kernel: csrc/conv3x3.hip (round 5)")
 for B, K, H, W, N in SHAPES:
     x = torch.randn(B, K, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(N, K, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

@@ -1,5 +1,5 @@
 """3x3 weight gradient (stride 1 and 2) per YOLOv5s layer shape: kernel-only HIP-event time of the partial-product launch (with the
-previous launch's slice sum riding in it, as in the step), median of 20.  HD_WGRAD3_V1=1: the round-4 kernels."""
+previous launch's slice sum riding in it, as in the step), median of 20.  WGRAD3_SELECT=1 | 2: the row kernels only | the flat kernel wherever it runs (hd_conv3x3_wgrad_select)."""
 import os
 import sys
 
@@ -12,10 +12,16 @@ dev = torch.device("cuda:0")
 # (B, Cin, Ho, Wo, Cout, stride)
 SHAPES = [(16, 64, 80, 80, 64, 1), (16, 128, 40, 40, 128, 1), (16, 256, 20, 20, 256, 1), (16, 64, 80, 80, 128, 2), (16, 128, 40, 40, 256, 2),
           (16, 256, 20, 20, 512, 2), (16, 128, 40, 40, 128, 2), (16, 256, 20, 20, 256, 2)]
-if os.environ.get("HD_WGRAD3_V1") != "1":
-    SHAPES += [(16, 32, 160, 160, 32, 1), (16, 32, 160, 160, 64, 2)]
-print("kernels", "v1 (round 4)" if os.environ.get("HD_WGRAD3_V1") == "1" else "v2 (round 5)", "HD_WGRAD3_WGS=" + os.environ.get("HD_WGRAD3_WGS", "default"))
+from heltondetection_amd import _lib  # noqa: E402
+sel = int(os.environ.get("WGRAD3_SELECT", "0"))
+_lib.load().hd_conv3x3_wgrad_select(sel)
+if sel != 1:
+    SHAPES += [(16, 32, 160, 160, 32, 1)]
+print("kernels:", {0: "automatic choice", 1: "row kernels (round 4)", 2: "flat-position kernel (round 5)"}[sel])
 for B, K, H, W, N, S in SHAPES:
+    if not ops.conv3x3_wgrad_supported(torch.empty((B, K, S * H, S * W), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last), N, S):
+        print(f"  {B}x{K}x{H}x{W}->{N} s{S}  not taken (library)")
+        continue
     x = torch.randn(B, K, S * H, S * W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dy = torch.randn(B, N, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     leaf = torch.zeros((N, K, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
