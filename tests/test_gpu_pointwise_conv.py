@@ -260,7 +260,9 @@ def test_conv_bn_act_node_matches_the_separate_modules(cin, cout, hw, act, resid
     hd_pointwise_bwd) through layers.ConvBNAct under autocast against the same layer with the 1x1 kernels switched off
     (library convolution + fused BatchNorm): ragged rows, post-activation residual, output in two places (the merged C3
     branch convolutions), a Cin > 256 layer, 32-channel tiles.  Two runs of float atomics and two convolution
-    implementations: equal up to a couple of bf16 roundings of the element or of a typical one."""
+    implementations: equal up to a couple of bf16 roundings of the element or of a typical one — except under ReLU, whose
+    derivative flips for pre-activations that the two paths round to different sides of zero (single elements then differ
+    by their whole value): those cases are bounded in relative L2 (2e-2) instead."""
     from heltondetection_amd import layers
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -291,6 +293,10 @@ def test_conv_bn_act_node_matches_the_separate_modules(cin, cout, hw, act, resid
     for k in runs[True]:
         a, b = runs[True][k], runs[False][k]
         if a is None:
+            continue
+        if act == "relu" and k in ("dx", "dw", "dgamma", "dbeta", "dres"):
+            rel = float((a - b).norm() / (b.norm() + 1e-12))
+            assert rel <= 2e-2, (k, rel)
             continue
         tol = 2.0 ** -5 * b.abs() + 2.0 ** -5 * b.abs().mean() + 1e-7
         assert bool(((a - b).abs() <= tol).all()), (k, float(((a - b).abs() / tol).max()))
