@@ -161,14 +161,14 @@ def loss_bwd_bytes(B, size, no, na=3, strides=(8, 16, 32)):
 
 
 def pmc_traffic(kernel, shape: str = ""):
-    """HBM bytes from the committed counter run of THIS round's build (profiles/r04_pmc_traffic.json, made by tools/prof_r04.sh +
-    tools/pmc_traffic_r04.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled for 16-byte streams as
+    """HBM bytes from the committed counter run of THIS round's build (profiles/r05_pmc_traffic.json, made by tools/prof_r05.sh +
+    tools/pmc_traffic_r05.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled for 16-byte streams as
     MI355X_MICROARCH.md prescribes).  `kernel`: a family name of that file ("hand-written convolutions", "fused BN+act") -> bytes
     per train step (YOLOv5s 640^2 bs16); a single-kernel key of its "single_kernels" table -> bytes per launch; or a kernel-name
     fragment -> bytes per launch of the first step kernel whose name contains it.  None when the file has no such entry (other
     model / size).  PMC counters cannot be read from inside this process, so this is a look-up, and the line says so."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
         fam = rec.get("families_per_step", {}).get(kernel)
         if fam is not None:
             return int(fam["traffic_bytes_per_step"])
@@ -183,9 +183,9 @@ def pmc_traffic(kernel, shape: str = ""):
     return None
 
 
-TRAFFIC_SOURCE = "profiles/r04_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build: eager " \
-                 "YOLOv5s 640x640 bs16 train steps (tools/prof_r04.sh: families = bytes per train step, step kernels = bytes per launch) " \
-                 "and the single-kernel probe at the micro leg's shapes (tools/pmc_traffic_r04.sh); null = no entry for this workload)"
+TRAFFIC_SOURCE = "profiles/r05_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build: eager " \
+                 "YOLOv5s 640x640 bs16 train steps (tools/prof_r05.sh: families = bytes per train step, step kernels = bytes per launch) " \
+                 "and the single-kernel probe at the micro leg's shapes (tools/pmc_traffic_r05.sh); null = no entry for this workload)"
 
 
 def usable_cores() -> int:

@@ -291,7 +291,7 @@ static bool wgrad3_use_v1(int B, int H, int W, int Cin, int Cout, int stride) {
   if (g_wgrad3_select == 1) return true;
   if (g_wgrad3_select == 2) return false;
   if (!hd_conv3x3_wgrad_supported_v1(B, H, W, Cin, Cout, stride)) return false;
-  return !(stride == 1 && W <= 26 && Cin >= 256 && Cout >= 256);
+  return !(stride == 1 && W <= 26 && Cin == 256 && Cout == 256);   // 16 x 256 x 20 x 20: 36 - 40 us flat against 52
 }
 #define wgrad3_v1() wgrad3_use_v1(B, H, W, Cin, Cout, stride)
 
@@ -304,10 +304,14 @@ extern "C" int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout
     return 0;
   if (!(flat_lds(stride, W, 1) <= 150 * 1024 && (long long)(Cin / 32) * (Cout / 32) <= 65535)) return 0;
   if (g_wgrad3_select == 2) return 1;   // tests / probes: every shape the kernel can run
-  // where it is measured to beat what it would replace (see wgrad3_use_v1): small pictures, or the 32-channel layers that
-  // the row kernels do not take (32 -> 32 at 160 x 160: 28 - 30 us against the library's 50 + zero-fill + cast); wide
-  // stride-2 layers (4 x the input of their output) stay where they were
-  return stride == 1 ? (W <= 52 || (Cin == 32 && Cout == 32)) : W <= 26;
+  // Only where it is measured to beat what it would replace (profiles/r05_wgrad3.md).  Shapes the row kernels do not take: narrow
+  // layers (<= 128 channels: the 32 -> 32 layer at 160 x 160 runs 28 - 30 us against the library's 50 + zero-fill + cast) on
+  // small pictures; NOT the 256 / 512-channel layers of config 3 (32 x 32 tiles make 64 - 256 tiles there, each walking a long
+  // chain of blocks: the FasterRCNN step lost 2.9 ms when they were taken) and not wide stride-2 layers (4 x the input of
+  // their output).
+  const bool narrow = Cin <= 128 && Cout <= 128;
+  if (hd_conv3x3_wgrad_supported_v1(B, H, W, Cin, Cout, stride)) return 1;   // the one 256 -> 256 case of wgrad3_use_v1
+  return stride == 1 ? ((W <= 52 && narrow) || (Cin == 32 && Cout == 32)) : (W <= 26 && narrow);
 }
 
 extern "C" size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride) {
