@@ -301,11 +301,12 @@ extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const v
   hipStream_t s = (hipStream_t)stream;
   // <W, ROWS, MT, workgroups per CU>: ROWS x (W + 2) flat positions per workgroup in 4 MT tiles of 32.  Measured per shape
   // (tools/conv3_probe.py, profiles/r05_conv3.md): 80 / 104-pixel rows two workgroups per CU with MT = 2 (MT = 4 alone on the CU:
-  // slower), 40-pixel rows one workgroup of MT = 2 per CU (224 workgroups; two of MT = 1: equal to 4 % slower), 20 / 26 / 52 MT = 1.
+  // slower), 52-pixel rows likewise (25.4 / 21.0 us against 31.6 / 26.3 with MT = 1), 40-pixel rows one workgroup of MT = 2 per CU
+  // (224 workgroups; two of MT = 1: equal to 4 % slower), 20 / 26-pixel rows MT = 1 (MT = 2 would leave half the CUs idle).
   switch (W) {
     case 104: return launch_conv3x3<104, 2, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 80: return launch_conv3x3<80, 3, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
-    case 52: return launch_conv3x3<52, 2, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
+    case 52: return launch_conv3x3<52, 4, 2, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 40: return launch_conv3x3<40, 6, 2, 1>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 26: return launch_conv3x3<26, 4, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
     case 20: return launch_conv3x3<20, 5, 1, 2>(x, x_row_stride, w, y, y_row_stride, B, H, Cin, Cout, stats, s);
