@@ -1025,6 +1025,10 @@ def main():
         log(f"timed region done: {out['value']} images/s (hipGraph={'on' if trainer._graph is not None else 'off'})")
         # Rooflines are measured live, with HIP events on the launch stream, on this workload's own shapes, right
         # after the timed region (inside it the launches sit in a replayed hipGraph, where no event can be recorded).
+        # world > 1: the roofline passes run on rank 0 ALONE, so no collective may be launched from them (an all-reduce the other
+        # ranks never join would sit in front of the final barrier for ever: seen as a hang of the 2-rank rehearsal in round 5)
+        hold_was = trainer.reducer._hold
+        trainer.reducer._hold = trainer.reducer._hold or world > 1
         try:
             if args.no_roofline:
                 out["roofline"] = None
@@ -1038,6 +1042,8 @@ def main():
                 out["roofline_secondary"] = fams[1:] + [roi_align_roofline(model, batches[0], args, device)]
         except Exception as e:  # never lose the headline number to a secondary measurement
             out["roofline_error"] = repr(e)[:300]
+        finally:
+            trainer.reducer._hold = hold_was
         # The CPU baseline comes BEFORE the companion legs: everything the bench contract requires is then in hand and is printed
         # once right away (a later time-limit kill inside a leg cannot lose the headline); the completed line follows at the end.
         if world == 1 and not args.no_cpu_baseline:
@@ -1141,8 +1147,12 @@ def main():
                 pass
         print(compact_line(out, detail), flush=True)   # the LAST thing this process writes
     if world > 1:
+        # a rank that hangs in the teardown must not hang the launcher (and the driver's clock): dump where, then leave
+        import faulthandler
+        faulthandler.dump_traceback_later(90, exit=True)
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
