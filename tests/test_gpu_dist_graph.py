@@ -253,3 +253,25 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst)   # shown with pytest -s / on failure
     assert all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst), worst
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_rank_rehearsal_prints_one_compact_line_and_exits(gpu):
+    """`HD_DIST_BACKEND=gloo python bench.py --gpus 2` on the one GPU: bench.py starts its own two ranks, replays the split graph,
+    runs its roofline passes on rank 0 alone and must still leave through the final barrier (round 5: those passes launched
+    all-reduces no other rank joined and the run hung), printing ONE compact JSON line with the rehearsal markers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "5", "--no-micro",
+                        "--no-cpu-baseline", "--no-legs", "--no-miopen-find"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), [len(l) for l in lines])
+    d = json.loads(lines[0])
+    assert d["config"]["ranks"] == 2 and d["config"]["rehearsal"] is True and d["n_gpus"] == 1 and d["config"]["backend"] == "gloo"
+    assert d["config"]["hip_graph"] is True and d["config"]["hip_graph_segments"] >= 3
+    assert d["value"] > 0 and d["roofline"] is not None and d["roofline"]["frac"] > 0
