@@ -123,6 +123,12 @@ def _worker_overlap(rank, world, port, tmp, use_graph):
     or eager (reference run) and is the ONE optimizer step with lr > 0, so no loss kink can be crossed between the runs."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # The box term stays in the compared step (ADVICE r04), so the logit gradient takes the float32, single-rounding path in BOTH
+    # runs: with the default bf16 rows, cells matched by several targets accumulate through order-dependent bf16 atomics, and that
+    # run-to-run noise is amplified layer by layer on the way back (first suite run of round 5 with the box term and bf16 rows:
+    # buckets 3 - 6 at 0.21 - 0.33 against <= 0.1 without it).  What this test is about — which bucket is reduced when — does not
+    # depend on the gradient's dtype; the bf16 rows are compared with the oracle in tests/test_gpu_parity.py.
+    os.environ["HD_HEAD_GRAD_BF16"] = "0"
     from heltondetection_amd import synthetic as syn
     from heltondetection_amd.detectors import build_detector
     from heltondetection_amd.dist import init_distributed
