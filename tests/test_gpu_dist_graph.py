@@ -257,7 +257,15 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
         cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
         worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
     print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst)   # shown with pytest -s / on failure
-    assert all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst), worst
+    ok = all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst)
+    if not ok:   # which tensors, and by what factor: norm ratio graph / eager per parameter gradient (both runs, rank 0)
+        ratios = []
+        for i, (a, b) in enumerate(zip(g0["grads"], e0["grads"])):
+            nb = float(b.double().norm())
+            ratios.append((i, tuple(a.shape), round(float(a.double().norm()) / nb, 3) if nb > 0 else None,
+                           round(float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm() + 1e-30)), 3)))
+        print("per-parameter (index, shape, |graph| / |eager|, cosine):", ratios)
+    assert ok, worst
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing
 
 
