@@ -178,9 +178,39 @@ def _worker_overlap(rank, world, port, tmp, use_graph):
     dist.destroy_process_group()
 
 
-def _pretrain(tmp_path, steps: int = 300):
+def _step_spread(tr, batch, reps: int = 5):
+    """Run-to-run spread of the eager bf16 step at the trainer's current weights: `reps` steps at lr = 0 on one batch, every
+    bucket's gradient against the first repetition's (relative L2); returns the median over the repetitions of the worst bucket."""
+    class _NoSched:
+        def step(self):
+            pass
+    sched, lrs = tr.sched, [grp["lr"] for grp in tr.opt.param_groups]
+    tr.sched = _NoSched()
+    for grp in tr.opt.param_groups:
+        grp["lr"] = 0.0
+    seen = []
+    for _ in range(reps):
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        seen.append([b.flat.detach().double().clone() for b in tr.reducer.buckets])
+    tr.sched = sched
+    for grp, lr in zip(tr.opt.param_groups, lrs):
+        grp["lr"] = lr
+    worst = sorted(max(float((a - b).norm() / b.norm()) for a, b in zip(rep, seen[0])) for rep in seen[1:])
+    return worst[len(worst) // 2]
+
+
+def _pretrain(tmp_path, steps: int = 300, calm: float = 0.12, rounds: int = 6):
     """One rank, eager: YOLOv5s 128^2 trained for a few hundred product steps on four fixed batches; the state dict is what
-    both 2-rank runs below start from."""
+    both 2-rank runs below start from.
+
+    Which point the training lands on is itself not reproducible (float atomics in the statistics and the loss), and the
+    points differ in how strongly they amplify that noise: tools/repro/step_spread.py (round 5, 60 eager repetitions of one
+    step at lr = 0, one process, no process group) found three points whose buckets stay within 0.15 - 0.19 of the first
+    repetition and one where 20 of 60 repetitions have a bucket beyond 0.33 (worst 0.44) — eager against eager.  A comparison of
+    two runs at such a point says nothing about the reduction (2 of ~10 suite runs of round 5 failed that way).  So the spread
+    is measured here (five lr = 0 steps on rank 0's test batch; median over repetitions of the worst bucket) and training
+    continues, 60 steps at a time, until it is <= `calm`; the calmest point seen is kept if none qualifies.  Returns the spread."""
     from heltondetection_amd import synthetic as syn
     from heltondetection_amd.detectors import build_detector
     from heltondetection_amd.train import Trainer
@@ -189,20 +219,36 @@ def _pretrain(tmp_path, steps: int = 300):
     torch.backends.cudnn.benchmark = False
     model = build_detector(dict(type="YOLOv5", variant="s", num_classes=8, img_size=128)).to(dev)
     model = model.to(memory_format=torch.channels_last).train()
-    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=steps + 10, warmup_steps=10, device=dev, use_graph=False)
+    tr = Trainer(model, lr=1e-3, amp_dtype=torch.bfloat16, total_steps=steps + 60 * rounds + 100, warmup_steps=10, device=dev,
+                 use_graph=False)
     g = syn.make_generator(77)
     pool = []
     for _ in range(4):
         img = syn.make_images(4, 128, g).to(dev).contiguous(memory_format=torch.channels_last)
         gtb, gtc, mv = syn.make_targets(4, 128, g, "coco", 8, 8)
         pool.append((img, gtb.to(dev), gtc.to(dev), mv.to(dev)))
-    for i in range(steps):
-        loss, _ = tr.step(*pool[i % 4])
-    assert bool(torch.isfinite(loss))
-    torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(str(tmp_path), "pretrained.pt"))
+    gt = syn.make_generator(200)   # rank 0's batch of the compared step (_worker_overlap)
+    img = syn.make_images(4, 128, gt).to(dev).contiguous(memory_format=torch.channels_last)
+    gtb, gtc, mv = syn.make_targets(4, 128, gt, "coco", 8, 8)
+    probe = (img, gtb.to(dev), gtc.to(dev), mv.to(dev))
+    done, best, history = 0, None, []
+    for r in range(rounds):
+        for i in range(steps if r == 0 else 60):
+            loss, _ = tr.step(*pool[(done + i) % 4])
+        done += steps if r == 0 else 60
+        assert bool(torch.isfinite(loss))
+        spread = _step_spread(tr, probe)
+        history.append(round(spread, 3))
+        if best is None or spread < best[0]:
+            best = (spread, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        if spread <= calm:
+            break
+    print("pre-train: eager step spread (median worst-bucket rel-L2 at lr = 0) per round:", history)
+    torch.save(best[1], os.path.join(str(tmp_path), "pretrained.pt"))
     del tr, model
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    return best[0]
 
 
 @pytest.mark.timeout(900)
@@ -210,7 +256,7 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     """VERDICT r02 #2a: the overlapped (graph_sync = False) multi-rank branch executes with a collective, under bf16
     autocast + bf16 weight shadows + HdAdamW, with lr > 0 for exactly one graph-replayed optimizer step."""
     world = 2
-    _pretrain(tmp_path)
+    spread = _pretrain(tmp_path)
     for use_graph in (True, False):
         mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
     g0, g1 = torch.load(tmp_path / "og0.pt"), torch.load(tmp_path / "og1.pt")
@@ -256,7 +302,7 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
         rel = float((a.double() - b.double()).norm() / b.double().norm())
         cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
         worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
-    print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst)   # shown with pytest -s / on failure
+    print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst, "eager step spread at this point:", round(spread, 3))
     ok = all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst)
     if not ok:   # which tensors, and by what factor: norm ratio graph / eager per parameter gradient (both runs, rank 0)
         ratios = []
