@@ -1320,6 +1320,11 @@ inline WgradPlan wgrad_plan(int64_t R, int Cin, int Cout) {
 
 }  // namespace
 
+// pointwise_longk.hip: long reductions on few rows (Cin = 512 / 1024, the 20x20 / 40x40 levels)
+int hd_pointwise_longk_supported(int64_t R, int Cin, int Cout);
+hd_status hd_pointwise_longk(const void* x, int64_t ldx, const void* w, int64_t R, int Cin, int Cout, void* y, int64_t ldy,
+                             float* stats, hipStream_t s);
+
 extern "C" int hd_pointwise_conv_supported(int64_t R, int Cin, int Cout) {
   return R >= 1 && R <= 0x7fffffff && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0 && Cin <= 8192 &&
          Cout <= 1024;  // <= 8 column tiles: the persistent grid (a multiple of 8) keeps one column tile per workgroup
@@ -1341,6 +1346,8 @@ extern "C" hd_status hd_pointwise_conv(const void* x, int64_t x_row_stride, cons
   if (Cin == 64 && try_stream<64>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
   if (Cin == 128 && try_stream<128>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
   if (Cin == 256 && try_stream<256>(x, x_row_stride, w, y, y_row_stride, M, Cout, stats, s, &st)) return st;
+  if (hd_pointwise_longk_supported(R, Cin, Cout))
+    return hd_pointwise_longk(x, x_row_stride, w, R, Cin, Cout, y, y_row_stride, stats, s);
   if (Cin % 64 == 0) return launch_bk<64>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
   return launch_bk<32>(x, x_row_stride, w, y, y_row_stride, (int)R, Cout, Cin, stats, s);
 }
@@ -1514,7 +1521,9 @@ extern "C" hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, c
 }
 
 extern "C" int hd_pointwise_conv_resident(int64_t R, int Cin, int Cout) {
-  // 1 when hd_pointwise_conv takes the streaming form (weights resident in LDS), the one worth preferring to the library
+  // 1 when hd_pointwise_conv takes a form with the weights resident in LDS (the streaming kernel, or pointwise_longk.hip for
+  // Cin = 512 / 1024 on few rows), the ones worth preferring to the library
+  if (hd_pointwise_longk_supported(R, Cin, Cout) && hd_pointwise_conv_supported(R, Cin, Cout)) return 1;
   if (!(Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256) || !hd_pointwise_conv_supported(R, Cin, Cout)) return 0;
   const int max_bn = Cin <= 128 ? 128 : 64;
   const int bn = (Cout % 128 == 0 && max_bn >= 128) ? 128 : (Cout % 64 == 0 ? 64 : 32);

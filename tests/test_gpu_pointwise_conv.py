@@ -19,12 +19,15 @@ def _ref(x, w):
 
 
 # (B, Cin, H, W, Cout): every streaming-form tile shape (K 32/64/128/256 x column tiles 32/64/128), the K-loop form
-# (K 512, 96, 1024), ragged row counts (not a multiple of 32 / 64 / 128) and a single-row input
+# (K 96, 768), the long-reduction form of csrc/pointwise_longk.hip (K 512 with 128- and 64-wide column tiles, K 1024; three
+# column tiles; more row blocks than workgroups), ragged row counts (not a multiple of 32 / 64 / 128) and a single-row input
 SHAPES = [(2, 32, 20, 20, 32), (2, 64, 24, 20, 64), (1, 64, 17, 13, 128), (2, 128, 9, 11, 128), (1, 128, 16, 16, 64),
           (2, 256, 10, 10, 256), (1, 256, 7, 9, 128), (1, 256, 5, 5, 32), (2, 64, 16, 16, 256), (1, 32, 33, 7, 96),
           (2, 512, 10, 10, 512), (1, 1024, 6, 6, 512), (1, 96, 7, 7, 160), (1, 64, 1, 1, 64), (16, 64, 80, 80, 64),
           # more than 8 column tiles per launch (ResNet50's 256 -> 1024; 12 and 20 tiles: not powers of two)
-          (2, 256, 13, 13, 1024), (1, 256, 9, 9, 768), (1, 64, 31, 9, 640), (4, 256, 52, 52, 1024)]
+          (2, 256, 13, 13, 1024), (1, 256, 9, 9, 768), (1, 64, 31, 9, 640), (4, 256, 52, 52, 1024),
+          (16, 512, 20, 20, 256), (16, 512, 20, 20, 512), (4, 512, 23, 17, 384), (16, 1024, 20, 20, 512), (16, 512, 40, 40, 256),
+          (3, 1024, 11, 9, 192), (1, 512, 1, 1, 128), (20, 512, 40, 40, 128), (1, 768, 9, 7, 128)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -63,6 +66,32 @@ def test_pointwise_conv_reads_and_writes_channel_slices():
     ref = _ref(x, w)
     assert torch.allclose(out.float(), ref, rtol=2.0 ** -7, atol=1e-3)
     assert bool((buf[:, :32] == 7.0).all()) and bool((buf[:, 128:] == 7.0).all())  # neighbours untouched
+
+
+def test_long_reduction_form_reads_and_writes_channel_slices():
+    """As above for csrc/pointwise_longk.hip: a 512-channel slice of a 768-channel concatenation in, a slice of a wider buffer
+    out, 2 x 13 x 11 = 286 rows (three row blocks, the last ragged), statistics of the written tensor."""
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 13, 11
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn((B, 768, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 128:640]
+    w = (torch.randn((256, 512, 1, 1), generator=g) * 512 ** -0.5).to(dev).to(torch.bfloat16)
+    assert _lib.load().hd_pointwise_conv_resident(B * H * W, 512, 256) == 1
+    buf = torch.full((B, 384, H, W), 7.0, dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    out = buf[:, 64:320]
+    rep = _lib.load().hd_bn_act_replicas()
+    stats = torch.zeros(rep * 2 * 256, dtype=torch.float32, device=dev)
+    ops.pointwise_conv_rows(x, w.view(256, 512), stats, out)
+    ref = _ref(x, w)
+    tol = 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max()
+    assert bool(((out.float() - ref).abs() <= tol * 1.01).all())
+    assert bool((buf[:, :64] == 7.0).all()) and bool((buf[:, 320:] == 7.0).all())  # neighbours untouched
+    yf = out.double()
+    got = stats.view(rep, 2, 256).double().sum(0)
+    assert torch.allclose(got[0], yf.sum((0, 2, 3)), rtol=0, atol=2e-6 * float(yf.abs().sum((0, 2, 3)).max()))
+    assert torch.allclose(got[1], (yf * yf).sum((0, 2, 3)), rtol=2e-6, atol=0)
 
 
 def test_pointwise_conv_rejects_what_it_cannot_take():
@@ -159,9 +188,10 @@ def test_pointwise_dgrad_from_the_forward_weight(shape):
     assert torch.equal(ops.pointwise_dgrad_rows(dy, w), ops.pointwise_conv_rows(dy, w.t().contiguous()))
 
 
-def test_long_reduction_layer_uses_library_forward_and_our_backward():
-    """Cin = 512 > 256: forward through MIOpen (+ the separate statistics kernel), weight gradient through
-    hd_pointwise_wgrad; results must match the all-library path."""
+def test_long_reduction_layer_runs_on_our_forward_and_backward():
+    """Cin = 512 > 256: forward through hd_pointwise_conv's long-reduction form (csrc/pointwise_longk.hip, statistics in its
+    epilogue; the library + a separate statistics launch until round 5), weight gradient through hd_pointwise_wgrad; results
+    must match the all-library path."""
     from heltondetection_amd import layers, ops
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
@@ -175,14 +205,16 @@ def test_long_reduction_layer_uses_library_forward_and_our_backward():
             m.zero_grad(set_to_none=True)
             ops.bn_arena_reset(dev)
             x = x0.clone().requires_grad_(True)
-            ops.enable_timing("pointwise_wgrad")
+            ops.enable_timing("pointwise_wgrad", "pointwise_conv", "bn_stats_kernel")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = m(x)
             (y.float() * gy).sum().backward()
             torch.cuda.synchronize()
-            ran = len(ops.collect_timing()["pointwise_wgrad"])
+            timed = ops.collect_timing()
             ops.disable_timing()
-            assert ran == (1 if on else 0)
+            assert len(timed["pointwise_wgrad"]) == (1 if on else 0)
+            assert len(timed["pointwise_conv"]) == (1 if on else 0)
+            assert len(timed["bn_stats_kernel"]) == (0 if on else 1)   # the statistics come from the convolution's epilogue
             res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
         finally:
             layers.ConvBNAct.pointwise = True
