@@ -199,10 +199,12 @@ hd_status launch_longk(const void* x, int64_t ldx, const void* w, void* y, int64
 
 }  // namespace
 
-// Shapes this kernel is preferred on (measured against the library on the YOLOv5s / l pyramids at 640^2 - 832^2 only): the
-// reduction 512 long, at most 32 768 rows, the output a multiple of 128 columns and at most 32 column tiles.
+// Shapes this kernel is preferred on, measured against the library's convolution + the separate statistics launch in replayed
+// graphs (tools/pw_long_k_probe.py, profiles/r05_pw_long_k.md): the reduction 512 long and at most 16 384 rows — 6 400 rows:
+// 9.2 against 12.2 us (-> 256 channels) and 12.6 against 16.8 us (-> 512); 10 816 rows: 20.4 against 20.3; from 25 600 rows on
+// (two row blocks per workgroup) it ties or loses (21.5 against 21.6 us) and the library keeps those.
 int hd_pointwise_longk_supported(int64_t R, int Cin, int Cout) {
-  if (R < 1 || R > 32768) return 0;
+  if (R < 1 || R > 16384) return 0;
   if (Cin == 512) return Cout % 128 == 0 && Cout / 128 <= 32;
   return 0;  // Cin = 1024 (SPPF cv2) measured slower than the library with its separate statistics launch (25.4 against 21.8 us)
 }

@@ -27,7 +27,8 @@ SHAPES = [(2, 32, 20, 20, 32), (2, 64, 24, 20, 64), (1, 64, 17, 13, 128), (2, 12
           # more than 8 column tiles per launch (ResNet50's 256 -> 1024; 12 and 20 tiles: not powers of two)
           (2, 256, 13, 13, 1024), (1, 256, 9, 9, 768), (1, 64, 31, 9, 640), (4, 256, 52, 52, 1024),
           (16, 512, 20, 20, 256), (16, 512, 20, 20, 512), (4, 512, 23, 17, 384), (16, 1024, 20, 20, 512), (16, 512, 40, 40, 256),
-          (3, 1024, 11, 9, 192), (1, 512, 1, 1, 128), (20, 512, 40, 40, 128), (1, 768, 9, 7, 128)]
+          (3, 1024, 11, 9, 192), (1, 512, 1, 1, 128), (20, 512, 40, 40, 128), (1, 768, 9, 7, 128),
+          (16, 512, 32, 32, 1024), (9, 512, 37, 41, 640)]   # 16 384 / 13 653 rows x 8 / 5 column tiles: four row blocks per workgroup
 
 
 @pytest.mark.parametrize("shape", SHAPES)
