@@ -271,6 +271,13 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
             return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
         return FusedBNAct.apply(bn, ops.conv3x3(x, w, conv.stride[0], None, ConvBNAct.conv3x3_forward), act, residual,
                                 residual_after_act, out)
+    if _conv3x3_s2_first(conv, bn, x):
+        from . import ops
+        w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
+        w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        w = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        # forward and weight gradient with the library; the data gradient (76 us + a 25 us zero-fill there) on hd_conv3x3s2_dgrad
+        return FusedBNAct.apply(bn, ops.conv3x3(x, w, 2, None, False), act, residual, residual_after_act, out)
     if _stem_ours(conv, bn, x):
         from . import ops
         w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
@@ -316,6 +323,20 @@ def _conv3x3_ours(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
         return False
     from . import ops
     return ops.conv3x3_wgrad_supported(x, conv.out_channels, conv.stride[0])
+
+
+def _conv3x3_s2_first(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
+    """The first stride-2 3x3 layer of the YOLOv5 backbone at 640^2 (32 -> 64 channels, 320^2 -> 160^2), whose weight gradient
+    hd_conv3x3_wgrad does not take: its data gradient runs on hd_conv3x3s2_dgrad (ops._Conv3x3Fn.backward)."""
+    if not (ConvBNAct.pointwise and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.is_cuda and bn.training
+            and x.dtype == torch.bfloat16 and x.dim() == 4 and x.requires_grad and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and conv.weight.requires_grad
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+        return False
+    from . import _lib
+    return bool(_lib.load().hd_conv3x3s2_dgrad_supported(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, conv.in_channels,
+                                                         conv.out_channels))
 
 
 class Bottleneck(nn.Module):

@@ -760,6 +760,35 @@ def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Ten
     return y
 
 
+def conv3x3s2_dgrad_supported(dy: torch.Tensor, x_shape, weight: torch.Tensor) -> bool:
+    """hd_conv3x3s2_dgrad (csrc/conv3x3s2_dgrad.hip): the first stride-2 layer of the YOLOv5 backbone (32 <- 64 channels, dy 160
+    pixels wide, the input exactly twice the output)."""
+    if not (dy.is_cuda and dy.dim() == 4 and dy.dtype == torch.bfloat16 and _cl_row_stride(dy, 8) is not None
+            and weight.dtype == torch.bfloat16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and weight.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    B, N, Ho, Wo = dy.shape
+    if tuple(x_shape) != (B, weight.shape[1], 2 * Ho, 2 * Wo) or weight.shape[0] != N:
+        return False
+    return bool(_lib.load().hd_conv3x3s2_dgrad_supported(B, Ho, Wo, int(weight.shape[1]), N))
+
+
+def conv3x3s2_dgrad_rows(dy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """dx [B, Cin, 2 Ho, 2 Wo] (bf16 channels-last) of a 3x3 / stride 2 / pad 1 convolution from dy [B, Cout, Ho, Wo] and the layer's
+    own weight [Cout, Cin, 3, 3] (channels-last memory); every element written once, no autograd."""
+    lib = _lib.load()
+    B, N, Ho, Wo = dy.shape
+    K = weight.shape[1]
+    if not conv3x3s2_dgrad_supported(dy, (B, K, 2 * Ho, 2 * Wo), weight):
+        raise _lib.HdError("conv3x3s2_dgrad: needs bf16 channels-last rows [B, 64, H, 160] and a channels-last bf16 [64, 32, 3, 3] weight")
+    dx = torch.empty((B, K, 2 * Ho, 2 * Wo), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    _note_bytes("conv3x3s2_dgrad", 2 * (B * Ho * Wo * (N + 4 * K) + 9 * N * K), {"flops": 18 * B * Ho * Wo * K * N, "shape": (B, Ho, Wo, K, N, 2)})
+    with _ktimed("conv3x3s2_dgrad"):
+        check(lib.hd_conv3x3s2_dgrad(_ptr(dy), int(_cl_row_stride(dy, 8)), _ptr(weight), B, Ho, Wo, K, N, _ptr(dx), K, _stream(dy)),
+              "hd_conv3x3s2_dgrad")
+    return dx
+
+
 class FlippedWeights:
     """The flipped, transposed copies hd_conv3x3_fwd needs as a data gradient (wt[c][ky][kx][n] = w[n][2-ky][2-kx][c]), rebuilt
     for every registered weight by ONE launch at the head of a training step (hd_conv3x3_flip_weights) instead of a flip + a
@@ -817,7 +846,8 @@ class FlippedWeights:
 class _Conv3x3Fn(torch.autograd.Function):
     """3x3 / pad 1 convolution of stride 1 or 2.  Stride 1 with a supported shape: forward on hd_conv3x3_fwd (BatchNorm
     statistics into `slot` from its epilogue) and the data gradient on the same kernel with the flipped, transposed weights;
-    otherwise those two stay with MIOpen.  The weight gradient always runs on hd_conv3x3_wgrad."""
+    stride 2 on the first backbone layer's shape: the data gradient on hd_conv3x3s2_dgrad; otherwise those stay with MIOpen.
+    The weight gradient runs on hd_conv3x3_wgrad wherever that takes the shape."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, slot, ours_fwd):
@@ -846,11 +876,17 @@ class _Conv3x3Fn(torch.autograd.Function):
                 if wt is None:
                     wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
                 dx = conv3x3_fwd_rows(g, wt, None, name="conv3x3_dgrad")
+            elif st == 2 and conv3x3s2_dgrad_supported(g, x.shape, weight):
+                dx = conv3x3s2_dgrad_rows(g, weight)   # the first stride-2 layer: every dx element written once, no zero-fill
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_wgrad_rows(g, x, st, leaf=weight)
+            if conv3x3_wgrad_supported(x, weight.shape[0], st):
+                dw = conv3x3_wgrad_rows(g, x, st, leaf=weight)
+            else:   # the first stride-2 layer (32 -> 64 channels at 320^2): only its data gradient is ours
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
         return dx, dw, None, None, None
 
 

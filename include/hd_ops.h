@@ -568,6 +568,15 @@ int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);
 hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout, void* y,
                          int64_t y_row_stride, float* stats, hd_stream stream);
 
+/* Data gradient of the first stride-2 3x3 convolution of the YOLOv5 backbone (csrc/conv3x3s2_dgrad.hip): 3x3 / stride 2 / pad 1,
+ * Cin = 32 (channels of dx), Cout = 64 (channels of dy), Wout = 160, the input exactly twice the output (2 Hout x 2 Wout):
+ *     dx[b, p, q, c] (bfloat16) = sum over (ky, kx, n) with p = 2 i - 1 + ky, q = 2 j - 1 + kx of dy[b, i, j, n] * w[n][ky][kx][c]
+ * w: the layer's own channels-last [Cout, Cin, 3, 3] bfloat16 weight (memory [Cout][3][3][Cin]; no flipped copy).  Every element
+ * of dx is written exactly once (no zero-fill by the caller).  Row strides in elements (0 = dense, multiples of 8). */
+int hd_conv3x3s2_dgrad_supported(int B, int Hout, int Wout, int Cin, int Cout);
+hd_status hd_conv3x3s2_dgrad(const void* dy, int64_t dy_row_stride, const void* w, int B, int Hout, int Wout, int Cin, int Cout,
+                             void* dx, int64_t dx_row_stride, hd_stream stream);
+
 /* Weight gradient of a 3x3 / pad 1 convolution of stride 1 or 2 on channels-last rows (the bottleneck and the downsampling
  * 3x3 convolutions of the YOLOv5 backbone / neck):
  *     dw[n][ky][kx][k] (bfloat16, i.e. a channels-last [Cout, Cin, 3, 3] weight) = sum over (b, h, w) of

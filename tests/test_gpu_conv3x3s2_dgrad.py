@@ -1,0 +1,92 @@
+"""hd_conv3x3s2_dgrad (csrc/conv3x3s2_dgrad.hip): the data gradient of the first stride-2 3x3 layer of the YOLOv5 backbone.
+Compared with aten.convolution_backward of the same bf16-rounded operands in float32 (tolerance = one bf16 rounding of the result
+plus float32 summation-order noise), exactly on small-integer data, and through the autograd node the model uses."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(dy, x_shape, w):
+    x = torch.zeros(x_shape, dtype=torch.float32, device=dy.device)
+    return torch.ops.aten.convolution_backward(dy.float(), x, w.float(), None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
+                                               (True, False, False))[0]
+
+
+def _mk(B, H, seed, dev, ints=False):
+    g = torch.Generator().manual_seed(seed)
+    if ints:
+        dy = torch.randint(-3, 4, (B, 64, H, 160), generator=g).float()
+        w = torch.randint(-2, 3, (64, 32, 3, 3), generator=g).float()
+    else:
+        dy = torch.randn((B, 64, H, 160), generator=g)
+        w = torch.randn((64, 32, 3, 3), generator=g) * (9 * 64) ** -0.5
+    dy = dy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = w.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return dy, w
+
+
+# (B, Hout): one row per workgroup walk / several; more images than workgroup slots; the bench shape
+@pytest.mark.parametrize("B,H", [(1, 1), (1, 2), (2, 7), (3, 160), (16, 160), (300, 3)])
+def test_stride2_dgrad_matches_fp32_reference(B, H):
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    dy, w = _mk(B, H, 11 + B + H, dev)
+    assert ops.conv3x3s2_dgrad_supported(dy, (B, 32, 2 * H, 320), w)
+    dx = ops.conv3x3s2_dgrad_rows(dy, w)
+    ref = _ref(dy, (B, 32, 2 * H, 320), w)
+    assert dx.shape == ref.shape and dx.dtype == torch.bfloat16 and dx.is_contiguous(memory_format=torch.channels_last)
+    tol = 2.0 ** -8 * ref.abs() + 2e-5 * ref.abs().max()
+    assert bool(((dx.float() - ref).abs() <= tol * 1.01).all()), float((dx.float() - ref).abs().max())
+
+
+def test_stride2_dgrad_is_exact_on_integer_data_and_reads_channel_slices():
+    """Small integers: every product and sum is exact in float32 and the result (|.| <= 9 * 64 * 6) exact in bf16 only up to 256,
+    so the comparison is with the float32 reference ROUNDED to bf16.  dy is a channel slice of a wider tensor."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, H = 2, 9
+    dy, w = _mk(B, H, 5, dev, ints=True)
+    wide = torch.zeros((B, 160, H, 160), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    wide[:, 32:96] = dy
+    view = wide[:, 32:96]
+    dx = ops.conv3x3s2_dgrad_rows(view, w)
+    ref = _ref(dy, (B, 32, 2 * H, 320), w).to(torch.bfloat16)
+    assert torch.equal(dx, ref)
+
+
+def test_stride2_dgrad_rejects_other_shapes():
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    assert lib.hd_conv3x3s2_dgrad_supported(16, 160, 160, 32, 64) == 1
+    assert lib.hd_conv3x3s2_dgrad_supported(16, 208, 208, 32, 64) == 0      # 832^2: stays with the library
+    assert lib.hd_conv3x3s2_dgrad_supported(16, 160, 160, 64, 128) == 0
+    dy, w = _mk(1, 4, 0, dev)
+    assert not ops.conv3x3s2_dgrad_supported(dy, (1, 32, 7, 320), w)        # odd input height: 2 Hout - 1
+    assert not ops.conv3x3s2_dgrad_supported(dy.float(), (1, 32, 8, 320), w)
+    with pytest.raises(_lib.HdError):
+        ops.conv3x3s2_dgrad_rows(dy[:, :, :, :80], w)
+
+
+def test_first_stride2_layer_backward_runs_on_the_kernel_and_matches_the_library():
+    """ops.conv3x3 (the autograd node ConvBNAct uses) with stride 2 on the layer's shape: dx from hd_conv3x3s2_dgrad, equal to the
+    library's data gradient to bf16 rounding; the weight gradient is untouched by this path."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    x = torch.randn((2, 32, 48, 320), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn((64, 32, 3, 3), device=dev) * 0.06).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn((2, 64, 24, 160), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ops.enable_timing("conv3x3s2_dgrad")
+    y = ops.conv3x3(x, w, 2)
+    y.backward(gy)
+    ops.flush_wgrad()
+    torch.cuda.synchronize()
+    ran = len(ops.collect_timing()["conv3x3s2_dgrad"])
+    ops.disable_timing()
+    assert ran == 1
+    ref = _ref(gy, x.shape, w.detach())
+    tol = 2.0 ** -8 * ref.abs() + 2e-5 * ref.abs().max()
+    assert bool(((x.grad.float() - ref).abs() <= tol * 1.01).all())
+    assert w.grad is not None and bool(torch.isfinite(w.grad.float()).all())
