@@ -107,33 +107,53 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_dgrad_c32_kernel(const unsi
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    // The 4 + 9 fragments of k-step s + 1 are requested before the nine MFMAs of k-step s issue (left to the compiler: read, wait,
+    // multiply per fragment — an LDS round trip per MFMA, which was where the first version spent its time, not in memory).
+    struct Frags {
+      bf16x8 a00, a01, a10, a11, t[9];
+    };
+    Frags fr[2];
+    auto fetch = [&](const int s, Frags& f) {
+      f.a00 = *reinterpret_cast<const bf16x8*>(cur + s * 32);
+      f.a01 = *reinterpret_cast<const bf16x8*>(cur + PX + s * 32);
+      f.a10 = *reinterpret_cast<const bf16x8*>(nxt + s * 32);
+      f.a11 = *reinterpret_cast<const bf16x8*>(nxt + PX + s * 32);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) f.t[tap] = *reinterpret_cast<const bf16x8*>(wl + tap * (CI * W_ROW) + s * 32);
+    };
+    fetch(0, fr[0]);
 #pragma unroll
     for (int s = 0; s < CO / 16; ++s) {
-      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(cur + s * 32);
-      const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(cur + PX + s * 32);
-      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(nxt + s * 32);
-      const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(nxt + PX + s * 32);
-      auto tapm = [&](int ky, int kx) { return *reinterpret_cast<const bf16x8*>(wl + (ky * 3 + kx) * (CI * W_ROW) + s * 32); };
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, tapm(1, 1), acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, tapm(1, 2), acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, tapm(2, 1), acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, tapm(2, 2), acc[1][1], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, tapm(1, 0), acc[0][1], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, tapm(2, 0), acc[1][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, tapm(0, 1), acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, tapm(0, 2), acc[1][1], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, tapm(0, 0), acc[1][1], 0, 0, 0);
+      if (s + 1 < CO / 16) fetch(s + 1, fr[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests above the multiplies they are meant to overlap
+      const Frags& f = fr[s & 1];         // tap index = 3 ky + kx
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[4], f.a00, acc[0][0], 0, 0, 0);  // W11
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[5], f.a00, acc[0][1], 0, 0, 0);  // W12
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[7], f.a00, acc[1][0], 0, 0, 0);  // W21
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[8], f.a00, acc[1][1], 0, 0, 0);  // W22
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[3], f.a01, acc[0][1], 0, 0, 0);  // W10
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[6], f.a01, acc[1][1], 0, 0, 0);  // W20
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[1], f.a10, acc[1][0], 0, 0, 0);  // W01
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[2], f.a10, acc[1][1], 0, 0, 0);  // W02
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.t[0], f.a11, acc[1][1], 0, 0, 0);  // W00
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // C/D map: col = lane & 31 (ci), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (position)  ->  patch[position][c][ci]
+    // The products are formed TRANSPOSED (tap matrix as the A operand, dy pixels as B), so the C/D map reads: col = lane & 31 =
+    // position, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = ci — four consecutive ci per register quad, one 8-byte LDS write per
+    // quad into patch[position][c][ci] (as 2-byte writes from the untransposed map the patch cost more LDS time than the
+    // fragment reads: 64 ds_write_b16 per wave and dy row).
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pos = (r & 3) + 8 * (r >> 2) + 4 * fh;
-          *reinterpret_cast<unsigned short*>(patch + pos * PATCH_ROW + (c * CI + frow) * 2) =
-              __builtin_bit_cast(unsigned short, (__bf16)acc[a][c][r]);  // v_cvt_pk_bf16_f32, RNE
+        for (int g = 0; g < 4; ++g) {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 lo = {acc[a][c][4 * g], acc[a][c][4 * g + 1]}, hi = {acc[a][c][4 * g + 2], acc[a][c][4 * g + 3]};
+          const uint2 v = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),   // v_cvt_pk_bf16_f32, RNE
+                                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
+          *reinterpret_cast<uint2*>(patch + frow * PATCH_ROW + (c * CI + 8 * g + 4 * fh) * 2) = v;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own patch writes, before its lanes read each other's
       unsigned short* drow = dxb + ((long long)(2 * i + a) * (2 * WOUT) + 2 * j0) * ld_dx;

@@ -276,7 +276,11 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, act, x, residual=None, resi
         w = conv.lp_weight() if isinstance(conv, ShadowConv2d) else conv.weight
         w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
         w = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
-        # forward and weight gradient with the library; the data gradient (76 us + a 25 us zero-fill there) on hd_conv3x3s2_dgrad
+        # weight gradient with the library; forward (+ the BatchNorm statistics, a 12 us pass of their own after the library's
+        # 47 us) on hd_conv3x3s2_fwd, the data gradient (76 us + a 25 us zero-fill there) on hd_conv3x3s2_dgrad
+        if ConvBNAct.conv3x3_forward and FusedBNAct.enabled and bn.momentum is not None and ops.conv3x3_takes_stats(x, w, 2):
+            y = ops.conv3x3(x, w, 2, FusedBNAct.slot_of(bn, x.device))
+            return FusedBNAct.apply(bn, y, act, residual, residual_after_act, out, stats_done=True)
         return FusedBNAct.apply(bn, ops.conv3x3(x, w, 2, None, False), act, residual, residual_after_act, out)
     if _stem_ours(conv, bn, x):
         from . import ops

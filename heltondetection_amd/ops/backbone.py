@@ -760,6 +760,35 @@ def conv3x3_fwd_rows(x: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Ten
     return y
 
 
+def conv3x3s2_fwd_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """hd_conv3x3s2_fwd (csrc/conv3x3s2_fwd.hip): the first stride-2 layer of the YOLOv5 backbone (32 -> 64 channels, 320 pixels wide
+    in, even height)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and _cl_row_stride(x, 8) is not None
+            and weight.dtype == torch.bfloat16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and weight.shape[1] == x.shape[1] and weight.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    B, K, H, W = x.shape
+    if H % 2 or W % 2:
+        return False
+    return bool(_lib.load().hd_conv3x3s2_fwd_supported(B, H // 2, W // 2, K, int(weight.shape[0])))
+
+
+def conv3x3s2_fwd_rows(x: torch.Tensor, weight: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y [B, Cout, H / 2, W / 2] (bf16 channels-last) = 3x3 / stride 2 / pad 1 convolution of x with the channels-last weight
+    [Cout, Cin, 3, 3]; stats as for pointwise_conv_rows; no autograd."""
+    lib = _lib.load()
+    if not conv3x3s2_fwd_supported(x, weight):
+        raise _lib.HdError("conv3x3s2_fwd: needs bf16 channels-last rows [B, 32, 2 H, 320] and a channels-last bf16 [64, 32, 3, 3] weight")
+    B, K, H, W = x.shape
+    N, Ho, Wo = weight.shape[0], H // 2, W // 2
+    y = torch.empty((B, N, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _note_bytes("conv3x3s2_fwd", 2 * (B * Ho * Wo * (4 * K + N) + 9 * N * K), {"flops": 18 * B * Ho * Wo * K * N, "shape": (B, Ho, Wo, K, N, 2)})
+    with _ktimed("conv3x3s2_fwd"):
+        check(lib.hd_conv3x3s2_fwd(_ptr(x), int(_cl_row_stride(x, 8)), _ptr(weight), B, Ho, Wo, K, N, _ptr(y), N, _ptr(stats), _stream(x)),
+              "hd_conv3x3s2_fwd")
+    return y
+
+
 def conv3x3s2_dgrad_supported(dy: torch.Tensor, x_shape, weight: torch.Tensor) -> bool:
     """hd_conv3x3s2_dgrad (csrc/conv3x3s2_dgrad.hip): the first stride-2 layer of the YOLOv5 backbone (32 <- 64 channels, dy 160
     pixels wide, the input exactly twice the output)."""
@@ -858,8 +887,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             and weight.is_contiguous(memory_format=torch.channels_last)
         if ctx.ours:
             return conv3x3_fwd_rows(x, weight, _fwd_sums(slot, N) if slot is not None else None)
+        if ctx.stride == 2 and (bool(ours_fwd) or slot is not None) and conv3x3s2_fwd_supported(x, weight):
+            return conv3x3s2_fwd_rows(x, weight, _fwd_sums(slot, N) if slot is not None else None)   # the first stride-2 layer
         if slot is not None:
-            raise _lib.HdError("conv3x3: statistics in the epilogue need the hand-written forward (stride 1, supported shape)")
+            raise _lib.HdError("conv3x3: statistics in the epilogue need a hand-written forward (supported shape)")
         return torch.nn.functional.conv2d(x, weight, None, ctx.stride, 1)
 
     @staticmethod
@@ -899,6 +930,8 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, slot: Option
 
 def conv3x3_takes_stats(x: torch.Tensor, weight: torch.Tensor, stride: int) -> bool:
     """True when conv3x3(x, weight, stride, slot) runs the hand-written forward (and so can fill a BatchNorm slot)."""
+    if stride == 2:
+        return conv3x3s2_fwd_supported(x, weight)
     return (stride == 1 and weight.dtype == torch.bfloat16 and weight.is_contiguous(memory_format=torch.channels_last)
             and conv3x3_fwd_supported(x, weight.shape[0]))
 

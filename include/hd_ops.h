@@ -568,6 +568,14 @@ int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);
 hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout, void* y,
                          int64_t y_row_stride, float* stats, hd_stream stream);
 
+/* Forward of the first stride-2 3x3 convolution of the YOLOv5 backbone (csrc/conv3x3s2_fwd.hip): 3x3 / stride 2 / pad 1, Cin = 32,
+ * Cout = 64, Wout = 160, the input exactly 2 Hout x 2 Wout; BatchNorm statistics in the epilogue like hd_pointwise_conv:
+ *     y[b, i, j, n] (bfloat16) = sum over (ky, kx, c) of x[b, 2 i - 1 + ky, 2 j - 1 + kx, c] * w[n][ky][kx][c]
+ * w: channels-last [Cout, Cin, 3, 3] bfloat16 (memory [Cout][3][3][Cin]); stats: nullable, as for hd_pointwise_conv. */
+int hd_conv3x3s2_fwd_supported(int B, int Hout, int Wout, int Cin, int Cout);
+hd_status hd_conv3x3s2_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int Hout, int Wout, int Cin, int Cout,
+                           void* y, int64_t y_row_stride, float* stats, hd_stream stream);
+
 /* Data gradient of the first stride-2 3x3 convolution of the YOLOv5 backbone (csrc/conv3x3s2_dgrad.hip): 3x3 / stride 2 / pad 1,
  * Cin = 32 (channels of dx), Cout = 64 (channels of dy), Wout = 160, the input exactly twice the output (2 Hout x 2 Wout):
  *     dx[b, p, q, c] (bfloat16) = sum over (ky, kx, n) with p = 2 i - 1 + ky, q = 2 j - 1 + kx of dy[b, i, j, n] * w[n][ky][kx][c]

@@ -90,3 +90,85 @@ def test_first_stride2_layer_backward_runs_on_the_kernel_and_matches_the_library
     tol = 2.0 ** -8 * ref.abs() + 2e-5 * ref.abs().max()
     assert bool(((x.grad.float() - ref).abs() <= tol * 1.01).all())
     assert w.grad is not None and bool(torch.isfinite(w.grad.float()).all())
+
+
+# ---- the same layer's forward: hd_conv3x3s2_fwd (csrc/conv3x3s2_fwd.hip) ---------------------------------------------------------
+def _mkx(B, H, seed, dev, ints=False):
+    g = torch.Generator().manual_seed(seed)
+    if ints:
+        x = torch.randint(-3, 4, (B, 32, 2 * H, 320), generator=g).float()
+        w = torch.randint(-2, 3, (64, 32, 3, 3), generator=g).float()
+    else:
+        x = torch.randn((B, 32, 2 * H, 320), generator=g)
+        w = torch.randn((64, 32, 3, 3), generator=g) * (9 * 32) ** -0.5
+    x = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = w.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return x, w
+
+
+@pytest.mark.parametrize("B,H", [(1, 1), (1, 2), (2, 7), (3, 160), (16, 160), (300, 3)])
+def test_stride2_forward_matches_fp32_reference_and_statistics(B, H):
+    from heltondetection_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    x, w = _mkx(B, H, 23 + B + H, dev)
+    rep = _lib.load().hd_bn_act_replicas()
+    stats = torch.zeros(rep * 2 * 64, dtype=torch.float32, device=dev)
+    assert ops.conv3x3s2_fwd_supported(x, w)
+    y = ops.conv3x3s2_fwd_rows(x, w, stats)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 2, 1)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    tol = 2.0 ** -8 * ref.abs() + 2e-5 * ref.abs().max()
+    assert bool(((y.float() - ref).abs() <= tol * 1.01).all()), float((y.float() - ref).abs().max())
+    yf = y.double()   # the epilogue's statistics are those of the bf16 tensor it wrote
+    want = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))])
+    got = stats.view(rep, 2, 64).double().sum(0)
+    scale = torch.stack([yf.abs().sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]) + 1e-6
+    assert float(((got - want).abs() / scale).max()) < 2e-6
+
+
+def test_stride2_forward_is_exact_on_integer_data_and_reads_channel_slices():
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, H = 2, 9
+    x, w = _mkx(B, H, 6, dev, ints=True)
+    wide = torch.zeros((B, 96, 2 * H, 320), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    wide[:, 32:64] = x
+    y = ops.conv3x3s2_fwd_rows(wide[:, 32:64], w)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 2, 1).to(torch.bfloat16)
+    assert torch.equal(y, ref)
+
+
+def test_first_stride2_layer_module_forward_and_backward_match_the_library_path():
+    """ConvBNAct(32, 64, 3, 2) on the layer's shape under bf16 autocast: hd_conv3x3s2_fwd (+ statistics) and hd_conv3x3s2_dgrad
+    against the all-library path of the same module."""
+    from heltondetection_amd import layers, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = layers.ConvBNAct(32, 64, 3, 2).to(dev).to(memory_format=torch.channels_last).train()
+    x0 = torch.randn((2, 32, 48, 320), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((2, 64, 24, 160), device=dev).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        layers.ConvBNAct.pointwise = on
+        try:
+            m.zero_grad(set_to_none=True)
+            m.bn.running_mean.zero_(); m.bn.running_var.fill_(1.0)
+            ops.bn_arena_reset(dev)
+            x = x0.clone().requires_grad_(True)
+            ops.enable_timing("conv3x3s2_fwd", "conv3x3s2_dgrad", "bn_stats_kernel")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            (y.float() * gy).sum().backward()
+            ops.flush_wgrad()
+            torch.cuda.synchronize()
+            timed = ops.collect_timing()
+            ops.disable_timing()
+            assert len(timed["conv3x3s2_fwd"]) == len(timed["conv3x3s2_dgrad"]) == (1 if on else 0)
+            assert len(timed["bn_stats_kernel"]) == (0 if on else 1)
+            res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float(), m.bn.weight.grad.float(),
+                       m.bn.bias.grad.float(), m.bn.running_mean.clone(), m.bn.running_var.clone())
+        finally:
+            layers.ConvBNAct.pointwise = True
+    for name, a, b in zip(("y", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var"), res[True], res[False]):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
+        assert err < 3e-2, (name, err)   # two bf16 pipelines with different accumulation orders
