@@ -59,7 +59,7 @@ def test_conv3x3_layer_matches_library_path():
     res = {}
     for on in (True, False):
         layers.ConvBNAct.pointwise = on
-        layers.ConvBNAct.conv3x3_forward = on   # also the (off by default) hand-written forward / data gradient
+        layers.ConvBNAct.conv3x3_forward = on   # also the hand-written forward / data gradient
         try:
             m.zero_grad(set_to_none=True)
             ops.bn_arena_reset(dev)
@@ -75,7 +75,8 @@ def test_conv3x3_layer_matches_library_path():
             res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float())
         finally:
             layers.ConvBNAct.pointwise = True
-            layers.ConvBNAct.conv3x3_forward = False
+            layers.ConvBNAct.conv3x3_forward = True   # the default (restored as False until round 5: every later test of a suite
+                                                      # run then took the library's 3x3 forward; tests/conftest.py now guards this)
     for name, a, b in zip(("y", "dx", "dw"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)
