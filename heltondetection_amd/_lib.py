@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -153,6 +153,7 @@ SIGNATURES = {
     "hd_conv3x3_wgrad": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "hd_conv3x3_wgrad_partial": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _P, _P]),
     "hd_conv3x3_flip_weights": (_I, [_I, _P, _P, _P, _P, _P]),
+    "hd_conv_flip_weights": (_I, [_I, _P, _P, _P, _P, _P, _P]),
     "hd_adamw_multi": (_I, [_P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "hd_maxpool5_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_maxpool5_bwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),

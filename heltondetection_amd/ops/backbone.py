@@ -833,14 +833,21 @@ class FlippedWeights:
         self.items = []
         self.by_ptr = {}
         for w in weights:
-            if not (w.is_cuda and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.bfloat16
-                    and w.is_contiguous(memory_format=torch.channels_last)):
+            if not (w.is_cuda and w.dim() == 4 and w.dtype == torch.bfloat16):
+                continue
+            k = tuple(w.shape[2:])
+            if k == (3, 3) and w.is_contiguous(memory_format=torch.channels_last):
+                taps = 9
+            elif k == (1, 1) and w.is_contiguous():   # a 1x1 layer: the plain transpose [Cin][Cout] (see pointwise_dgrad_long)
+                taps = 1
+            else:
                 continue
             if len(self.items) >= 32:   # HD_MAX_FLIP
                 break
             N, K = w.shape[0], w.shape[1]
-            wt = torch.empty((K, N, 3, 3), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
-            self.items.append((w, wt))
+            wt = torch.empty((K, N) + k, dtype=torch.bfloat16, device=w.device,
+                             memory_format=torch.channels_last if taps == 9 else torch.contiguous_format)
+            self.items.append((w, wt, taps))
             self.by_ptr[w.data_ptr()] = wt
 
     def __len__(self):
@@ -850,13 +857,14 @@ class FlippedWeights:
         if not self.items:
             return
         n = len(self.items)
-        src = (C.c_void_p * n)(*[w.data_ptr() for w, _ in self.items])
-        dst = (C.c_void_p * n)(*[t.data_ptr() for _, t in self.items])
-        cout = (C.c_int * n)(*[int(w.shape[0]) for w, _ in self.items])
-        cin = (C.c_int * n)(*[int(w.shape[1]) for w, _ in self.items])
+        src = (C.c_void_p * n)(*[w.data_ptr() for w, _, _ in self.items])
+        dst = (C.c_void_p * n)(*[t.data_ptr() for _, t, _ in self.items])
+        cout = (C.c_int * n)(*[int(w.shape[0]) for w, _, _ in self.items])
+        cin = (C.c_int * n)(*[int(w.shape[1]) for w, _, _ in self.items])
+        taps = (C.c_int * n)(*[int(t) for _, _, t in self.items])
         dev = self.items[0][0].device
-        check(_lib.load().hd_conv3x3_flip_weights(n, src, dst, cout, cin, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-              "hd_conv3x3_flip_weights")
+        check(_lib.load().hd_conv_flip_weights(n, src, dst, cout, cin, taps, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+              "hd_conv_flip_weights")
 
     def __enter__(self):
         self._prev, FlippedWeights._current = FlippedWeights._current, self
@@ -1057,7 +1065,9 @@ class _PointwiseConvFn(torch.autograd.Function):
             dx = pointwise_dgrad_rows(dy, weight.view(N, K))
         if ours_w:
             dw = pointwise_wgrad_rows(dy, x, leaf=weight).view(N, K, 1, 1)
-        lib_w, lib_x = need_dw and not ours_w, need_dx and not ours
+        if need_dx and not ours:
+            dx = pointwise_dgrad_long(dy, weight)
+        lib_w, lib_x = need_dw and not ours_w, need_dx and dx is None
         if lib_w or lib_x:
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
             dyd = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
@@ -1068,6 +1078,21 @@ class _PointwiseConvFn(torch.autograd.Function):
             if lib_x:
                 dx = gi
         return dx, dw, None
+
+
+def pointwise_dgrad_long(dy: torch.Tensor, weight: torch.Tensor) -> Optional[torch.Tensor]:
+    """Data gradient of a 1x1 layer whose Cout is too long for hd_pointwise_conv_dgrad's transpose fragments (the five Cout = 512
+    layers of YOLOv5s): dx = hd_pointwise_conv(dy, w^T) on the long-reduction kernel (csrc/pointwise_longk.hip), with w^T the copy
+    the step's one flip launch rebuilt (FlippedWeights, taps = 1).  None when no such copy is registered or the shape is not
+    taken — the caller then asks the library (which also needs a zero-fill of dx)."""
+    wt = FlippedWeights.get(weight)
+    if wt is None or dy.dtype != torch.bfloat16 or _cl_row_stride(dy, 8) is None:
+        return None
+    N, K = weight.shape[0], weight.shape[1]
+    R = dy.shape[0] * dy.shape[2] * dy.shape[3]
+    if not _lib.load().hd_pointwise_conv_resident(R, N, K):
+        return None
+    return pointwise_conv_rows(dy, wt.view(K, N), None, name="pointwise_dgrad")
 
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatSlot"] = None) -> torch.Tensor:
@@ -1314,6 +1339,8 @@ class _PwConvBNActFn(torch.autograd.Function):
         if need_dx and ours_dx and dx is None:
             dx = pointwise_dgrad_rows(dy, weight.view(N, K), add=d_skip)   # the shortcut's gradient rides in the epilogue
             d_skip = None
+        if need_dx and dx is None:
+            dx = pointwise_dgrad_long(dy, weight)
         lib_w, lib_x = need_dw and dw is None, need_dx and dx is None
         if lib_w or lib_x:
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)

@@ -150,6 +150,10 @@ class Trainer:
             ws = [m.weight_lp for m in model.modules() if isinstance(m, ShadowConv2d) and m.weight_lp is not None
                   and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
                   and m.in_channels % 64 == 0 and m.out_channels % 64 == 0]
+            # ... and the 1x1 layers whose data gradient is a long reduction (Cout = 512): their plain transposes, same launch
+            ws += [m.weight_lp for m in model.modules() if isinstance(m, ShadowConv2d) and m.weight_lp is not None
+                   and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.groups == 1 and m.bias is None
+                   and m.out_channels == 512 and m.in_channels % 128 == 0 and m.in_channels <= 4096]
             fl = ops.FlippedWeights(ws)
             self._flipped = fl if len(fl) else None
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: warmup_cosine(s, total_steps, warmup_steps))

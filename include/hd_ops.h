@@ -602,6 +602,11 @@ hd_status hd_conv3x3s2_dgrad(const void* dy, int64_t dy_row_stride, const void* 
 #define HD_MAX_FLIP 32
 hd_status hd_conv3x3_flip_weights(int n_layers, const void* const* w, void* const* wt, const int* cout, const int* cin,
                                   hd_stream stream);
+/* The same launch for a mix of 3x3 and 1x1 layers: taps[l] = 9 (as above) or 1 (w[l]: [Cout][Cin] -> wt[l]: [Cin][Cout], a plain
+ * transpose — the operand with which hd_pointwise_conv computes the DATA gradient of a 1x1 layer whose Cout is too long for the
+ * transpose-fragment form of hd_pointwise_conv_dgrad: dx = hd_pointwise_conv(dy, wt, Cin = Cout, Cout = Cin)).  taps: nullable = all 9. */
+hd_status hd_conv_flip_weights(int n_layers, const void* const* w, void* const* wt, const int* cout, const int* cin,
+                               const int* taps, hd_stream stream);
 int hd_conv3x3_wgrad_supported(int B, int H, int W, int Cin, int Cout, int stride);
 void hd_conv3x3_wgrad_select(int mode);
 size_t hd_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);

@@ -500,3 +500,46 @@ def test_deep_streaming_form_is_exact_on_integer_data_forward_gradient_and_fused
         dxa = ops.pointwise_dgrad_rows(dy, w, add=r)
         want_a = (dref + r.permute(0, 2, 3, 1).reshape(R, K).float()).to(torch.bfloat16).float()
         assert torch.equal(dxa.permute(0, 2, 3, 1).reshape(R, K).float(), want_a)
+
+
+# ---- data gradients of the Cout = 512 layers: hd_pointwise_conv on the transposed weight (round 5) -----------------------------------
+@pytest.mark.parametrize("cin,cout,hw", [(512, 512, 20), (256, 512, 13), (1024, 512, 20)])
+def test_long_output_layer_data_gradient_runs_on_the_transposed_weight(cin, cout, hw):
+    """Cout = 512 is too long for hd_pointwise_conv_dgrad's transpose fragments: with the layer's weight registered in
+    ops.FlippedWeights (taps = 1: one transposing launch per step for all such layers) the data gradient is hd_pointwise_conv(dy, w^T)
+    on the long-reduction kernel; without the registration the library computes it.  Both must agree with the float32 reference."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B = 16 if hw == 20 else 3
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    x = torch.randn((B, cin, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 1, 1), generator=g) * cin ** -0.5).to(dev).to(torch.bfloat16)
+    gy = torch.randn((B, cout, hw, hw), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.conv2d(gy.float(), w.float().permute(1, 0, 2, 3))   # dx = dy . w over Cout
+    fl = ops.FlippedWeights([w])
+    assert len(fl) == 1
+    fl.refresh()
+    assert torch.equal(fl.by_ptr[w.data_ptr()].view(cin, cout), w.view(cout, cin).t())   # the flip launch with taps = 1: a transpose
+    got = {}
+    for registered in (True, False):
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ops.enable_timing("pointwise_dgrad")
+        if registered:
+            fl2 = ops.FlippedWeights([wr.detach()])   # the registration is by storage: the trainer registers its bf16 shadows
+            fl2.by_ptr[wr.data_ptr()] = fl2.by_ptr.pop(wr.detach().data_ptr()) if wr.detach().data_ptr() != wr.data_ptr() else fl2.by_ptr[wr.data_ptr()]
+            fl2.refresh()
+            with fl2:
+                y = ops.pointwise_conv(xr, wr, None)
+                y.backward(gy)
+        else:
+            y = ops.pointwise_conv(xr, wr, None)
+            y.backward(gy)
+        ops.flush_wgrad()
+        torch.cuda.synchronize()
+        ran = len(ops.collect_timing()["pointwise_dgrad"])
+        ops.disable_timing()
+        assert ran == (1 if registered else 0)
+        got[registered] = xr.grad.float()
+    tol = 2.0 ** -8 * ref.abs() + 2e-5 * ref.abs().max()
+    assert bool(((got[True] - ref).abs() <= tol * 1.01).all()), float((got[True] - ref).abs().max())
+    assert float((got[False] - ref).abs().max() / ref.abs().max()) < 2e-2   # the library's path (bf16 output, its own order)
