@@ -488,7 +488,7 @@ def bn_family_roofline(model, batch, args, device, trainer=None):
     from heltondetection_amd import ops
     names = ("bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_dx_kernel")
     pw_names = ("pointwise_conv", "pointwise_dgrad", "pointwise_wgrad", "pointwise_bwd", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad",
-                "conv3x3s2_fwd", "conv3x3s2_dgrad", "stem_conv_fwd", "stem_conv_wgrad", "head_conv", "head_conv_bwd", "wgrad_reduce")
+                "conv3x3s2_fwd", "conv3x3s2_dgrad", "conv3x3s2_wgrad", "stem_conv_fwd", "stem_conv_wgrad", "head_conv", "head_conv_bwd", "wgrad_reduce")
     passes, per_pass, notes, tags = 3, [], None, None
     try:
         for it in range(passes + 1):  # the first pass warms up
@@ -560,7 +560,7 @@ def bn_family_roofline(model, batch, args, device, trainer=None):
         pby = {k: sum(notes[k]) for k in pw_names}
         pn = {k: len(per_pass[0][k]) for k in pw_names}
         pw = _hbm_entry("hand-written convolution family (1x1: pointwise_conv fwd + BN statistics / pointwise_bwd = data gradient + "
-                        "weight-gradient partials in one launch / pointwise_dgrad / pointwise_wgrad where that does not apply; 3x3: conv3x3_fwd + BN statistics / conv3x3_dgrad / conv3x3_wgrad + slice sum; first stride-2 3x3: conv3x3s2_fwd + BN statistics / conv3x3s2_dgrad; 6x6 stem: "
+                        "weight-gradient partials in one launch / pointwise_dgrad / pointwise_wgrad where that does not apply; 3x3: conv3x3_fwd + BN statistics / conv3x3_dgrad / conv3x3_wgrad + slice sum; first stride-2 3x3: conv3x3s2_fwd + BN statistics / conv3x3s2_dgrad / conv3x3s2_wgrad + slab sum; 6x6 stem: "
                         "stem_conv_fwd + BN statistics / stem_conv_wgrad; Detect: head_conv (float32 padded rows) / head_conv_bwd), step-weighted over the model's layers that take them",
                         sum(pms.values()), sum(pby.values()),
                         sum(pn.values()),

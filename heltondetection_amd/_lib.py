@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "csrc", "libhd_ops.so")
-ABI_VERSION = 33
+ABI_VERSION = 34
 MAX_LEVELS = 8
 MAX_ANCHORS = 16
 
@@ -145,6 +145,9 @@ SIGNATURES = {
     "hd_conv3x3_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "hd_conv3x3s2_fwd_supported": (_I, [_I, _I, _I, _I, _I]),
     "hd_conv3x3s2_fwd": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
+    "hd_conv3x3s2_wgrad_c32_supported": (_I, [_I, _I, _I, _I, _I]),
+    "hd_conv3x3s2_wgrad_c32_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "hd_conv3x3s2_wgrad_c32": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "hd_conv3x3s2_dgrad_supported": (_I, [_I, _I, _I, _I, _I]),
     "hd_conv3x3s2_dgrad": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "hd_conv3x3_wgrad_supported": (_I, [_I, _I, _I, _I, _I, _I]),

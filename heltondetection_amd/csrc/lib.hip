@@ -1,7 +1,7 @@
 // lib.hip — library-level entry points (version, status text, device probe).
 #include "hd_common.h"
 
-extern "C" int hd_abi_version(void) { return 33; }
+extern "C" int hd_abi_version(void) { return 34; }
 
 extern "C" const char* hd_status_str(hd_status s) {
   switch (s) {

@@ -789,6 +789,35 @@ def conv3x3s2_fwd_rows(x: torch.Tensor, weight: torch.Tensor, stats: Optional[to
     return y
 
 
+def conv3x3s2_wgrad_supported(dy: torch.Tensor, x: torch.Tensor) -> bool:
+    """hd_conv3x3s2_wgrad_c32 (csrc/conv3x3s2_wgrad.hip): the first stride-2 layer of the YOLOv5 backbone."""
+    if not (dy.is_cuda and dy.dim() == 4 and x.dim() == 4 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+            and _cl_row_stride(dy, 8) is not None and _cl_row_stride(x, 8) is not None):
+        return False
+    B, N, Ho, Wo = dy.shape
+    if tuple(x.shape[::3]) != (B, 2 * Wo) or x.shape[2] != 2 * Ho:
+        return False
+    return bool(_lib.load().hd_conv3x3s2_wgrad_c32_supported(B, Ho, Wo, int(x.shape[1]), N))
+
+
+def conv3x3s2_wgrad_rows(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dw [Cout, Cin, 3, 3] (bf16, channels-last memory [Cout][ky][kx][Cin]) of a 3x3 / stride 2 / pad 1 convolution from dy
+    [B, Cout, Ho, Wo] and x [B, Cin, 2 Ho, 2 Wo] (bf16 channels-last rows); no autograd."""
+    lib = _lib.load()
+    if not conv3x3s2_wgrad_supported(dy, x):
+        raise _lib.HdError("conv3x3s2_wgrad: needs bf16 channels-last rows dy [B, 64, H, 160] and x [B, 32, 2 H, 320]")
+    B, N, Ho, Wo = dy.shape
+    K = x.shape[1]
+    nbytes = lib.hd_conv3x3s2_wgrad_c32_workspace_bytes(B, Ho, Wo, K, N)
+    ws = torch.empty((nbytes // 4,), dtype=_F32, device=dy.device)
+    dw = torch.empty((N, K, 3, 3), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    _note_bytes("conv3x3s2_wgrad", 2 * (B * Ho * Wo * (4 * K + N) + 9 * N * K), {"flops": 18 * B * Ho * Wo * K * N, "shape": (B, Ho, Wo, K, N, 2)})
+    with _ktimed("conv3x3s2_wgrad"):
+        check(lib.hd_conv3x3s2_wgrad_c32(_ptr(dy), int(_cl_row_stride(dy, 8)), _ptr(x), int(_cl_row_stride(x, 8)), B, Ho, Wo, K, N,
+                                         _ptr(dw), _ptr(ws), nbytes, _stream(dy)), "hd_conv3x3s2_wgrad_c32")
+    return dw
+
+
 def conv3x3s2_dgrad_supported(dy: torch.Tensor, x_shape, weight: torch.Tensor) -> bool:
     """hd_conv3x3s2_dgrad (csrc/conv3x3s2_dgrad.hip): the first stride-2 layer of the YOLOv5 backbone (32 <- 64 channels, dy 160
     pixels wide, the input exactly twice the output)."""
@@ -923,7 +952,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if conv3x3_wgrad_supported(x, weight.shape[0], st):
                 dw = conv3x3_wgrad_rows(g, x, st, leaf=weight)
-            else:   # the first stride-2 layer (32 -> 64 channels at 320^2): only its data gradient is ours
+            elif st == 2 and conv3x3s2_wgrad_supported(g, x):
+                dw = conv3x3s2_wgrad_rows(g, x)   # the first stride-2 layer (32 -> 64 channels at 320^2)
+            else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (st, st), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (False, True, False))[1]
         return dx, dw, None, None, None

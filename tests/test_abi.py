@@ -29,7 +29,7 @@ def _header_abi_digest():
 # version -> digest of the header it was cut from.  A header edit without a new version (hd_abi_version in csrc/lib.hip,
 # ABI_VERSION in _lib.py, a line here) fails this test: a stale libhd_ops.so must fail with "rebuild", not AttributeError
 # (round 4 added 17 entry points at version 29).
-ABI_HEADER_DIGESTS = {30: "1f8ec122881dfc5b", 31: "7244275d8df1b40b", 32: "5edfa93a8d0aff03", 33: "f9939a4b68f2ccd1"}
+ABI_HEADER_DIGESTS = {30: "1f8ec122881dfc5b", 31: "7244275d8df1b40b", 32: "5edfa93a8d0aff03", 33: "f9939a4b68f2ccd1", 34: "f6ca61cea8bf4baf"}
 
 
 def test_abi_version_is_bumped_with_the_header():

@@ -71,7 +71,7 @@ def test_stride2_dgrad_rejects_other_shapes():
 
 def test_first_stride2_layer_backward_runs_on_the_kernel_and_matches_the_library():
     """ops.conv3x3 (the autograd node ConvBNAct uses) with stride 2 on the layer's shape: dx from hd_conv3x3s2_dgrad, equal to the
-    library's data gradient to bf16 rounding; the weight gradient is untouched by this path."""
+    library's data gradient to bf16 rounding."""
     from heltondetection_amd import ops
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
@@ -139,8 +139,8 @@ def test_stride2_forward_is_exact_on_integer_data_and_reads_channel_slices():
 
 
 def test_first_stride2_layer_module_forward_and_backward_match_the_library_path():
-    """ConvBNAct(32, 64, 3, 2) on the layer's shape under bf16 autocast: hd_conv3x3s2_fwd (+ statistics) and hd_conv3x3s2_dgrad
-    against the all-library path of the same module."""
+    """ConvBNAct(32, 64, 3, 2) on the layer's shape under bf16 autocast: hd_conv3x3s2_fwd (+ statistics), hd_conv3x3s2_dgrad and
+    hd_conv3x3s2_wgrad_c32 against the all-library path of the same module."""
     from heltondetection_amd import layers, ops
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -155,7 +155,7 @@ def test_first_stride2_layer_module_forward_and_backward_match_the_library_path(
             m.bn.running_mean.zero_(); m.bn.running_var.fill_(1.0)
             ops.bn_arena_reset(dev)
             x = x0.clone().requires_grad_(True)
-            ops.enable_timing("conv3x3s2_fwd", "conv3x3s2_dgrad", "bn_stats_kernel")
+            ops.enable_timing("conv3x3s2_fwd", "conv3x3s2_dgrad", "conv3x3s2_wgrad", "bn_stats_kernel")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = m(x)
             (y.float() * gy).sum().backward()
@@ -163,7 +163,7 @@ def test_first_stride2_layer_module_forward_and_backward_match_the_library_path(
             torch.cuda.synchronize()
             timed = ops.collect_timing()
             ops.disable_timing()
-            assert len(timed["conv3x3s2_fwd"]) == len(timed["conv3x3s2_dgrad"]) == (1 if on else 0)
+            assert len(timed["conv3x3s2_fwd"]) == len(timed["conv3x3s2_dgrad"]) == len(timed["conv3x3s2_wgrad"]) == (1 if on else 0)
             assert len(timed["bn_stats_kernel"]) == (0 if on else 1)
             res[on] = (y.float().detach(), x.grad.float(), m.conv.weight.grad.float(), m.bn.weight.grad.float(),
                        m.bn.bias.grad.float(), m.bn.running_mean.clone(), m.bn.running_var.clone())
@@ -172,3 +172,43 @@ def test_first_stride2_layer_module_forward_and_backward_match_the_library_path(
     for name, a, b in zip(("y", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var"), res[True], res[False]):
         err = float((a - b).abs().max() / (b.abs().max() + 1e-6))
         assert err < 3e-2, (name, err)   # two bf16 pipelines with different accumulation orders
+
+
+# ---- the same layer's weight gradient: hd_conv3x3s2_wgrad_c32 (csrc/conv3x3s2_wgrad.hip) -----------------------------------------------
+def _wref(dy, x, w_shape):
+    w = torch.zeros(w_shape, dtype=torch.float32, device=dy.device)
+    return torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
+                                               (False, True, False))[1]
+
+
+@pytest.mark.parametrize("B,H", [(1, 1), (1, 2), (2, 7), (3, 160), (16, 160), (300, 3)])
+def test_stride2_weight_gradient_matches_fp32_reference(B, H):
+    """Float32 partials per workgroup, summed in float32, one bf16 rounding at the end: within one bf16 rounding of the float32
+    reference plus the summation-order noise of a B x H x 160-term sum."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    x, _ = _mkx(B, H, 31 + B + H, dev)
+    dy, _ = _mk(B, H, 37 + B + H, dev)
+    assert ops.conv3x3s2_wgrad_supported(dy, x)
+    dw = ops.conv3x3s2_wgrad_rows(dy, x)
+    ref = _wref(dy, x, (64, 32, 3, 3))
+    assert dw.shape == ref.shape and dw.dtype == torch.bfloat16 and dw.is_contiguous(memory_format=torch.channels_last)
+    tol = 2.0 ** -8 * ref.abs() + 1e-4 * ref.abs().max()
+    assert bool(((dw.float() - ref).abs() <= tol * 1.01).all()), float((dw.float() - ref).abs().max() / ref.abs().max())
+
+
+def test_stride2_weight_gradient_is_exact_on_integer_data_and_reads_channel_slices():
+    """Small integers on a 2 x 3-row problem: every product and partial sum is an integer below 2^24 (exact in float32); the result
+    is compared with the float32 reference rounded to bf16.  Both operands are channel slices of wider tensors."""
+    from heltondetection_amd import ops
+    dev = torch.device("cuda:0")
+    B, H = 2, 3
+    x, _ = _mkx(B, H, 8, dev, ints=True)
+    dy, _ = _mk(B, H, 9, dev, ints=True)
+    widex = torch.zeros((B, 96, 2 * H, 320), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    widex[:, 64:96] = x
+    widey = torch.zeros((B, 128, H, 160), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    widey[:, 0:64] = dy
+    dw = ops.conv3x3s2_wgrad_rows(widey[:, 0:64], widex[:, 64:96])
+    ref = _wref(dy, x, (64, 32, 3, 3)).to(torch.bfloat16)
+    assert torch.equal(dw, ref.contiguous(memory_format=torch.channels_last))

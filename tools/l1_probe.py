@@ -33,8 +33,12 @@ def main():
     t_dg = timed(lambda i: ops.conv3x3s2_dgrad_rows(gs[i % ROT], w), inner=8)
     t_ldg = timed(lambda i: torch.ops.aten.convolution_backward(gs[i % ROT], xs[0], w, None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
                                                                 (True, False, False)), inner=8)
+    t_wg = timed(lambda i: ops.conv3x3s2_wgrad_rows(gs[i % ROT], xs[i % ROT]), inner=8)
+    t_lwg = timed(lambda i: torch.ops.aten.convolution_backward(gs[i % ROT], xs[i % ROT], w, None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
+                                                                (False, True, False)), inner=8)
     mb_f = 2 * (B * H * 160 * (4 * 32 + 64)) / 1e6
     print(f"forward : ours + statistics {t_fwd:.1f} us ({mb_f / t_fwd:.2f} TB/s of {mb_f:.0f} MB), without {t_fwd0:.1f}; library {t_lib:.1f} + bn_stats {t_st:.1f}")
+    print(f"wgrad   : ours (partials + sum) {t_wg:.1f} us; library incl. its fill and cast {t_lwg:.1f}")
     print(f"dgrad   : ours {t_dg:.1f} us ({mb_f / t_dg:.2f} TB/s); library incl. its fill {t_ldg:.1f}")
 
 

@@ -17,7 +17,7 @@ STEPS = 7
 def family(name: str) -> str:
     if re.search(r"bn_(stats|apply|bwd_reduce|bwd_dx)_kernel", name):
         return "fused BN+act"
-    if re.search(r"pointwise_(stream|conv|wgrad|bwd|longk)_kernel|pointwise_wgrad32_kernel|conv3x3(s2)?_(fwd|wgrad|tap|wgrad_flat)_kernel|conv3x3s2_(fwd|dgrad)_c32_kernel|stem6x6_|wgrad_reduce_kernel", name):
+    if re.search(r"pointwise_(stream|conv|wgrad|bwd|longk)_kernel|pointwise_wgrad32_kernel|conv3x3(s2)?_(fwd|wgrad|tap|wgrad_flat)_kernel|conv3x3s2_(fwd|dgrad|wgrad)_c32_kernel|conv3x3s2_wgrad_sum_kernel|stem6x6_|wgrad_reduce_kernel", name):
         return "hand-written convolutions"
     if "naive_conv" in name:
         return "MIOpen find-mode reference kernels (first step only)"
