@@ -284,7 +284,12 @@ extern "C" int hd_conv3_stamps_read(unsigned long long* host, int n) {
 
 extern "C" int hd_bn_act_replicas(void);
 
+// conv3x3_c32.hip: 32 -> 32 channels on 160-pixel rows (the first C3 block's bottleneck), a row-walk kernel of its own
+int hd_conv3x3_c32_supported(int B, int H, int W, int Cin, int Cout);
+hd_status hd_conv3x3_c32(const void* x, int64_t ldx, const void* w, int B, int H, void* y, int64_t ldy, float* stats, hipStream_t s);
+
 extern "C" int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout) {
+  if (hd_conv3x3_c32_supported(B, H, W, Cin, Cout)) return 1;
   return B >= 1 && H >= 1 && conv3x3_width_ok(W) && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0 &&
          Cin <= 1024 && Cout <= 1024 && (long long)B * H * W <= 0x7fffffff && (long long)B * H <= 65535;
 }
@@ -299,6 +304,7 @@ extern "C" hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const v
   if (!hd_aligned16(x) || !hd_aligned16(w) || !hd_aligned16(y)) return HD_ERR_ALIGN;
   if (stats && hd_bn_act_replicas() != kStatReplicas) return HD_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if (hd_conv3x3_c32_supported(B, H, W, Cin, Cout)) return hd_conv3x3_c32(x, x_row_stride, w, B, H, y, y_row_stride, stats, s);
   // <W, ROWS, MT, workgroups per CU>: ROWS x (W + 2) flat positions per workgroup in 4 MT tiles of 32.  Measured per shape
   // (tools/conv3_probe.py, profiles/r05_conv3.md): 80 / 104-pixel rows two workgroups per CU with MT = 2 (MT = 4 alone on the CU:
   // slower), 52-pixel rows likewise (25.4 / 21.0 us against 31.6 / 26.3 with MT = 1), 40-pixel rows one workgroup of MT = 2 per CU

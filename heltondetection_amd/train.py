@@ -149,7 +149,7 @@ class Trainer:
             from . import ops
             ws = [m.weight_lp for m in model.modules() if isinstance(m, ShadowConv2d) and m.weight_lp is not None
                   and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
-                  and m.in_channels % 64 == 0 and m.out_channels % 64 == 0]
+                  and ((m.in_channels % 64 == 0 and m.out_channels % 64 == 0) or (m.in_channels == m.out_channels == 32))]
             # ... and the 1x1 layers whose data gradient is a long reduction (Cout = 512): their plain transposes, same launch
             ws += [m.weight_lp for m in model.modules() if isinstance(m, ShadowConv2d) and m.weight_lp is not None
                    and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.groups == 1 and m.bias is None

@@ -560,8 +560,8 @@ hd_status hd_pointwise_wgrad(const void* dy, int64_t dy_row_stride, const void* 
  * hd_pointwise_conv (the bottleneck 3x3 of the YOLOv5 C3 blocks):
  *     y[b, h, w, n] (bfloat16) = sum over (ky, kx, c) of x[b, h + ky - 1, w + kx - 1, c] * w[n][ky][kx][c]
  * w: a channels-last [Cout, Cin, 3, 3] bfloat16 weight, i.e. memory [Cout][3][3][Cin].  W in {20, 26, 40, 52, 80, 104}; Cin a
- * multiple of 32, Cout of 64 (csrc/conv3x3.hip); row strides in elements (0 = dense, multiples of 8).  stats: nullable, as for
- * hd_pointwise_conv.
+ * multiple of 32, Cout of 64 (csrc/conv3x3.hip); also W = 160 with Cin = Cout = 32 (csrc/conv3x3_c32.hip); row strides in
+ * elements (0 = dense, multiples of 8).  stats: nullable, as for hd_pointwise_conv.
  * The data gradient is the same entry point applied to dy with the weights flipped and transposed:
  *     wt[c][ky][kx][n] = w[n][2 - ky][2 - kx][c]   ->   dx = hd_conv3x3_fwd(dy, wt, ..., Cin = Cout, Cout = Cin). */
 int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);

@@ -104,7 +104,9 @@ def test_conv3x3_stride2_wgrad_is_exact_on_integer_data(shape, wgrad_kernel):
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 20, 64), (1, 128, 7, 20, 64), (2, 64, 40, 40, 128), (1, 128, 13, 40, 128),
                                    (1, 64, 80, 80, 64), (2, 64, 5, 80, 128), (16, 256, 20, 20, 256), (1, 64, 1, 20, 64),
-                                   (3, 192, 9, 40, 64), (2, 128, 26, 26, 64), (1, 64, 11, 52, 128), (1, 64, 7, 104, 64)])
+                                   (3, 192, 9, 40, 64), (2, 128, 26, 26, 64), (1, 64, 11, 52, 128), (1, 64, 7, 104, 64),
+                                   # csrc/conv3x3_c32.hip (32 -> 32 channels, 160-pixel rows): one row, two, a ragged walk, the bench shape
+                                   (1, 32, 1, 160, 32), (1, 32, 2, 160, 32), (3, 32, 23, 160, 32), (16, 32, 160, 160, 32), (600, 32, 3, 160, 32)])
 def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
     """Small integers: exact sums, so the ring / halo / tap views, the Cin chunking, the pixel-tile padding and the
     transposed store must reproduce F.conv2d exactly; the epilogue's statistics are those of the tensor written."""
@@ -132,7 +134,8 @@ def test_conv3x3_forward_and_statistics_are_exact_on_integer_data(shape):
     assert torch.equal(dx.float(), dref.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("shape", [(2, 96, 9, 40, 64), (1, 32, 6, 20, 64), (2, 160, 4, 80, 128), (1, 32, 3, 104, 64), (2, 96, 5, 26, 64)])
+@pytest.mark.parametrize("shape", [(2, 96, 9, 40, 64), (1, 32, 6, 20, 64), (2, 160, 4, 80, 128), (1, 32, 3, 104, 64), (2, 96, 5, 26, 64),
+                                   (2, 32, 9, 160, 32)])
 def test_conv3x3_forward_takes_input_channels_in_multiples_of_32_and_channel_slices(shape):
     """Round 5: the kernel walks Cin in 32-channel chunks, so Cin = 32, 96, 160 run (the round-4 kernel needed multiples of 64);
     x and y as channel slices of wider channels-last tensors (row stride > channels), the neighbours of y untouched."""

@@ -38,6 +38,16 @@ def main():
                                                                 (False, True, False)), inner=8)
     mb_f = 2 * (B * H * 160 * (4 * 32 + 64)) / 1e6
     print(f"forward : ours + statistics {t_fwd:.1f} us ({mb_f / t_fwd:.2f} TB/s of {mb_f:.0f} MB), without {t_fwd0:.1f}; library {t_lib:.1f} + bn_stats {t_st:.1f}")
+    # the 32 -> 32 3x3 / stride 1 layer at 160^2 (csrc/conv3x3_c32.hip)
+    x32 = [torch.randn(B, 32, 160, 160, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(ROT)]
+    w32 = (torch.randn(32, 32, 3, 3, device=dev) * 0.06).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    st32 = torch.zeros(reps * 2 * 32, device=dev)
+    t_c = timed(lambda i: ops.conv3x3_fwd_rows(x32[i % ROT], w32, st32), inner=8)
+    t_c0 = timed(lambda i: ops.conv3x3_fwd_rows(x32[i % ROT], w32, None), inner=8)
+    t_cl = timed(lambda i: torch.nn.functional.conv2d(x32[i % ROT], w32, None, 1, 1), inner=8)
+    t_cd = timed(lambda i: torch.ops.aten.convolution_backward(x32[i % ROT], x32[0], w32, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                               (True, False, False)), inner=8)
+    print(f"32->32 3x3 at 160^2: ours + statistics {t_c:.1f} us, without (= data gradient) {t_c0:.1f}; library forward {t_cl:.1f}, data gradient incl. fill {t_cd:.1f}")
     print(f"wgrad   : ours (partials + sum) {t_wg:.1f} us; library incl. its fill and cast {t_lwg:.1f}")
     print(f"dgrad   : ours {t_dg:.1f} us ({mb_f / t_dg:.2f} TB/s); library incl. its fill {t_ldg:.1f}")
 
