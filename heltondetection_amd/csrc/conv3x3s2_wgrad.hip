@@ -144,20 +144,25 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_wgrad_c32_kernel(const unsi
     }
 }
 
+// 64 gradient elements per workgroup (288 workgroups: every CU has one), the slabs dealt round-robin to its four waves, the four
+// partial sums folded through LDS.  (One thread per element over all slabs — 72 workgroups — took 23 us for the 19 MB.)
 __global__ __launch_bounds__(256) void conv3x3s2_wgrad_sum_kernel(const float* __restrict__ slab, int n_slabs,
                                                                   unsigned short* __restrict__ dw) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= DW_ELEMS) return;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;  // DW_ELEMS is a multiple of 64
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int k = 0;
-  for (; k + 4 <= n_slabs; k += 4) {
+  int k = wave;
+  for (; k + 12 < n_slabs; k += 16) {
     s0 += slab[(long long)k * DW_ELEMS + e];
-    s1 += slab[(long long)(k + 1) * DW_ELEMS + e];
-    s2 += slab[(long long)(k + 2) * DW_ELEMS + e];
-    s3 += slab[(long long)(k + 3) * DW_ELEMS + e];
+    s1 += slab[(long long)(k + 4) * DW_ELEMS + e];
+    s2 += slab[(long long)(k + 8) * DW_ELEMS + e];
+    s3 += slab[(long long)(k + 12) * DW_ELEMS + e];
   }
-  for (; k < n_slabs; ++k) s0 += slab[(long long)k * DW_ELEMS + e];
-  dw[e] = __builtin_bit_cast(unsigned short, (__bf16)((s0 + s1) + (s2 + s3)));
+  for (; k < n_slabs; k += 4) s0 += slab[(long long)k * DW_ELEMS + e];
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0) dw[e] = __builtin_bit_cast(unsigned short, (__bf16)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])));
 }
 
 inline void plan(int B, int Hout, int* rows, int* per_img) {
@@ -199,7 +204,7 @@ extern "C" hd_status hd_conv3x3s2_wgrad_c32(const void* dy, int64_t dy_row_strid
                   static_cast<const unsigned short*>(dy), (long long)dy_row_stride, static_cast<const unsigned short*>(x),
                   (long long)x_row_stride, static_cast<float*>(workspace), Hout, rows, per_img);
   HD_RETURN_IF_LAUNCH_FAILED();
-  (void)hd_launch(conv3x3s2_wgrad_sum_kernel, dim3((unsigned)((DW_ELEMS + 255) / 256)), dim3(256), 0, s,
+  (void)hd_launch(conv3x3s2_wgrad_sum_kernel, dim3((unsigned)(DW_ELEMS / 64)), dim3(256), 0, s,
                   static_cast<const float*>(workspace), blocks, static_cast<unsigned short*>(dw));
   HD_RETURN_IF_LAUNCH_FAILED();
   return HD_OK;
