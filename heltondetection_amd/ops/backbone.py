@@ -1057,7 +1057,7 @@ def stem_conv(x: torch.Tensor, weight: torch.Tensor, slot: Optional["_StatSlot"]
     return _StemConvFn.apply(x, weight, slot)
 
 
-POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form (weights resident in LDS); longer reductions -> MIOpen
+POINTWISE_MAX_REDUCTION = 256  # hd_pointwise_conv's streaming form; longer reductions -> pointwise_longk.hip (Cin = 512, few rows) or MIOpen
 
 
 class _PointwiseConvFn(torch.autograd.Function):
