@@ -257,61 +257,71 @@ def test_two_rank_overlapped_split_replay_bf16_one_optimizer_step(gpu, tmp_path)
     autocast + bf16 weight shadows + HdAdamW, with lr > 0 for exactly one graph-replayed optimizer step."""
     world = 2
     spread = _pretrain(tmp_path)
-    for use_graph in (True, False):
-        mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
-    g0, g1 = torch.load(tmp_path / "og0.pt"), torch.load(tmp_path / "og1.pt")
-    e0, e1 = torch.load(tmp_path / "oe0.pt"), torch.load(tmp_path / "oe1.pt")
-    assert g0["graph"] and g1["graph"], (g0["graph_error"], g1["graph_error"])
-    assert g0["segments"] >= 3
-    assert g0["graph_sync"] is False and g1["graph_sync"] is False           # the overlapped branch really ran ...
-    # the overlapped replay checks itself at capture (Trainer._verify_overlap): every bucket's overlapped all-reduce equals
-    # the drained all-reduce of a stream-ordered copy of the same packed gradients — exact up to float32 summation order,
-    # so a collective that ran ahead of its segment (stale or half-written bucket) cannot pass
-    assert g0["overlap_error"] is None and g1["overlap_error"] is None, (g0["overlap_error"], g1["overlap_error"])
-    assert g0["overlap_check"] is not None and g0["overlap_check"] < 1e-5, g0["overlap_check"]
-    for a, b in zip(g0["params"], g1["params"]):
-        assert torch.equal(a, b)                                             # ... and left both ranks bit-identical
-    for a, b in zip(g0["shadows"], g1["shadows"]):
-        assert torch.equal(a, b)
-    for a, b in zip(g0["grads"], g1["grads"]):
-        assert torch.equal(a, b)
-    for a, b in zip(e0["params"], e1["params"]):
-        assert torch.equal(a, b)
-    assert all(bool(torch.isfinite(a).all()) for a in g0["params"])
-    moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["params"], g0["before"]))
-    assert moved > 0                                                         # lr > 0: the replayed step moved the weights
-    assert g0["segments"] >= 6                                               # the shipped bucket plan, not a test-sized one
-    # Against the eager 2-rank step, PER BUCKET.  Both runs start from the same pre-trained weights: at random init this
-    # network amplifies rounding differences so strongly that two FLOAT32 runs of one step differ by 0.27 in their gradients
-    # (profiles/r04_grad_fidelity.md: chaos of a random-init BatchNorm network, not bf16 storage of a common-mode part — that
-    # round-3 hypothesis is refuted there); after a few hundred steps two bf16 runs agree to ~0.14.  Bound stated before the
-    # first run of this form: every bucket's averaged gradient within 0.33 relative L2 (cosine >= 0.9) of the eager run's.  A
-    # bucket that missed its all-reduce, was reduced before its segment finished, or lost a tensor is off by >= 1.0: it
-    # cannot pass by a factor of three.
-    # The box term stays in the compared step (round 4 had switched it off after a 1-in-5 failure; ADVICE r04: then a missing
-    # or mis-ordered reduction that only touches the Detect bucket's box gradient would pass).  d(CIoU)/d(box) jumps where an
-    # edge of the predicted box crosses the target's, so two runs whose logits differ by rounding noise occasionally sit on
-    # different sides of such a kink for one of the ~100 positives of this small batch: seen once in five runs as bucket 0 (the
-    # Detect layers) at 0.351 / cosine 0.94, every other bucket <= 0.1 (typical bucket 0: 0.01 - 0.10).  Bound for bucket 0 ONLY,
-    # stated before this form first ran: 0.5 relative L2, cosine >= 0.85 (a Detect bucket that was not reduced is one shard's
-    # gradient against the two-shard mean; the ranks' parameters, shadows and gradients are also compared bit for bit above).
-    assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"]), (g0["loss"], e0["loss"])
-    assert len(g0["buckets"]) == len(e0["buckets"]) >= 6
-    worst = []
-    for k, (a, b) in enumerate(zip(g0["buckets"], e0["buckets"])):
-        rel = float((a.double() - b.double()).norm() / b.double().norm())
-        cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
-        worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
-    print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst, "eager step spread at this point:", round(spread, 3))
-    ok = all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst)
-    if not ok:   # which tensors, and by what factor: norm ratio graph / eager per parameter gradient (both runs, rank 0)
-        ratios = []
-        for i, (a, b) in enumerate(zip(g0["grads"], e0["grads"])):
-            nb = float(b.double().norm())
-            ratios.append((i, tuple(a.shape), round(float(a.double().norm()) / nb, 3) if nb > 0 else None,
-                           round(float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm() + 1e-30)), 3)))
-        print("per-parameter (index, shape, |graph| / |eager|, cosine):", ratios)
-    assert ok, worst
+    # What is tested is deterministic when it fails (a bucket that missed its all-reduce, was reduced early or lost a tensor is off by
+    # >= 1.0 in EVERY run; the structural checks fail in every run); the run-to-run noise of the compared gradients is not — even at
+    # a calm point one of eight graph runs of tools/repro/two_rank_flake.py had its Detect-side buckets at 0.57 while two eager runs
+    # agreed to 0.011.  So: up to three attempts (a graph run + an eager run each); the structural checks must hold in every attempt,
+    # the numeric bound in at least one.
+    seen = []
+    for attempt in range(3):
+        for use_graph in (True, False):
+            mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
+        g0, g1 = torch.load(tmp_path / "og0.pt"), torch.load(tmp_path / "og1.pt")
+        e0, e1 = torch.load(tmp_path / "oe0.pt"), torch.load(tmp_path / "oe1.pt")
+        assert g0["graph"] and g1["graph"], (g0["graph_error"], g1["graph_error"])
+        assert g0["segments"] >= 3
+        assert g0["graph_sync"] is False and g1["graph_sync"] is False           # the overlapped branch really ran ...
+        # the overlapped replay checks itself at capture (Trainer._verify_overlap): every bucket's overlapped all-reduce equals
+        # the drained all-reduce of a stream-ordered copy of the same packed gradients — exact up to float32 summation order,
+        # so a collective that ran ahead of its segment (stale or half-written bucket) cannot pass
+        assert g0["overlap_error"] is None and g1["overlap_error"] is None, (g0["overlap_error"], g1["overlap_error"])
+        assert g0["overlap_check"] is not None and g0["overlap_check"] < 1e-5, g0["overlap_check"]
+        for a, b in zip(g0["params"], g1["params"]):
+            assert torch.equal(a, b)                                             # ... and left both ranks bit-identical
+        for a, b in zip(g0["shadows"], g1["shadows"]):
+            assert torch.equal(a, b)
+        for a, b in zip(g0["grads"], g1["grads"]):
+            assert torch.equal(a, b)
+        for a, b in zip(e0["params"], e1["params"]):
+            assert torch.equal(a, b)
+        assert all(bool(torch.isfinite(a).all()) for a in g0["params"])
+        moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(g0["params"], g0["before"]))
+        assert moved > 0                                                         # lr > 0: the replayed step moved the weights
+        assert g0["segments"] >= 6                                               # the shipped bucket plan, not a test-sized one
+        # Against the eager 2-rank step, PER BUCKET.  Both runs start from the same pre-trained weights: at random init this
+        # network amplifies rounding differences so strongly that two FLOAT32 runs of one step differ by 0.27 in their gradients
+        # (profiles/r04_grad_fidelity.md: chaos of a random-init BatchNorm network, not bf16 storage of a common-mode part — that
+        # round-3 hypothesis is refuted there); after a few hundred steps two bf16 runs agree to ~0.14.  Bound stated before the
+        # first run of this form: every bucket's averaged gradient within 0.33 relative L2 (cosine >= 0.9) of the eager run's.  A
+        # bucket that missed its all-reduce, was reduced before its segment finished, or lost a tensor is off by >= 1.0: it
+        # cannot pass by a factor of three.
+        # The box term stays in the compared step (round 4 had switched it off after a 1-in-5 failure; ADVICE r04: then a missing
+        # or mis-ordered reduction that only touches the Detect bucket's box gradient would pass).  d(CIoU)/d(box) jumps where an
+        # edge of the predicted box crosses the target's, so two runs whose logits differ by rounding noise occasionally sit on
+        # different sides of such a kink for one of the ~100 positives of this small batch: seen once in five runs as bucket 0 (the
+        # Detect layers) at 0.351 / cosine 0.94, every other bucket <= 0.1 (typical bucket 0: 0.01 - 0.10).  Bound for bucket 0 ONLY,
+        # stated before this form first ran: 0.5 relative L2, cosine >= 0.85 (a Detect bucket that was not reduced is one shard's
+        # gradient against the two-shard mean; the ranks' parameters, shadows and gradients are also compared bit for bit above).
+        assert abs(g0["loss"] - e0["loss"]) < 2e-2 * abs(e0["loss"]), (g0["loss"], e0["loss"])
+        assert len(g0["buckets"]) == len(e0["buckets"]) >= 6
+        worst = []
+        for k, (a, b) in enumerate(zip(g0["buckets"], e0["buckets"])):
+            rel = float((a.double() - b.double()).norm() / b.double().norm())
+            cos = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
+            worst.append((round(rel, 3), round(cos, 4), k, a.numel()))
+        print("per-bucket (rel-L2, cosine, bucket, elements) graph vs eager:", worst, "eager step spread at this point:", round(spread, 3))
+        ok = all((rel < 0.5 and cos >= 0.85) if k == 0 else (rel < 0.33 and cos >= 0.9) for rel, cos, k, _ in worst)
+        if not ok:   # which tensors, and by what factor: norm ratio graph / eager per parameter gradient (both runs, rank 0)
+            ratios = []
+            for i, (a, b) in enumerate(zip(g0["grads"], e0["grads"])):
+                nb = float(b.double().norm())
+                ratios.append((i, tuple(a.shape), round(float(a.double().norm()) / nb, 3) if nb > 0 else None,
+                               round(float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm() + 1e-30)), 3)))
+            print("per-parameter (index, shape, |graph| / |eager|, cosine):", ratios)
+        seen.append(worst)
+        if ok:
+            break
+    assert ok, seen
     assert max(g0["times"]) < 60.0 and max(g1["times"]) < 60.0                # generous: correctness run, not a timing
 
 
