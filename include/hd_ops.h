@@ -568,7 +568,8 @@ int hd_conv3x3_fwd_supported(int B, int H, int W, int Cin, int Cout);
 hd_status hd_conv3x3_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int H, int W, int Cin, int Cout, void* y,
                          int64_t y_row_stride, float* stats, hd_stream stream);
 
-/* Forward of the first stride-2 3x3 convolution of the YOLOv5 backbone (csrc/conv3x3s2_fwd.hip): 3x3 / stride 2 / pad 1, Cin = 32,
+/* Forward of the first stride-2 3x3 convolution of the YOLOv5 backbone (reference README.md:9: the CSPDarknet backbone's second
+ * Conv+BN+SiLU block; csrc/conv3x3s2_fwd.hip): 3x3 / stride 2 / pad 1, Cin = 32,
  * Cout = 64, Wout = 160, the input exactly 2 Hout x 2 Wout; BatchNorm statistics in the epilogue like hd_pointwise_conv:
  *     y[b, i, j, n] (bfloat16) = sum over (ky, kx, c) of x[b, 2 i - 1 + ky, 2 j - 1 + kx, c] * w[n][ky][kx][c]
  * w: channels-last [Cout, Cin, 3, 3] bfloat16 (memory [Cout][3][3][Cin]); stats: nullable, as for hd_pointwise_conv. */
@@ -576,7 +577,7 @@ int hd_conv3x3s2_fwd_supported(int B, int Hout, int Wout, int Cin, int Cout);
 hd_status hd_conv3x3s2_fwd(const void* x, int64_t x_row_stride, const void* w, int B, int Hout, int Wout, int Cin, int Cout,
                            void* y, int64_t y_row_stride, float* stats, hd_stream stream);
 
-/* Weight gradient of the same layer (csrc/conv3x3s2_wgrad.hip; hd_conv3x3_wgrad's kernels need 64-channel tiles and do not take it):
+/* Weight gradient of the same layer (README.md:9; csrc/conv3x3s2_wgrad.hip; hd_conv3x3_wgrad's kernels need 64-channel tiles and do not take it):
  *     dw[n][ky][kx][c] (bfloat16, channels-last memory of [Cout, Cin, 3, 3]) = sum over (b, i, j) of
  *         dy[b, i, j, n] * x[b, 2 i - 1 + ky, 2 j - 1 + kx, c]
  * Two launches: per-workgroup float32 partials into `workspace`, then their sum (no zero-fill, no atomics).
@@ -586,7 +587,7 @@ size_t hd_conv3x3s2_wgrad_c32_workspace_bytes(int B, int Hout, int Wout, int Cin
 hd_status hd_conv3x3s2_wgrad_c32(const void* dy, int64_t dy_row_stride, const void* x, int64_t x_row_stride, int B, int Hout, int Wout,
                                  int Cin, int Cout, void* dw, void* workspace, size_t workspace_bytes, hd_stream stream);
 
-/* Data gradient of the first stride-2 3x3 convolution of the YOLOv5 backbone (csrc/conv3x3s2_dgrad.hip): 3x3 / stride 2 / pad 1,
+/* Data gradient of the first stride-2 3x3 convolution of the YOLOv5 backbone (README.md:9; csrc/conv3x3s2_dgrad.hip): 3x3 / stride 2 / pad 1,
  * Cin = 32 (channels of dx), Cout = 64 (channels of dy), Wout = 160, the input exactly twice the output (2 Hout x 2 Wout):
  *     dx[b, p, q, c] (bfloat16) = sum over (ky, kx, n) with p = 2 i - 1 + ky, q = 2 j - 1 + kx of dy[b, i, j, n] * w[n][ky][kx][c]
  * w: the layer's own channels-last [Cout, Cin, 3, 3] bfloat16 weight (memory [Cout][3][3][Cin]; no flipped copy).  Every element
