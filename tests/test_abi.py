@@ -127,3 +127,41 @@ def test_detect_convolution_host_arithmetic_and_validation():
     assert lib.hd_head_conv_bwd_supported(6400, 128, 300) == 0
     assert lib.hd_head_conv_bwd_workspace_bytes(102400, 128, 255) == lib.hd_pointwise_bwd_workspace_bytes(102400, 128, 256) > 0
     assert lib.hd_head_conv_fwd(None, 0, None, None, 64, 128, 255, None, 0, None) == -1          # HD_ERR_NULL
+
+
+def test_first_layer_and_long_reduction_entry_points_host_arithmetic_and_validation():
+    """Round 5's late entry points: support predicates, the workspace query and the argument checks are host code (no GPU touched)."""
+    import ctypes as C
+    from heltondetection_amd import _lib
+    lib = _lib.load()
+    for fn in (lib.hd_conv3x3s2_fwd_supported, lib.hd_conv3x3s2_dgrad_supported, lib.hd_conv3x3s2_wgrad_c32_supported):
+        assert fn(16, 160, 160, 32, 64) == 1
+        assert fn(16, 208, 208, 32, 64) == 0            # 832^2: the library keeps the layer
+        assert fn(16, 160, 160, 64, 128) == 0
+        assert fn(0, 160, 160, 32, 64) == 0
+    # one float32 slab of 64 x 9 x 32 per workgroup, ~256 workgroups of whole rows of one image
+    assert lib.hd_conv3x3s2_wgrad_c32_workspace_bytes(16, 160, 160, 32, 64) == 16 * 16 * 64 * 9 * 32 * 4
+    assert lib.hd_conv3x3s2_wgrad_c32_workspace_bytes(1, 3, 160, 32, 64) == 3 * 64 * 9 * 32 * 4
+    assert lib.hd_conv3x3s2_wgrad_c32_workspace_bytes(16, 80, 80, 64, 128) == 0
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    assert lib.hd_conv3x3s2_fwd(None, 0, p, 1, 4, 160, 32, 64, p, 0, None, None) == -1                      # HD_ERR_NULL
+    assert lib.hd_conv3x3s2_fwd(p, 0, p, 1, 4, 80, 32, 64, p, 0, None, None) == -2                          # HD_ERR_SHAPE
+    assert lib.hd_conv3x3s2_fwd(p, 36, p, 1, 4, 160, 32, 64, p, 0, None, None) == -2                        # row stride not a multiple of 8
+    assert lib.hd_conv3x3s2_dgrad(C.c_void_p(p.value + 2), 0, p, 1, 4, 160, 32, 64, p, 0, None) == -3       # HD_ERR_ALIGN
+    assert lib.hd_conv3x3s2_wgrad_c32(p, 0, p, 0, 1, 4, 160, 32, 64, p, p, 16, None) == -4                  # HD_ERR_WORKSPACE
+    # the 32 -> 32 layer at 160 pixels rides behind hd_conv3x3_fwd; the tap kernel's own shapes are unchanged
+    assert lib.hd_conv3x3_fwd_supported(16, 160, 160, 32, 32) == 1
+    assert lib.hd_conv3x3_fwd_supported(16, 160, 160, 32, 64) == 0 and lib.hd_conv3x3_fwd_supported(16, 80, 80, 32, 32) == 0
+    assert lib.hd_conv3x3_fwd_supported(16, 80, 80, 64, 64) == 1
+    # long reductions: Cin = 512 on at most 16 384 rows (pointwise_longk.hip) counts as a resident-weight form
+    assert lib.hd_pointwise_conv_resident(6400, 512, 256) == 1 and lib.hd_pointwise_conv_resident(6400, 512, 512) == 1
+    assert lib.hd_pointwise_conv_resident(25600, 512, 256) == 0 and lib.hd_pointwise_conv_resident(6400, 1024, 512) == 0
+    assert lib.hd_pointwise_conv_resident(6400, 512, 192) == 0          # not a multiple of the 128-wide column tile
+    # the flip launch: tap counts other than 1 and 9 are refused before anything is launched
+    one = (C.c_void_p * 1)(p.value)
+    n = (C.c_int * 1)(32)
+    bad = (C.c_int * 1)(4)
+    assert lib.hd_conv_flip_weights(1, one, one, n, n, bad, None) == -2
+    assert lib.hd_conv_flip_weights(0, None, None, None, None, None, None) == 0
+    assert lib.hd_conv_flip_weights(33, one, one, n, n, None, None) == -2
