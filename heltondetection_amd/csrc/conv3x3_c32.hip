@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NTHREAD, 2) void conv3x3_c32_kernel(const unsigned 
   unsigned short* yb = y + (long long)b * H * WD * ld_y;
 
   u32x4 pre[LD_IT];
-  auto gload = [&](int row) {  // rows outside the image are zeros (uniform branch)
+  auto gload = [&](u32x4 (&pre)[LD_IT], int row) {  // rows outside the image are zeros (uniform branch)
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
       const int id = p * NTHREAD + tid;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NTHREAD, 2) void conv3x3_c32_kernel(const unsigned 
     }
   };
   auto slot_of = [&](int row) { return s_ring + ((row + 3) % 3) * ROW_BYTES; };
-  auto lstore = [&](int row) {
+  auto lstore = [&](const u32x4 (&pre)[LD_IT], int row) {
     unsigned char* dst = slot_of(row) + EN;  // pixel p is entry p + 1
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
@@ -72,28 +72,38 @@ __global__ __launch_bounds__(NTHREAD, 2) void conv3x3_c32_kernel(const unsigned 
     }
   };
 
-  gload(r0 - 1);
+  // Prologue: the weight's chunks (4 per thread) and rows r0 - 1, r0 are all requested before the first LDS store (a load -> store
+  // loop is one L2 round trip per chunk: see conv3x3s2_fwd.hip).
+  constexpr int WCH = CO * (KTOT / 8), WIT = (WCH + NTHREAD - 1) / NTHREAD;
+  u32x4 wreg[WIT], pre_b[LD_IT];
+#pragma unroll
+  for (int p = 0; p < WIT; ++p) {
+    const int id = p * NTHREAD + tid < WCH ? p * NTHREAD + tid : WCH - 1;  // threads past the end re-read the last chunk (never stored)
+    wreg[p] = *reinterpret_cast<const u32x4*>(w + (long long)(id / (KTOT / 8)) * KTOT + (id % (KTOT / 8)) * 8);
+  }
+  gload(pre_b, r0 - 1);
+  gload(pre, r0);
   if (tid < 3 * 2 * 4) {  // the zero pixels left and right of each ring row (never overwritten)
     const int slot = tid / 8, side = (tid >> 2) & 1, c = tid & 3;
     *reinterpret_cast<u32x4*>(s_ring + slot * ROW_BYTES + (side ? (WD + 1) * EN : 0) + c * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   if (STATS)
     for (int i = tid; i < 2 * CO; i += NTHREAD) s_st[i] = 0.0f;
-  for (int id = tid; id < CO * (KTOT / 8); id += NTHREAD) {  // the weight as it lies: [co][288] -> rows of 592 bytes
-    const int co = id / (KTOT / 8), c = id % (KTOT / 8);
-    *reinterpret_cast<u32x4*>(s_w + co * W_ROW + c * 16) = *reinterpret_cast<const u32x4*>(w + (long long)co * KTOT + c * 8);
+#pragma unroll
+  for (int p = 0; p < WIT; ++p) {  // the weight as it lies: [co][288] -> rows of 592 bytes
+    const int id = p * NTHREAD + tid;
+    if (id < WCH) *reinterpret_cast<u32x4*>(s_w + (id / (KTOT / 8)) * W_ROW + (id % (KTOT / 8)) * 16) = wreg[p];
   }
-  lstore(r0 - 1);
-  gload(r0);
-  lstore(r0);
-  gload(r0 + 1);  // stored inside the first iteration
+  lstore(pre_b, r0 - 1);
+  lstore(pre, r0);
+  gload(pre, r0 + 1);  // stored inside the first iteration
 
   const int j0 = wave * 32;
   float s_sum = 0.0f, s_sq = 0.0f;
   // Invariant at the top of iteration i: rows i - 1 and i are in the ring, `pre` holds row i + 1.
   for (int i = r0; i < r1; ++i) {
-    lstore(i + 1);    // into the slot row i - 2 left: its last reader passed the barrier at the end of iteration i - 1
-    if (i + 1 < r1) gload(i + 2);
+    lstore(pre, i + 1);    // into the slot row i - 2 left: its last reader passed the barrier at the end of iteration i - 1
+    if (i + 1 < r1) gload(pre, i + 2);
     __syncthreads();  // the three rows of this output row are visible
     f32x16 acc;
 #pragma unroll

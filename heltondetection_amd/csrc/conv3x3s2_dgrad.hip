@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_dgrad_c32_kernel(const unsi
   unsigned short* dxb = dx + (long long)b * (2 * H) * (2 * WOUT) * ld_dx;
 
   u32x4 pre[LD_IT];
-  auto gload = [&](int row) {  // rows >= H are zeros (uniform branch)
+  auto gload = [&](u32x4 (&pre)[LD_IT], int row) {  // rows >= H are zeros (uniform branch)
     if (row < H) {
 #pragma unroll
       for (int p = 0; p < LD_IT; ++p) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_dgrad_c32_kernel(const unsi
       for (int p = 0; p < LD_IT; ++p) pre[p] = u32x4{0u, 0u, 0u, 0u};
     }
   };
-  auto lstore = [&](int row) {
+  auto lstore = [&](const u32x4 (&pre)[LD_IT], int row) {
     unsigned char* dst = s_ring + (row % 3) * ROW_BYTES;
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
@@ -75,28 +75,41 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_dgrad_c32_kernel(const unsi
     }
   };
 
-  gload(r0);
+  // Prologue: the weight's chunks (8 per thread) and dy rows r0, r0 + 1 are all requested before the first LDS store (as a
+  // load -> store loop the weight alone was eight L2 round trips per workgroup: see conv3x3s2_fwd.hip).
+  constexpr int WCH = CO * 9 * (CI / 8), WIT = (WCH + NTHREAD - 1) / NTHREAD;
+  u32x4 wreg[WIT], pre_b[LD_IT];
+#pragma unroll
+  for (int p = 0; p < WIT; ++p) {
+    const int id = p * NTHREAD + tid < WCH ? p * NTHREAD + tid : WCH - 1;  // threads past the end re-read the last chunk (never stored)
+    const int co = id / (9 * (CI / 8)), rem = id % (9 * (CI / 8)), tap = rem / (CI / 8), c8 = rem % (CI / 8);
+    wreg[p] = *reinterpret_cast<const u32x4*>(w + ((long long)co * 9 + tap) * CI + c8 * 8);
+  }
+  gload(pre, r0);
+  gload(pre_b, r0 + 1);
   if (tid < 3 * 8)  // the zero pixel right of each ring row (never overwritten)
     *reinterpret_cast<u32x4*>(s_ring + (tid >> 3) * ROW_BYTES + WOUT * PX + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
-  for (int id = tid; id < CO * 9 * (CI / 8); id += NTHREAD) {  // w[co][tap][ci] -> s_w[tap][ci][co]
-    const int co = id / (9 * (CI / 8)), rem = id % (9 * (CI / 8)), tap = rem / (CI / 8), c8 = rem % (CI / 8);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((long long)co * 9 + tap) * CI + c8 * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const unsigned short x = (unsigned short)(v[e >> 1] >> ((e & 1) * 16));
-      *reinterpret_cast<unsigned short*>(s_w + (tap * CI + c8 * 8 + e) * W_ROW + co * 2) = x;
+  for (int p = 0; p < WIT; ++p) {  // w[co][tap][ci] -> s_w[tap][ci][co]
+    const int id = p * NTHREAD + tid;
+    if (id < WCH) {
+      const int co = id / (9 * (CI / 8)), rem = id % (9 * (CI / 8)), tap = rem / (CI / 8), c8 = rem % (CI / 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned short x = (unsigned short)(wreg[p][e >> 1] >> ((e & 1) * 16));
+        *reinterpret_cast<unsigned short*>(s_w + (tap * CI + c8 * 8 + e) * W_ROW + co * 2) = x;
+      }
     }
   }
-  lstore(r0);
-  gload(r0 + 1);
-  lstore(r0 + 1);
-  if (r0 + 2 <= r1) gload(r0 + 2);
+  lstore(pre, r0);
+  lstore(pre_b, r0 + 1);
+  if (r0 + 2 <= r1) gload(pre, r0 + 2);
 
   const int j0 = wave * 32;
   for (int i = r0; i < r1; ++i) {
     __syncthreads();  // the previous row's reads are done (its slot is free), the rows stored since are visible
-    if (i + 2 <= r1) lstore(i + 2);
-    if (i + 3 <= r1) gload(i + 3);
+    if (i + 2 <= r1) lstore(pre, i + 2);
+    if (i + 3 <= r1) gload(pre, i + 3);
     const unsigned char* cur = s_ring + (i % 3) * ROW_BYTES + (j0 + frow) * PX + fh * 16;
     const unsigned char* nxt = s_ring + ((i + 1) % 3) * ROW_BYTES + (j0 + frow) * PX + fh * 16;
     const unsigned char* wl = s_w + frow * W_ROW + fh * 16;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_fwd_c32_kernel(const unsign
   unsigned short* yb = y + (long long)b * H * WOUT * ld_y;
 
   u32x4 pre[LD_IT];
-  auto gload = [&](int row0, int first, int last) {  // fetch instructions [first, last) of input rows row0, row0 + 1
+  auto gload = [&](u32x4 (&pre)[LD_IT], int row0, int first, int last) {  // fetch instructions [first, last) of input rows row0, row0 + 1
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
       if (p < first || p >= last) continue;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_fwd_c32_kernel(const unsign
     }
   };
   auto slot_of = [&](int row) { return s_ring + ((row + 3) % 3) * ROW_BYTES; };
-  auto lstore = [&](int row0, int first, int last) {  // fetch instructions [first, last) of the two rows
+  auto lstore = [&](const u32x4 (&pre)[LD_IT], int row0, int first, int last) {  // fetch instructions [first, last) of the two rows
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
       if (p < first || p >= last) continue;
@@ -79,19 +79,30 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_fwd_c32_kernel(const unsign
     }
   };
 
-  gload(2 * r0 - 1, 0, LD_IT);  // rows 2 r0 - 1, 2 r0
+  // Prologue: EVERY load of the start-up — the weight (8 chunks per thread), input rows 2 r0 - 1, 2 r0 and 2 r0 + 1 — is issued
+  // before the first LDS store.  (As a load -> store loop the weight alone was eight L2 round trips per workgroup, and the rows
+  // two more: ~10 us of a 44 us launch; the same finding as in the streaming 1x1 kernels)
+  constexpr int WCH = CO * (KTOT / 8), WIT = (WCH + NTHREAD - 1) / NTHREAD;
+  u32x4 wreg[WIT], pre_b[LD_IT];
+#pragma unroll
+  for (int p = 0; p < WIT; ++p) {
+    const int id = p * NTHREAD + tid < WCH ? p * NTHREAD + tid : WCH - 1;  // threads past the end re-read the last chunk (never stored)
+    wreg[p] = *reinterpret_cast<const u32x4*>(w + (long long)(id / (KTOT / 8)) * KTOT + (id % (KTOT / 8)) * 8);
+  }
+  gload(pre, 2 * r0 - 1, 0, LD_IT);        // rows 2 r0 - 1, 2 r0
+  gload(pre_b, 2 * r0 + 1, 0, LD_IT / 2);  // row 2 r0 + 1 completes output row r0
   if (tid < 3 * 4)    // odd-plane entry 0 of each ring row: the zero pixel left of the image (never overwritten)
     *reinterpret_cast<u32x4*>(s_ring + (tid >> 2) * ROW_BYTES + ODD_OFF + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
   if (STATS)
     for (int i = tid; i < 2 * CO; i += NTHREAD) s_st[i] = 0.0f;
-  for (int id = tid; id < CO * (KTOT / 8); id += NTHREAD) {  // the weight as it lies: [co][288] -> rows of 592 bytes
-    const int co = id / (KTOT / 8), c = id % (KTOT / 8);
-    *reinterpret_cast<u32x4*>(s_w + co * W_ROW + c * 16) = *reinterpret_cast<const u32x4*>(w + (long long)co * KTOT + c * 8);
+#pragma unroll
+  for (int p = 0; p < WIT; ++p) {  // the weight as it lies: [co][288] -> rows of 592 bytes
+    const int id = p * NTHREAD + tid;
+    if (id < WCH) *reinterpret_cast<u32x4*>(s_w + (id / (KTOT / 8)) * W_ROW + (id % (KTOT / 8)) * 16) = wreg[p];
   }
-  lstore(2 * r0 - 1, 0, LD_IT);
-  gload(2 * r0 + 1, 0, LD_IT / 2);  // row 2 r0 + 1 completes output row r0
-  lstore(2 * r0 + 1, 0, LD_IT / 2);
-  if (r0 + 1 < r1) gload(2 * r0 + 2, 0, LD_IT);  // rows 2 r0 + 2, 2 r0 + 3 travel while row r0 is multiplied
+  lstore(pre, 2 * r0 - 1, 0, LD_IT);
+  lstore(pre_b, 2 * r0 + 1, 0, LD_IT / 2);
+  if (r0 + 1 < r1) gload(pre, 2 * r0 + 2, 0, LD_IT);  // rows 2 r0 + 2, 2 r0 + 3 travel while row r0 is multiplied
 
   const int j0 = wave * 32;
   float s_sum[2] = {0.0f, 0.0f}, s_sq[2] = {0.0f, 0.0f};
@@ -130,8 +141,8 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_fwd_c32_kernel(const unsign
     }
     __syncthreads();  // every wave has read rows 2i - 1 and 2i: their slots take rows 2i + 2 and 2i + 3
     if (i + 1 < r1) {
-      lstore(2 * i + 2, 0, LD_IT);
-      if (i + 2 < r1) gload(2 * i + 4, 0, LD_IT);
+      lstore(pre, 2 * i + 2, 0, LD_IT);
+      if (i + 2 < r1) gload(pre, 2 * i + 4, 0, LD_IT);
     }
     // C/D map: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (position)  ->  patch[position][co]
 #pragma unroll

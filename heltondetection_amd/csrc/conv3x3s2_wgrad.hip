@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_wgrad_c32_kernel(const unsi
 
   // one fetch = input rows xrow0, xrow0 + 1 and dy row drow: chunk ids [0, 2 XCHUNKS) are x, the rest dy
   u32x4 pre[LD_IT];
-  auto gload = [&](int xrow0, int drow, bool first_x_only) {
+  auto gload = [&](u32x4 (&pre)[LD_IT], int xrow0, int drow, bool first_x_only) {
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
       const int id = p * NTHREAD + tid;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_wgrad_c32_kernel(const unsi
     }
   };
   auto xslot = [&](int row) { return s_x + ((row + 3) % 3) * XROW_BYTES; };
-  auto lstore = [&](int xrow0, int drow, bool second_x, bool with_dy) {
+  auto lstore = [&](const u32x4 (&pre)[LD_IT], int xrow0, int drow, bool second_x, bool with_dy) {
 #pragma unroll
     for (int p = 0; p < LD_IT; ++p) {
       const int id = p * NTHREAD + tid;
@@ -99,11 +99,13 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_wgrad_c32_kernel(const unsi
 
   if (tid < 3 * 4)  // odd-plane entry 0 of each x ring row: the zero pixel left of the image (never overwritten)
     *reinterpret_cast<u32x4*>(s_x + (tid >> 2) * XROW_BYTES + ODD_OFF + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
-  gload(2 * r0 - 1, r0, false);   // x rows 2 r0 - 1, 2 r0; dy row r0
-  lstore(2 * r0 - 1, r0, true, true);
-  gload(2 * r0 + 1, 0, true);     // x row 2 r0 + 1 completes output row r0 (only the first row of this fetch is loaded)
-  lstore(2 * r0 + 1, 0, false, false);
-  if (r0 + 1 < r1) gload(2 * r0 + 2, r0 + 1, false);  // the next output row's operands travel while this one is multiplied
+  u32x4 pre_b[LD_IT];
+  gload(pre, 2 * r0 - 1, r0, false);   // x rows 2 r0 - 1, 2 r0; dy row r0
+  gload(pre_b, 2 * r0 + 1, 0, true);   // x row 2 r0 + 1 completes output row r0 (only the first row of this fetch is loaded);
+                                       // both fetches are in flight before the first LDS store
+  lstore(pre, 2 * r0 - 1, r0, true, true);
+  lstore(pre_b, 2 * r0 + 1, 0, false, false);
+  if (r0 + 1 < r1) gload(pre, 2 * r0 + 2, r0 + 1, false);  // the next output row's operands travel while this one is multiplied
 
   const int nt = wave / 3, ky = wave % 3;  // this wave's tiles: dw[32 nt ..][ky][kx = 0, 1, 2][c]
   f32x16 acc[3];
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(NTHREAD) void conv3x3s2_wgrad_c32_kernel(const unsi
     }
     __syncthreads();  // every wave has read x rows 2i - 1, 2i and dy row i: their slots take the next operands
     if (i + 1 < r1) {
-      lstore(2 * i + 2, i + 1, true, true);
-      if (i + 2 < r1) gload(2 * i + 4, i + 2, false);
+      lstore(pre, 2 * i + 2, i + 1, true, true);
+      if (i + 2 < r1) gload(pre, 2 * i + 4, i + 2, false);
     }
   }
   // C/D map: col = lane & 31 (c), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)  ->  slab[workgroup][n][ky][kx][c]
