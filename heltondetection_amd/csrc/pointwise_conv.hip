@@ -939,7 +939,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  const int half = PAIR ? (int)(threadIdx.x >> 8) : 0;
+  const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: slice, rows and ring base stay in SGPRs
   unsigned char* xs = smem + half * RING;
   unsigned char* ys = xs + 3 * XROW;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -957,27 +957,32 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
   // both halves run the same number of (image, row) iterations: the barriers are the workgroup's
   const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
-  for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-
   const u32x4 zero = {0u, 0u, 0u, 0u};
   int b = b_first;
+  // Row loads are buffer instructions: a descriptor per (image row, 64-channel tile) built from uniform values, whose range ends
+  // with the tile's last channel of the row's last pixel; the lane's byte offset inside a block of 32 pixels in ONE VGPR per
+  // tensor for the whole kernel, the block's offset (i * 32 pixels) in an SGPR — instead of a 64-bit address per load and lane.
+  const int vo_x = ((tid >> 3) * (int)ld_x + (tid & 7) * 8) * 2, vo_y = ((tid >> 3) * (int)ld_dy + (tid & 7) * 8) * 2;
+  const int sx32 = 32 * (int)ld_x * 2, sy32 = 32 * (int)ld_dy * 2;
+  const int rec_x = ((W - 1) * (int)ld_x + 64) * 2, rec_y = ((W - 1) * (int)ld_dy + 64) * 2;
   auto load_x = [&](int h, u32x4* r) {  // image row h of X (zeros outside the image)
     const int hc = min(max(h, 0), H - 1);
     const unsigned short* base = X + ((long long)(b * H + hc) * W) * ld_x + k0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_x, 0x00020000);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int id = i * 256 + tid;
-      if (CH % 256 == 0 || id < CH) r[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_x + (id & 7) * 8);
+      if (CH % 256 == 0 || id < CH) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
     }
   };
   auto load_y = [&](int h, u32x4* r) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_y, 0x00020000);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int id = i * 256 + tid;
-      if (CH % 256 == 0 || id < CH) r[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_dy + (id & 7) * 8);
+      if (CH % 256 == 0 || id < CH) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
     }
   };
   auto stash_x = [&](int h, const u32x4* r) {
@@ -1003,16 +1008,24 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // Start of a slice: the four rows the first multiply needs (X rows h0 - 1, h0, h0 + 1 and dY row h0) are requested back to
+  // back — ONE memory round trip, not four load -> wait -> store rounds — and the first image's requests are issued before the
+  // ring is zeroed, so the 75 KB of LDS stores run under that round trip too.  Every row register has ONE defining load site
+  // per loop level: a second copy of these loads outside the image loop made the compiler carry the rows through register
+  // copies and wait for ALL outstanding loads at the top of every row's multiply (seen in the ISA, never shipped).
   u32x4 rx[IT], ry[IT];
   for (int bb = 0; bb < img_iters; ++bb) {
   b = b_first + bb;
   const bool live_img = b < b_last && h0 < h1;
   if (bb > 0) __syncthreads();  // the previous image's last row has been read
+  u32x4 t0[IT], t1[IT];
+  if (live_img) { load_x(h0 - 1, t0); load_x(h0, t1); load_x(h0 + 1, rx); load_y(h0, ry); }
+  if (bb == 0) {
+    for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
   if (live_img) {
-    load_x(h0 - 1, rx); stash_x(h0 - 1, rx);
-    load_x(h0, rx);     stash_x(h0, rx);
-    load_x(h0 + 1, rx); stash_x(h0 + 1, rx);
-    load_y(h0, ry);     stash_y(ry);
+    stash_x(h0 - 1, t0); stash_x(h0, t1); stash_x(h0 + 1, rx); stash_y(ry);
     load_x(h0 + 2, rx);
     load_y(h0 + 1, ry);
   }
@@ -1099,7 +1112,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  const int half = PAIR ? (int)(threadIdx.x >> 8) : 0;
+  const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: slice, rows and ring base stay in SGPRs
   unsigned char* xs = smem + half * RING;
   unsigned char* ys = xs + 3 * XROW;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -1116,27 +1129,30 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
   const int h1 = min(H, h0 + rows_per_slice);
   const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
-  for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-
   const u32x4 zero = {0u, 0u, 0u, 0u};
   int b = b_first;
+  // buffer row loads as in conv3x3_wgrad_kernel: one descriptor per (row, 64-channel tile), one offset VGPR per tensor
+  const int vo_x = ((tid >> 3) * (int)ld_x + (tid & 7) * 8) * 2, vo_y = ((tid >> 3) * (int)ld_dy + (tid & 7) * 8) * 2;
+  const int sx32 = 32 * (int)ld_x * 2, sy32 = 32 * (int)ld_dy * 2;
+  const int rec_x = ((Wi - 1) * (int)ld_x + 64) * 2, rec_y = ((W - 1) * (int)ld_dy + 64) * 2;
   auto load_x = [&](int r, u32x4* v) {  // input row r (zeros outside the image)
     const int rc = min(max(r, 0), Hi - 1);
     const unsigned short* base = X + ((long long)(b * Hi + rc) * Wi) * ld_x + k0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_x, 0x00020000);
 #pragma unroll
     for (int i = 0; i < ITX; ++i) {
       const int id = i * 256 + tid;
-      if (CHX % 256 == 0 || id < CHX) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_x + (id & 7) * 8);
+      if (CHX % 256 == 0 || id < CHX) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
     }
   };
   auto load_y = [&](int h, u32x4* v) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_y, 0x00020000);
 #pragma unroll
     for (int i = 0; i < ITY; ++i) {
       const int id = i * 256 + tid;
-      if (CHY % 256 == 0 || id < CHY) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(id >> 3) * ld_dy + (id & 7) * 8);
+      if (CHY % 256 == 0 || id < CHY) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
     }
   };
   auto stash_x = [&](int r, const u32x4* v) {
@@ -1165,16 +1181,20 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // start of a slice as in conv3x3_wgrad_kernel: the first four rows in one round trip, the first image's under the ring's zeroing
   u32x4 ra[ITX], rb[ITX], ry[ITY];
   for (int bb = 0; bb < img_iters; ++bb) {
     b = b_first + bb;
     const bool live_img = b < b_last && h0 < h1;
     if (bb > 0) __syncthreads();
+    u32x4 t0[ITX];
+    if (live_img) { load_x(2 * h0 - 1, t0); load_x(2 * h0, ra); load_x(2 * h0 + 1, rb); load_y(h0, ry); }
+    if (bb == 0) {
+      for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
     if (live_img) {
-      load_x(2 * h0 - 1, ra); stash_x(2 * h0 - 1, ra);
-      load_x(2 * h0, ra);     stash_x(2 * h0, ra);
-      load_x(2 * h0 + 1, ra); stash_x(2 * h0 + 1, ra);
-      load_y(h0, ry);         stash_y(ry);
+      stash_x(2 * h0 - 1, t0); stash_x(2 * h0, ra); stash_x(2 * h0 + 1, rb); stash_y(ry);
       load_x(2 * h0 + 2, ra);
       load_x(2 * h0 + 3, rb);
       load_y(h0 + 1, ry);
