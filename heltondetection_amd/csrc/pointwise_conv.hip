@@ -962,27 +962,31 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
   // Row loads are buffer instructions: a descriptor per (image row, 64-channel tile) built from uniform values, whose range ends
   // with the tile's last channel of the row's last pixel; the lane's byte offset inside a block of 32 pixels in ONE VGPR per
   // tensor for the whole kernel, the block's offset (i * 32 pixels) in an SGPR — instead of a 64-bit address per load and lane.
+  // Lanes past the row's last pixel (rows are not multiples of 32 pixels) fall outside the descriptor's range: the hardware
+  // returns zeros without a memory access (range check on voffset + soffset, profiles/r05_soffset_probe.log; row strides are
+  // >= the tile's 64 channels), so every load is unconditional and the compiler's vmcnt counts stay exact — with the loads
+  // under a lane predicate it waited for vmcnt(0) before every store to the ring, whatever was still in flight behind it.
   const int vo_x = ((tid >> 3) * (int)ld_x + (tid & 7) * 8) * 2, vo_y = ((tid >> 3) * (int)ld_dy + (tid & 7) * 8) * 2;
   const int sx32 = 32 * (int)ld_x * 2, sy32 = 32 * (int)ld_dy * 2;
   const int rec_x = ((W - 1) * (int)ld_x + 64) * 2, rec_y = ((W - 1) * (int)ld_dy + 64) * 2;
-  auto load_x = [&](int h, u32x4* r) {  // image row h of X (zeros outside the image)
+  // `on` = false gives the descriptor an empty range: the instruction is issued (the in-order vmcnt bookkeeping of the row
+  // sets stays the same on every path) and returns zeros without touching memory.
+  auto load_x = [&](int h, u32x4* r, bool on) {  // image row h of X (zeros outside the image)
     const int hc = min(max(h, 0), H - 1);
     const unsigned short* base = X + ((long long)(b * H + hc) * W) * ld_x + k0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_x, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_x : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      const int id = i * 256 + tid;
-      if (CH % 256 == 0 || id < CH) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
     }
   };
-  auto load_y = [&](int h, u32x4* r) {
+  auto load_y = [&](int h, u32x4* r, bool on) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_y, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_y : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      const int id = i * 256 + tid;
-      if (CH % 256 == 0 || id < CH) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
     }
   };
   auto stash_x = [&](int h, const u32x4* r) {
@@ -1013,24 +1017,32 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
   // ring is zeroed, so the 75 KB of LDS stores run under that round trip too.  Every row register has ONE defining load site
   // per loop level: a second copy of these loads outside the image loop made the compiler carry the rows through register
   // copies and wait for ALL outstanding loads at the top of every row's multiply (seen in the ISA, never shipped).
-  u32x4 rx[IT], ry[IT];
+  // D row sets travel in registers: set j holds X row h + 2 and dY row h + 1 of the output row h + 1 it will be stored for, and
+  // is requested D rows ahead.  A row's multiply (9 KS MFMAs per wave, 0.25 - 0.6 us) is shorter than one memory round trip, so
+  // with one set every row waited for its loads; two sets where the registers allow (W <= 52, and the one-wave-per-SIMD widths).
+  constexpr int D = (W <= 52 || W > 80) ? 2 : 1;
+  u32x4 rx[D][IT], ry[D][IT];
   for (int bb = 0; bb < img_iters; ++bb) {
   b = b_first + bb;
   const bool live_img = b < b_last && h0 < h1;
   if (bb > 0) __syncthreads();  // the previous image's last row has been read
   u32x4 t0[IT], t1[IT];
-  if (live_img) { load_x(h0 - 1, t0); load_x(h0, t1); load_x(h0 + 1, rx); load_y(h0, ry); }
+  if (live_img) { load_x(h0 - 1, t0, true); load_x(h0, t1, true); load_x(h0 + 1, rx[0], true); load_y(h0, ry[0], true); }
   if (bb == 0) {
     for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
   if (live_img) {
-    stash_x(h0 - 1, t0); stash_x(h0, t1); stash_x(h0 + 1, rx); stash_y(ry);
-    load_x(h0 + 2, rx);
-    load_y(h0 + 1, ry);
+    stash_x(h0 - 1, t0); stash_x(h0, t1); stash_x(h0 + 1, rx[0]); stash_y(ry[0]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) { load_x(h0 + 2 + j, rx[j], h0 + 1 + j < h1); load_y(h0 + 1 + j, ry[j], h0 + 1 + j < h1); }
   }
-  for (int hh = 0; hh < row_iters; ++hh) {
-    const int h = h0 + hh;
+  for (int hh = 0; hh < row_iters; hh += D) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    // no early exit for an odd row count: the extra body is a padded one (h >= h1: two barriers, empty-range requests), and
+    // the row sets are always requested in the same order, which is what lets the compiler wait for set j only
+    const int h = h0 + hh + j;
     const bool live = live_img && h < h1;   // uniform over the half: the padded iterations only keep the barrier count
     __syncthreads();
     if (live) {
@@ -1050,11 +1062,14 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
     }
     __syncthreads();
     if (live && h + 1 < h1) {
-      stash_x(h + 2, rx);  // into the slot row h - 1 just left
-      stash_y(ry);
-      load_x(h + 3, rx);
-      load_y(h + 2, ry);
+      stash_x(h + 2, rx[j]);  // into the slot row h - 1 just left
+      stash_y(ry[j]);
     }
+    // Requested on EVERY path (empty range when output row h + 1 + D is not this slice's): with the requests under the
+    // condition above, the compiler could not order set j's loads against the other set's and waited for all of them.
+    load_x(h + 2 + D, rx[j], live && h + 1 + D < h1);
+    load_y(h + 1 + D, ry[j], live && h + 1 + D < h1);
+  }
   }
   }
 
@@ -1135,24 +1150,22 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
   const int vo_x = ((tid >> 3) * (int)ld_x + (tid & 7) * 8) * 2, vo_y = ((tid >> 3) * (int)ld_dy + (tid & 7) * 8) * 2;
   const int sx32 = 32 * (int)ld_x * 2, sy32 = 32 * (int)ld_dy * 2;
   const int rec_x = ((Wi - 1) * (int)ld_x + 64) * 2, rec_y = ((W - 1) * (int)ld_dy + 64) * 2;
-  auto load_x = [&](int r, u32x4* v) {  // input row r (zeros outside the image)
+  auto load_x = [&](int r, u32x4* v, bool on) {  // input row r (zeros outside the image); !on: empty range, no memory access
     const int rc = min(max(r, 0), Hi - 1);
     const unsigned short* base = X + ((long long)(b * Hi + rc) * Wi) * ld_x + k0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_x, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_x : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < ITX; ++i) {
-      const int id = i * 256 + tid;
-      if (CHX % 256 == 0 || id < CHX) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
     }
   };
-  auto load_y = [&](int h, u32x4* v) {
+  auto load_y = [&](int h, u32x4* v, bool on) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec_y, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_y : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < ITY; ++i) {
-      const int id = i * 256 + tid;
-      if (CHY % 256 == 0 || id < CHY) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
     }
   };
   auto stash_x = [&](int r, const u32x4* v) {
@@ -1182,25 +1195,32 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   // start of a slice as in conv3x3_wgrad_kernel: the first four rows in one round trip, the first image's under the ring's zeroing
-  u32x4 ra[ITX], rb[ITX], ry[ITY];
+  // D row sets in registers as in conv3x3_wgrad_kernel: set j holds input rows 2 (h + 1), 2 (h + 1) + 1 and dY row h + 1
+  constexpr int D = (W <= 26 || W > 40) ? 2 : 1;
+  u32x4 ra[D][ITX], rb[D][ITX], ry[D][ITY];
   for (int bb = 0; bb < img_iters; ++bb) {
     b = b_first + bb;
     const bool live_img = b < b_last && h0 < h1;
     if (bb > 0) __syncthreads();
     u32x4 t0[ITX];
-    if (live_img) { load_x(2 * h0 - 1, t0); load_x(2 * h0, ra); load_x(2 * h0 + 1, rb); load_y(h0, ry); }
+    if (live_img) { load_x(2 * h0 - 1, t0, true); load_x(2 * h0, ra[0], true); load_x(2 * h0 + 1, rb[0], true); load_y(h0, ry[0], true); }
     if (bb == 0) {
       for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
       __syncthreads();
     }
     if (live_img) {
-      stash_x(2 * h0 - 1, t0); stash_x(2 * h0, ra); stash_x(2 * h0 + 1, rb); stash_y(ry);
-      load_x(2 * h0 + 2, ra);
-      load_x(2 * h0 + 3, rb);
-      load_y(h0 + 1, ry);
+      stash_x(2 * h0 - 1, t0); stash_x(2 * h0, ra[0]); stash_x(2 * h0 + 1, rb[0]); stash_y(ry[0]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load_x(2 * (h0 + 1 + j), ra[j], h0 + 1 + j < h1);
+        load_x(2 * (h0 + 1 + j) + 1, rb[j], h0 + 1 + j < h1);
+        load_y(h0 + 1 + j, ry[j], h0 + 1 + j < h1);
+      }
     }
-    for (int hh = 0; hh < row_iters; ++hh) {
-      const int h = h0 + hh;
+    for (int hh = 0; hh < row_iters; hh += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int h = h0 + hh + j;  // no early exit for an odd row count (see conv3x3_wgrad_kernel)
       const bool live = live_img && h < h1;   // uniform over the half
       __syncthreads();
       if (live) {
@@ -1221,13 +1241,15 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
       }
       __syncthreads();
       if (live && h + 1 < h1) {
-        stash_x(2 * h + 2, ra);  // into the slots input rows 2 h - 1 and 2 h just left
-        stash_x(2 * h + 3, rb);
-        stash_y(ry);
-        load_x(2 * h + 4, ra);
-        load_x(2 * h + 5, rb);
-        load_y(h + 2, ry);
+        stash_x(2 * h + 2, ra[j]);  // into the slots input rows 2 h - 1 and 2 h just left
+        stash_x(2 * h + 3, rb[j]);
+        stash_y(ry[j]);
       }
+      // requested on every path (empty range past the slice), as in conv3x3_wgrad_kernel
+      load_x(2 * (h + 1 + D), ra[j], live && h + 1 + D < h1);
+      load_x(2 * (h + 1 + D) + 1, rb[j], live && h + 1 + D < h1);
+      load_y(h + 1 + D, ry[j], live && h + 1 + D < h1);
+    }
     }
   }
 
