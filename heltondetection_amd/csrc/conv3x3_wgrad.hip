@@ -291,7 +291,9 @@ static bool wgrad3_use_v1(int B, int H, int W, int Cin, int Cout, int stride) {
   if (g_wgrad3_select == 1) return true;
   if (g_wgrad3_select == 2) return false;
   if (!hd_conv3x3_wgrad_supported_v1(B, H, W, Cin, Cout, stride)) return false;
-  return !(stride == 1 && W <= 26 && Cin == 256 && Cout == 256);   // 16 x 256 x 20 x 20: 36 - 40 us flat against 52
+  // every shape the row kernels take: since their 512-thread pair form went (round 5) the one case the flat kernel had won —
+  // 16 x 256 x 20 x 20 -> 256, stride 1: 36 - 40 us flat against 52 — runs 32 us on them (profiles/r05b_wgrad_rows.md)
+  return true;
 }
 #define wgrad3_v1() wgrad3_use_v1(B, H, W, Cin, Cout, stride)
 

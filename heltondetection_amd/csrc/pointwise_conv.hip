@@ -915,13 +915,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hdfuse::ReduceJ
 // the dY row; the nine taps are nine (row slot, pixel shift) views of that ring, so borders need no masks — out-of-image
 // rows are stored as zeros, out-of-image pixels are the halo.  Per 16 pixels a wave issues one dY fragment, nine X
 // fragments and nine MFMAs.  The next X row and dY row travel in registers while the current row is multiplied.
-// PAIR: a 512-thread workgroup whose two halves (waves 0-3, 4-7) are two workgroups of the plain form on two CONSECUTIVE row
-// slices, each with its own LDS ring, sharing the barriers (so both run the same padded number of iterations); at the end the
-// upper half's 9 x 16 accumulators are added to the lower half's through LDS (three passes of three taps) and ONE partial is
-// written: the slab — 37.7 MB written and read back per layer at 256 slices x tiles, the largest weight-gradient slab of
-// the step (profiles/r04_pmc_traffic.json) — halves at unchanged parallelism (8 waves per CU either way).
-template <int W, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void conv3x3_wgrad_kernel(
+//
+// Global loads are buffer instructions: a descriptor per (image row, 64-channel tile) built from uniform values, whose range
+// ends with the tile's last channel of the row's last pixel; the lane's byte offset inside a block of 32 pixels in ONE VGPR per
+// tensor for the whole kernel, the block's offset (i * 32 pixels) in an SGPR — instead of a 64-bit address per load and lane
+// (the 80-pixel instantiation spilled 12 bytes per lane with those; every instantiation is now scratch-free).  Lanes past the
+// row's last pixel (rows are not multiples of 32 pixels) fall outside the range: the hardware returns zeros without a memory
+// access (range check on voffset + soffset, profiles/r05_soffset_probe.log; row strides are >= the tile's 64 channels), and
+// a request for a row that is not this slice's gets an EMPTY range — so every load is unconditional, no row past the slice
+// is fetched, and the compiler's vmcnt counts stay exact.
+//
+// History of the variants measured on this kernel (profiles/r05b_wgrad_rows.md): a 512-thread form whose two halves walked
+// two consecutive slices and folded their accumulators through LDS (round 4: half the slab) lost 10 - 35 % per launch to
+// the shared barriers and was removed in round 5; two row sets in flight instead of one changed nothing (the row loop is
+// not bound by the load round trip).
+template <int W>
+__global__ __launch_bounds__(256, W > 80 ? 1 : 2) void conv3x3_wgrad_kernel(
     const unsigned short* __restrict__ dY, long long ld_dy, const unsigned short* __restrict__ X, long long ld_x, int B, int H,
     int N, int K, int rows_per_slice, int images_per_slice, float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
   __shared__ float4 s_part[16][17];
@@ -931,63 +940,44 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
   constexpr int RING = 3 * XROW + DYROW;
   constexpr int CH = W * 8;                       // 16-byte chunks per image row of a 64-channel tile
   constexpr int IT = (CH + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per half: [3 X rows | dY row]; later the fold area
-  const int n_groups = PAIR ? (n_slices + 1) / 2 : n_slices;            // slab partials = grid rows that multiply
-  if ((int)blockIdx.y >= n_groups) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
-    if (PAIR && threadIdx.x >= 256) return;
-    const long long blk = (long long)(blockIdx.y - n_groups) * gridDim.x + blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 X rows | dY row]
+  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: slice, rows and ring base stay in SGPRs
-  unsigned char* xs = smem + half * RING;
+  unsigned char* xs = smem;
   unsigned char* ys = xs + 3 * XROW;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = K / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   // a slice is a range of image rows of one image (rows_per_slice < H), or images_per_slice whole images
-  const int slice = PAIR ? (int)blockIdx.y * 2 + half : (int)blockIdx.y;
-  const bool live_slice = slice < n_slices;       // an odd slice count leaves the last upper half without work
+  const int slice = (int)blockIdx.y;
   const int spi = (H + rows_per_slice - 1) / rows_per_slice;  // slices per image (1 when a slice holds whole images)
   const int b_first = spi > 1 ? slice / spi : slice * images_per_slice;
-  const int b_last = !live_slice ? b_first : (spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice));
+  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
   const int h0 = spi > 1 ? (slice % spi) * rows_per_slice : 0;
   const int h1 = min(H, h0 + rows_per_slice);
-  // both halves run the same number of (image, row) iterations: the barriers are the workgroup's
-  const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
   const u32x4 zero = {0u, 0u, 0u, 0u};
   int b = b_first;
-  // Row loads are buffer instructions: a descriptor per (image row, 64-channel tile) built from uniform values, whose range ends
-  // with the tile's last channel of the row's last pixel; the lane's byte offset inside a block of 32 pixels in ONE VGPR per
-  // tensor for the whole kernel, the block's offset (i * 32 pixels) in an SGPR — instead of a 64-bit address per load and lane.
-  // Lanes past the row's last pixel (rows are not multiples of 32 pixels) fall outside the descriptor's range: the hardware
-  // returns zeros without a memory access (range check on voffset + soffset, profiles/r05_soffset_probe.log; row strides are
-  // >= the tile's 64 channels), so every load is unconditional and the compiler's vmcnt counts stay exact — with the loads
-  // under a lane predicate it waited for vmcnt(0) before every store to the ring, whatever was still in flight behind it.
   const int vo_x = ((tid >> 3) * (int)ld_x + (tid & 7) * 8) * 2, vo_y = ((tid >> 3) * (int)ld_dy + (tid & 7) * 8) * 2;
   const int sx32 = 32 * (int)ld_x * 2, sy32 = 32 * (int)ld_dy * 2;
   const int rec_x = ((W - 1) * (int)ld_x + 64) * 2, rec_y = ((W - 1) * (int)ld_dy + 64) * 2;
-  // `on` = false gives the descriptor an empty range: the instruction is issued (the in-order vmcnt bookkeeping of the row
-  // sets stays the same on every path) and returns zeros without touching memory.
-  auto load_x = [&](int h, u32x4* r, bool on) {  // image row h of X (zeros outside the image)
+  auto load_x = [&](int h, u32x4* r, bool on) {  // image row h of X (zeros outside the image); !on: empty range, no access
     const int hc = min(max(h, 0), H - 1);
     const unsigned short* base = X + ((long long)(b * H + hc) * W) * ld_x + k0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_x : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
-    }
+    for (int i = 0; i < IT; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
   };
   auto load_y = [&](int h, u32x4* r, bool on) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_y : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
-    }
+    for (int i = 0; i < IT; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
   };
   auto stash_x = [&](int h, const u32x4* r) {
     unsigned char* slot = xs + ((h + 3) % 3) * XROW;
@@ -1012,40 +1002,25 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // Start of a slice: the four rows the first multiply needs (X rows h0 - 1, h0, h0 + 1 and dY row h0) are requested back to
-  // back — ONE memory round trip, not four load -> wait -> store rounds — and the first image's requests are issued before the
-  // ring is zeroed, so the 75 KB of LDS stores run under that round trip too.  Every row register has ONE defining load site
-  // per loop level: a second copy of these loads outside the image loop made the compiler carry the rows through register
-  // copies and wait for ALL outstanding loads at the top of every row's multiply (seen in the ISA, never shipped).
-  // D row sets travel in registers: set j holds X row h + 2 and dY row h + 1 of the output row h + 1 it will be stored for, and
-  // is requested D rows ahead.  A row's multiply (9 KS MFMAs per wave, 0.25 - 0.6 us) is shorter than one memory round trip, so
-  // with one set every row waited for its loads; two sets where the registers allow (W <= 52, and the one-wave-per-SIMD widths).
-  constexpr int D = (W <= 52 || W > 80) ? 2 : 1;
-  u32x4 rx[D][IT], ry[D][IT];
-  for (int bb = 0; bb < img_iters; ++bb) {
-  b = b_first + bb;
-  const bool live_img = b < b_last && h0 < h1;
-  if (bb > 0) __syncthreads();  // the previous image's last row has been read
-  u32x4 t0[IT], t1[IT];
-  if (live_img) { load_x(h0 - 1, t0, true); load_x(h0, t1, true); load_x(h0 + 1, rx[0], true); load_y(h0, ry[0], true); }
-  if (bb == 0) {
-    for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-  }
-  if (live_img) {
-    stash_x(h0 - 1, t0); stash_x(h0, t1); stash_x(h0 + 1, rx[0]); stash_y(ry[0]);
-#pragma unroll
-    for (int j = 0; j < D; ++j) { load_x(h0 + 2 + j, rx[j], h0 + 1 + j < h1); load_y(h0 + 1 + j, ry[j], h0 + 1 + j < h1); }
-  }
-  for (int hh = 0; hh < row_iters; hh += D) {
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    // no early exit for an odd row count: the extra body is a padded one (h >= h1: two barriers, empty-range requests), and
-    // the row sets are always requested in the same order, which is what lets the compiler wait for set j only
-    const int h = h0 + hh + j;
-    const bool live = live_img && h < h1;   // uniform over the half: the padded iterations only keep the barrier count
-    __syncthreads();
-    if (live) {
+  // Start of an image's rows: the four rows the first multiply needs (X rows h0 - 1, h0, h0 + 1 and dY row h0) are requested
+  // back to back — ONE memory round trip, not four load -> wait -> store rounds — and the first image's requests are issued
+  // before the ring is zeroed, so the 75 KB of LDS stores run under that round trip too.  Every row register has ONE defining
+  // load site per loop level: a second copy of these loads outside the image loop made the compiler carry the rows through
+  // register copies and wait for ALL outstanding loads at the top of every row's multiply (seen in the ISA, never shipped).
+  u32x4 rx[IT], ry[IT];
+  for (b = b_first; b < b_last; ++b) {
+    if (b > b_first) __syncthreads();  // the previous image's last row has been read
+    u32x4 t0[IT], t1[IT];
+    load_x(h0 - 1, t0, true); load_x(h0, t1, true); load_x(h0 + 1, rx, true); load_y(h0, ry, true);
+    if (b == b_first) {
+      for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
+    stash_x(h0 - 1, t0); stash_x(h0, t1); stash_x(h0 + 1, rx); stash_y(ry);
+    load_x(h0 + 2, rx, h0 + 1 < h1);
+    load_y(h0 + 1, ry, h0 + 1 < h1);
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
@@ -1059,42 +1034,17 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
           }
         }
       }
+      __syncthreads();
+      if (h + 1 < h1) {
+        stash_x(h + 2, rx);  // into the slot row h - 1 just left
+        stash_y(ry);
+      }
+      load_x(h + 3, rx, h + 2 < h1);  // requested on every path: the rows of output row h + 2, an empty range past the slice
+      load_y(h + 2, ry, h + 2 < h1);
     }
-    __syncthreads();
-    if (live && h + 1 < h1) {
-      stash_x(h + 2, rx[j]);  // into the slot row h - 1 just left
-      stash_y(ry[j]);
-    }
-    // Requested on EVERY path (empty range when output row h + 1 + D is not this slice's): with the requests under the
-    // condition above, the compiler could not order set j's loads against the other set's and waited for all of them.
-    load_x(h + 2 + D, rx[j], live && h + 1 + D < h1);
-    load_y(h + 1 + D, ry[j], live && h + 1 + D < h1);
-  }
-  }
   }
 
-  if (PAIR) {  // upper half -> LDS -> lower half, three taps at a time (4 waves x 3 x 16 registers x 256 B = 48 KB)
-    float* fold = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * 16 * 64;
-#pragma unroll
-    for (int p3 = 0; p3 < 3; ++p3) {
-      __syncthreads();   // the rings (first pass) / the previous pass's reads are done
-      if (half == 1) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) fold[(t * 16 + r) * 64 + lane] = acc[p3 * 3 + t][r];
-      }
-      __syncthreads();
-      if (half == 0) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[p3 * 3 + t][r] += fold[(t * 16 + r) * 64 + lane];
-      }
-    }
-    if (half == 1) return;
-  }
-  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice group][n][tap][k]
+  // C/D map: col (k) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); slab[slice][n][tap][k]
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
   const int k = k0 + wk * 32 + (lane & 31);
   const int nb = n0 + wn * 32 + 4 * (lane >> 5);
@@ -1108,8 +1058,8 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 80 ? 1 : 2)) void
 // row is stored de-interleaved — even pixels E[j] = x[2 j] and odd pixels O[j] = x[2 j + 1], each with the one-pixel zero
 // halo — so the three column taps are again contiguous views: kx = 0 -> O[wo - 1], kx = 1 -> E[wo], kx = 2 -> O[wo].  The
 // ring holds input rows 2 ho - 1, 2 ho, 2 ho + 1; advancing one output row brings in two input rows.  H, W: OUTPUT size.
-template <int W, bool PAIR>   // PAIR: as for conv3x3_wgrad_kernel
-__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void conv3x3s2_wgrad_kernel(
+template <int W>
+__global__ __launch_bounds__(256, W > 40 ? 1 : 2) void conv3x3s2_wgrad_kernel(
     const unsigned short* __restrict__ dY, long long ld_dy, const unsigned short* __restrict__ X, long long ld_x, int B, int H,
     int N, int K, int rows_per_slice, int images_per_slice, float* __restrict__ slab, int n_slices, const hdfuse::ReduceJob job) {
   __shared__ float4 s_part[16][17];
@@ -1119,30 +1069,25 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
   constexpr int RING = 3 * XROW + DYROW;
   constexpr int CHX = 2 * W * 8, CHY = W * 8;  // 16-byte chunks per input row / per dY row of a 64-channel tile
   constexpr int ITX = (CHX + 255) / 256, ITY = (CHY + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per half: [3 input rows (E | O planes) | dY row]
-  const int n_groups = PAIR ? (n_slices + 1) / 2 : n_slices;
-  if ((int)blockIdx.y >= n_groups) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
-    if (PAIR && threadIdx.x >= 256) return;
-    const long long blk = (long long)(blockIdx.y - n_groups) * gridDim.x + blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 input rows (E | O planes) | dY row]
+  if ((int)blockIdx.y >= n_slices) {  // the slice sum of the previous weight-gradient launch rides along (hd_wgrad_job)
+    const long long blk = (long long)(blockIdx.y - n_slices) * gridDim.x + blockIdx.x;
     if (blk < hdfuse::reduce_blocks(job.count)) hdfuse::reduce_block(job, blk, s_part);
     return;
   }
-  const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: slice, rows and ring base stay in SGPRs
-  unsigned char* xs = smem + half * RING;
+  unsigned char* xs = smem;
   unsigned char* ys = xs + 3 * XROW;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = K / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   const int Hi = 2 * H, Wi = 2 * W;
-  const int slice = PAIR ? (int)blockIdx.y * 2 + half : (int)blockIdx.y;
-  const bool live_slice = slice < n_slices;
+  const int slice = (int)blockIdx.y;
   const int spi = (H + rows_per_slice - 1) / rows_per_slice;
   const int b_first = spi > 1 ? slice / spi : slice * images_per_slice;
-  const int b_last = !live_slice ? b_first : (spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice));
+  const int b_last = spi > 1 ? b_first + 1 : min(B, b_first + images_per_slice);
   const int h0 = spi > 1 ? (slice % spi) * rows_per_slice : 0;
   const int h1 = min(H, h0 + rows_per_slice);
-  const int img_iters = spi > 1 ? 1 : images_per_slice, row_iters = spi > 1 ? rows_per_slice : H;
 
   const u32x4 zero = {0u, 0u, 0u, 0u};
   int b = b_first;
@@ -1155,18 +1100,14 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
     const unsigned short* base = X + ((long long)(b * Hi + rc) * Wi) * ld_x + k0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_x : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < ITX; ++i) {
-      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
-    }
+    for (int i = 0; i < ITX; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_x, i * sx32, 0);
   };
   auto load_y = [&](int h, u32x4* v, bool on) {
     const int hc = min(h, H - 1);
     const unsigned short* base = dY + ((long long)(b * H + hc) * W) * ld_dy + n0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, on ? rec_y : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < ITY; ++i) {
-      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
-    }
+    for (int i = 0; i < ITY; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_y, i * sy32, 0);
   };
   auto stash_x = [&](int r, const u32x4* v) {
     unsigned char* slot = xs + ((r + 3) % 3) * XROW;
@@ -1194,86 +1135,49 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (W > 40 ? 1 : 2)) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // start of a slice as in conv3x3_wgrad_kernel: the first four rows in one round trip, the first image's under the ring's zeroing
-  // D row sets in registers as in conv3x3_wgrad_kernel: set j holds input rows 2 (h + 1), 2 (h + 1) + 1 and dY row h + 1
-  constexpr int D = (W <= 26 || W > 40) ? 2 : 1;
-  u32x4 ra[D][ITX], rb[D][ITX], ry[D][ITY];
-  for (int bb = 0; bb < img_iters; ++bb) {
-    b = b_first + bb;
-    const bool live_img = b < b_last && h0 < h1;
-    if (bb > 0) __syncthreads();
+  // start of an image's rows as in conv3x3_wgrad_kernel: the first four rows in one round trip, the first image's under the
+  // ring's zeroing
+  u32x4 ra[ITX], rb[ITX], ry[ITY];
+  for (b = b_first; b < b_last; ++b) {
+    if (b > b_first) __syncthreads();
     u32x4 t0[ITX];
-    if (live_img) { load_x(2 * h0 - 1, t0, true); load_x(2 * h0, ra[0], true); load_x(2 * h0 + 1, rb[0], true); load_y(h0, ry[0], true); }
-    if (bb == 0) {
+    load_x(2 * h0 - 1, t0, true); load_x(2 * h0, ra, true); load_x(2 * h0 + 1, rb, true); load_y(h0, ry, true);
+    if (b == b_first) {
       for (int i = tid; i < RING / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
       __syncthreads();
     }
-    if (live_img) {
-      stash_x(2 * h0 - 1, t0); stash_x(2 * h0, ra[0]); stash_x(2 * h0 + 1, rb[0]); stash_y(ry[0]);
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        load_x(2 * (h0 + 1 + j), ra[j], h0 + 1 + j < h1);
-        load_x(2 * (h0 + 1 + j) + 1, rb[j], h0 + 1 + j < h1);
-        load_y(h0 + 1 + j, ry[j], h0 + 1 + j < h1);
-      }
-    }
-    for (int hh = 0; hh < row_iters; hh += D) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int h = h0 + hh + j;  // no early exit for an odd row count (see conv3x3_wgrad_kernel)
-      const bool live = live_img && h < h1;   // uniform over the half
+    stash_x(2 * h0 - 1, t0); stash_x(2 * h0, ra); stash_x(2 * h0 + 1, rb); stash_y(ry);
+    load_x(2 * h0 + 2, ra, h0 + 1 < h1);
+    load_x(2 * h0 + 3, rb, h0 + 1 < h1);
+    load_y(h0 + 1, ry, h0 + 1 < h1);
+    for (int h = h0; h < h1; ++h) {
       __syncthreads();
-      if (live) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = tr_fragment(ys, SX, wn * 32, ks * 16, lane);
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
-            const unsigned char* slot = xs + ((2 * h + ky - 1 + 3) % 3) * XROW;
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* slot = xs + ((2 * h + ky - 1 + 3) % 3) * XROW;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              // kx = 0: O[wo - 1] (pixel row wo), kx = 1: E[wo] (pixel row wo + 1), kx = 2: O[wo] (pixel row wo + 1)
-              const bf16x8 bq = tr_fragment(slot + (kx == 1 ? 0 : PLANE), SX, wk * 32, ks * 16 + (kx == 0 ? 0 : 1), lane);
-              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
-            }
+          for (int kx = 0; kx < 3; ++kx) {
+            // kx = 0: O[wo - 1] (pixel row wo), kx = 1: E[wo] (pixel row wo + 1), kx = 2: O[wo] (pixel row wo + 1)
+            const bf16x8 bq = tr_fragment(slot + (kx == 1 ? 0 : PLANE), SX, wk * 32, ks * 16 + (kx == 0 ? 0 : 1), lane);
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[ky * 3 + kx], 0, 0, 0);
           }
         }
       }
       __syncthreads();
-      if (live && h + 1 < h1) {
-        stash_x(2 * h + 2, ra[j]);  // into the slots input rows 2 h - 1 and 2 h just left
-        stash_x(2 * h + 3, rb[j]);
-        stash_y(ry[j]);
+      if (h + 1 < h1) {
+        stash_x(2 * h + 2, ra);  // into the slots input rows 2 h - 1 and 2 h just left
+        stash_x(2 * h + 3, rb);
+        stash_y(ry);
       }
-      // requested on every path (empty range past the slice), as in conv3x3_wgrad_kernel
-      load_x(2 * (h + 1 + D), ra[j], live && h + 1 + D < h1);
-      load_x(2 * (h + 1 + D) + 1, rb[j], live && h + 1 + D < h1);
-      load_y(h + 1 + D, ry[j], live && h + 1 + D < h1);
-    }
+      load_x(2 * h + 4, ra, h + 2 < h1);  // on every path; an empty range past the slice
+      load_x(2 * h + 5, rb, h + 2 < h1);
+      load_y(h + 2, ry, h + 2 < h1);
     }
   }
 
-  if (PAIR) {  // upper half -> LDS -> lower half, three taps at a time
-    float* fold = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * 16 * 64;
-#pragma unroll
-    for (int p3 = 0; p3 < 3; ++p3) {
-      __syncthreads();
-      if (half == 1) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) fold[(t * 16 + r) * 64 + lane] = acc[p3 * 3 + t][r];
-      }
-      __syncthreads();
-      if (half == 0) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[p3 * 3 + t][r] += fold[(t * 16 + r) * 64 + lane];
-      }
-    }
-    if (half == 1) return;
-  }
   float* out = slab + (size_t)blockIdx.y * N * 9 * K;
   const int k = k0 + wk * 32 + (lane & 31);
   const int nb = n0 + wn * 32 + 4 * (lane >> 5);
@@ -1289,20 +1193,16 @@ static inline bool conv3x3_width_ok(int W) { return W == 20 || W == 26 || W == 4
 
 struct Wgrad3Plan {
   int tiles, rows_per_slice, images_per_slice, slices;
-  bool pair;     // two consecutive slices per 512-thread workgroup, folded in LDS: the slab holds (slices + 1) / 2 partials
-  int partials;  // slab partials = grid rows that multiply
+  int partials;  // slab partials = grid rows that multiply (= slices)
 };
-static bool wgrad3_pair_fits(int W, int stride) {   // two rings (+ the static reduce area) within 160 KB of LDS
-  const int WP = (W + 15) / 16 * 16;
-  const size_t ring = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
-  return 2 * ring + 4608 <= 160 * 1024;
-}
 inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout, int W = 0, int stride = 1) {
   // Every workgroup writes a 64 x 9 x 64 float32 partial (147 KB) that the reduce kernel reads back, so the slab traffic
   // grows with the workgroup count while the operands do not (75 MB for the 128-channel 40 x 40 layer at 512 workgroups
   // against 13 MB of operands): the partial kernel is bound by that write.  Measured per launch in the step, W = 40 / 80 / 20
   // stride 1: 512 workgroups 24.5 / 24.1 / 26.5 us (+ 6.9 us reduce); 256: 23.0 / 22.8 / 29.8 (+ 5.9); 128: 36 / 33 / 47
-  // (+ 4.9, the row loop then dominates).  Two rows of loads in flight instead of one changed nothing.
+  // (+ 4.9, the row loop then dominates).  Two rows of loads in flight instead of one changed nothing.  Round 5 (final
+  // kernels, per-launch probe incl. the riding slice sum, profiles/r05b_wgrad_rows.md): 256 slices x tiles stays the
+  // choice — 512 and 1024 are slower on every YOLOv5s shape but the 64-channel 80-pixel one (20.0 - 21.0 against 18.8 us).
   Wgrad3Plan p;
   p.tiles = (Cout / 64) * (Cin / 64);
   int want = 256 / p.tiles;
@@ -1319,8 +1219,7 @@ inline Wgrad3Plan wgrad3_plan(int B, int H, int Cin, int Cout, int W = 0, int st
     p.images_per_slice = (B + want - 1) / want;
     p.slices = (B + p.images_per_slice - 1) / p.images_per_slice;
   }
-  p.pair = W > 0 && p.slices >= 2 && wgrad3_pair_fits(W, stride);
-  p.partials = p.pair ? (p.slices + 1) / 2 : p.slices;
+  p.partials = p.slices;
   return p;
 }
 
@@ -1651,27 +1550,22 @@ hd_status hd_conv3x3_wgrad_partial_v1(const void* dy, int64_t dy_row_stride, con
   const dim3 grid((unsigned)p.tiles, (unsigned)p.partials + piggyback_rows(jv, (unsigned)p.tiles));
   const int WP = (W + 15) / 16 * 16;
   const size_t ring = (size_t)(3 * stride * (WP + 2) + WP) * (64 * 2 + 64);
-  const size_t lds = p.pair ? (2 * ring > 49152 ? 2 * ring : 49152) : ring;
-  const dim3 block(p.pair ? 512 : 256);
-  // HD_WG3(WW, S2, PR): one instantiation; the pair form only where two rings fit (wgrad3_pair_fits)
-#define HD_WG3(WW, KERNEL, PR)                                                                                          \
-  (void)hd_launch(KERNEL<WW, PR>, grid, block, lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, p.rows_per_slice, \
+  const size_t lds = ring;
+  const dim3 block(256);
+#define HD_WG3(WW, KERNEL)                                                                                         \
+  (void)hd_launch(KERNEL<WW>, grid, block, lds, s, a, dy_row_stride, b, x_row_stride, B, H, Cout, Cin, p.rows_per_slice, \
                   p.images_per_slice, slab, p.slices, jv)
-#define HD_WGRAD3_CASE(WW, S1PAIR, S2PAIR)                                                                              \
-  case WW:                                                                                                              \
-    if (stride == 2) {                                                                                                  \
-      if (S2PAIR && p.pair) HD_WG3(WW, conv3x3s2_wgrad_kernel, S2PAIR); else HD_WG3(WW, conv3x3s2_wgrad_kernel, false);      \
-    } else {                                                                                                            \
-      if (S1PAIR && p.pair) HD_WG3(WW, conv3x3_wgrad_kernel, S1PAIR); else HD_WG3(WW, conv3x3_wgrad_kernel, false);          \
-    }                                                                                                                   \
+#define HD_WGRAD3_CASE(WW)                                                                          \
+  case WW:                                                                                          \
+    if (stride == 2) HD_WG3(WW, conv3x3s2_wgrad_kernel); else HD_WG3(WW, conv3x3_wgrad_kernel);     \
     break;
   switch (W) {
-    HD_WGRAD3_CASE(20, true, true)
-    HD_WGRAD3_CASE(26, true, true)
-    HD_WGRAD3_CASE(40, true, true)
-    HD_WGRAD3_CASE(52, true, false)
-    HD_WGRAD3_CASE(80, true, false)
-    HD_WGRAD3_CASE(104, false, false)
+    HD_WGRAD3_CASE(20)
+    HD_WGRAD3_CASE(26)
+    HD_WGRAD3_CASE(40)
+    HD_WGRAD3_CASE(52)
+    HD_WGRAD3_CASE(80)
+    HD_WGRAD3_CASE(104)
     default: return HD_ERR_SHAPE;
   }
 #undef HD_WGRAD3_CASE

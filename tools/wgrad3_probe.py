@@ -12,6 +12,9 @@ dev = torch.device("cuda:0")
 # (B, Cin, Ho, Wo, Cout, stride)
 SHAPES = [(16, 64, 80, 80, 64, 1), (16, 128, 40, 40, 128, 1), (16, 256, 20, 20, 256, 1), (16, 64, 80, 80, 128, 2), (16, 128, 40, 40, 256, 2),
           (16, 256, 20, 20, 512, 2), (16, 128, 40, 40, 128, 2), (16, 256, 20, 20, 256, 2)]
+if os.environ.get("WGRAD3_SHAPES") == "frcnn":  # BASELINE config 3 (ResNet50 + PAFPN, 832^2 bs16): 26 / 52 / 104-pixel rows
+    SHAPES = [(16, 128, 104, 104, 128, 1), (16, 256, 52, 52, 256, 1), (16, 512, 26, 26, 512, 1), (16, 256, 104, 104, 256, 1),
+              (16, 256, 26, 26, 256, 1), (16, 256, 52, 52, 256, 2), (16, 256, 26, 26, 256, 2), (16, 128, 104, 104, 128, 2)]
 from heltondetection_amd import _lib  # noqa: E402
 sel = int(os.environ.get("WGRAD3_SELECT", "0"))
 _lib.load().hd_conv3x3_wgrad_select(sel)
