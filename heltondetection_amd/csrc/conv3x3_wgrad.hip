@@ -283,9 +283,10 @@ hd_status hd_conv3x3_wgrad_partial_v1(const void* dy, int64_t dy_row_stride, con
 // Which kernel takes a shape.  Measured per YOLOv5s layer (tools/wgrad3_probe.py, profiles/r05_wgrad3.md): the 64 x 64-tile row
 // kernels of round 4 read every operand in whole 128-byte lines, once per 64-channel tile; the flat kernel's 32 x 32 tiles read
 // 64-byte half lines once per 32-channel tile — 4 x the cache-line traffic, which overflows the 4 MB L2 of an XCD on the 40- and
-// 80-pixel levels (stamps: 6.7 - 8 us to copy a 56 KB block).  The flat kernel wins where the picture is small and the
-// channel count large (20 x 20, 256 -> 256, stride 1: 36 - 40 us against 52) and is the only one for 32-channel layers and
-// for widths other than 20 / 26 / 40 / 52 / 80 / 104.  hd_conv3x3_wgrad_select forces one or the other (tests, probes).
+// 80-pixel levels (stamps: 6.7 - 8 us to copy a 56 KB block).  The flat kernel had won where the picture is small and the
+// channel count large (20 x 20, 256 -> 256, stride 1: 36 - 40 us against the pair-form row kernel's 52); without the pair form
+// the row kernel runs that shape in 32 us, so the flat kernel is now the one for what the row kernels do not take: 32-channel
+// layers and widths other than 20 / 26 / 40 / 52 / 80 / 104.  hd_conv3x3_wgrad_select forces one or the other (tests, probes).
 static int g_wgrad3_select = 0;   // hd_conv3x3_wgrad_select: 0 auto, 1 the row kernels only, 2 the flat kernel wherever it can run
 static bool wgrad3_use_v1(int B, int H, int W, int Cin, int Cout, int stride) {
   if (g_wgrad3_select == 1) return true;

@@ -926,9 +926,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hdfuse::ReduceJ
 // is fetched, and the compiler's vmcnt counts stay exact.
 //
 // History of the variants measured on this kernel (profiles/r05b_wgrad_rows.md): a 512-thread form whose two halves walked
-// two consecutive slices and folded their accumulators through LDS (round 4: half the slab) lost 10 - 35 % per launch to
-// the shared barriers and was removed in round 5; two row sets in flight instead of one changed nothing (the row loop is
-// not bound by the load round trip).
+// two consecutive slices and folded their accumulators through LDS (round 4: half the slab) ran 10 - 35 % slower per launch
+// than two independent 256-thread workgroups per CU (its halves share every barrier and so multiply and store in lock step)
+// and was removed in round 5; two row sets in flight instead of one changed nothing (the row loop is not bound by the load
+// round trip).
 template <int W>
 __global__ __launch_bounds__(256, W > 80 ? 1 : 2) void conv3x3_wgrad_kernel(
     const unsigned short* __restrict__ dY, long long ld_dy, const unsigned short* __restrict__ X, long long ld_x, int B, int H,
