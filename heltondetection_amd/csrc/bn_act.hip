@@ -725,7 +725,12 @@ extern "C" hd_status hd_bn_act_bwd_reduce(const void* x, const void* dy, int64_t
   if (!hd_aligned16(x) || !hd_aligned16(dy) || (res && !hd_aligned16(res))) return HD_ERR_ALIGN;
   const int V = dtype == 0 ? 4 : 8;
   const long long nvec = R * (long long)(C / V);
-  const Launch l = plan(nvec / 8 + 1, C / V, 512);  // ~8 vectors per lane, <= 2 workgroups per CU
+  // ~4 vectors per lane, <= 2 workgroups per CU.  Re-swept in the YOLOv5s step of round 5's final build (alternating runs on one
+  // box, profiles/r05b_bn_plan_scan.log): 8 vectors per lane (the forward statistics' choice, 100 workgroups for a 3.3 MB
+  // layer) 3315 images/s, 4 / 3 vectors 3348 / 3347 (+1.0 %), 6 vectors 3323, 2 vectors on <= 2048 workgroups 3299, 16 on
+  // <= 256 3187; caps of 256 / 768 workgroups at 4 vectors 3278 / 3337.  Most layers are small enough that the cap does not
+  // bind, so the halved per-lane loop is what counts; the layers of config 3 (100 - 350 MB) sit on the cap either way.
+  const Launch l = plan(nvec / 4 + 1, C / V, 512);
   const size_t lds = reduce_lds_bytes(l, C / V, C);
   hipStream_t s = (hipStream_t)stream;
 #define HD_RED_R(T, A, RS_, XT)                                                                                    \
