@@ -185,7 +185,10 @@ def pmc_traffic(kernel, shape: str = ""):
 
 TRAFFIC_SOURCE = "profiles/r05_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build: eager " \
                  "YOLOv5s 640x640 bs16 train steps (tools/prof_r05.sh: families = bytes per train step, step kernels = bytes per launch) " \
-                 "and the single-kernel probe at the micro leg's shapes (tools/pmc_traffic_r05.sh); null = no entry for this workload)"
+                 "and the single-kernel probe at the micro leg's shapes (tools/pmc_traffic_r05.sh); null = no entry for this workload).  " \
+                 "The counter run predates the round's last two changes: the 3x3 weight gradients' 512-thread pair form was removed after " \
+                 "it (twice the partial slabs: round 4's counter A/B of exactly that switch measured +0.3 GB per step on the convolution " \
+                 "family, so 6.97 rather than 6.67 GB is the figure to expect), and bn_bwd_reduce runs on twice the workgroups (same bytes)"
 
 
 def usable_cores() -> int:
